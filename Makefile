@@ -1,0 +1,29 @@
+# Build everything in-tree (the .so files travel to the GPU box with the gpurun snapshot).
+#   make hip     -> lt-mapper_amd/libltm_hip.so   (product: C ABI + gfx950 kernels)
+#   make oracle  -> oracle/libltm_oracle.so       (test infrastructure: CPU restatement of the reference)
+#   make host    -> lt-mapper_amd/host/ltm_run    (C++ mirror of Removerter/Session + CLI)
+HIPCC ?= /opt/rocm/bin/hipcc
+ARCH  ?= gfx950
+PKG    = lt-mapper_amd
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fPIC -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-result
+
+all: hip oracle host
+
+hip: $(PKG)/libltm_hip.so
+$(PKG)/csrc/ltm_kernels.o: $(PKG)/csrc/ltm_kernels.hip $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_device_math.h
+	$(HIPCC) $(HIPFLAGS) -c $< -o $@
+$(PKG)/csrc/ltm_api.o: $(PKG)/csrc/ltm_api.cpp $(PKG)/csrc/ltm_kernels.h include/ltm.h
+	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
+$(PKG)/libltm_hip.so: $(PKG)/csrc/ltm_kernels.o $(PKG)/csrc/ltm_api.o
+	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
+
+oracle:
+	$(MAKE) -C oracle
+
+host:
+	@if [ -f $(PKG)/host/Makefile ]; then $(MAKE) -C $(PKG)/host; fi
+
+clean:
+	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so
+	$(MAKE) -C oracle clean
+.PHONY: all hip oracle host clean

@@ -1,0 +1,158 @@
+/*
+ * ltm.h -- C ABI of libltm_hip.so: the MI355X (gfx950) implementation of the LT-removert /
+ * LT-map hot path of gisbi-kim/lt-mapper (package `removert`).
+ *
+ * The reference has no plugin/FFI boundary: Removerter/Session are
+ * monolithic C++ classes.  This header is the boundary a maintainer binds instead of the
+ * PCL/OpenCV/OpenMP bodies of the functions cited on each entry point below; the host-side
+ * mirror of the class surface that calls it lives in lt-mapper_amd/host/ (C++) and
+ * the ctypes binding lt-mapper_amd/capi.py (used by the tests and bench.py).  INTEGRATION.md shows the
+ * reference-side patch.
+ *
+ * Conventions
+ *  - C linkage, POD only, no torch/PCL/Eigen types.  Every call returns LTM_OK (0) or a
+ *    negative LTM_E_* code; the library never throws and never exits.  ltm_last_error()
+ *    gives the message for the last failing call on that context.
+ *  - A context owns one HIP stream and all device memory reachable through its handles.
+ *    It is NOT thread-safe: call it from one host thread (as the reference's run() does).
+ *  - Clouds are XYZI float32, 16 B / point on the device.  Host buffers are described by a
+ *    byte stride (16 = packed, 32 = pcl::PointXYZI: xyz+pad, intensity+pad).
+ *  - Matrices are 4x4 row-major double (the layout of the pose text files, Session.cpp:102-114).
+ *  - The library never keeps a host pointer after a call returns.  Calls are synchronous
+ *    with respect to the host unless stated otherwise.
+ *  - There is no CPU fallback: without a usable gfx950 device ltm_create() fails.
+ */
+#ifndef LTM_H
+#define LTM_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LTM_ABI_VERSION 1
+
+enum {
+    LTM_OK = 0,
+    LTM_E_INVALID = -1,    /* bad argument / bad handle */
+    LTM_E_DEVICE = -2,     /* HIP runtime error, no device */
+    LTM_E_NOMEM = -3,      /* device or host allocation failed */
+    LTM_E_UNSUPPORTED = -4 /* outside the supported domain (e.g. octree depth > 21) */
+};
+
+typedef struct ltm_ctx ltm_ctx;
+typedef uint64_t ltm_cloud;   /* device-resident XYZI cloud; 0 is never a valid handle */
+typedef uint64_t ltm_scanset; /* N per-keyframe clouds packed in one device array + offsets[N+1] */
+typedef uint64_t ltm_poses;   /* N keyframe poses + inverse poses (double, device + host copy) */
+
+/* RosParamServer.cpp:15-33 -- the parameters the hot path reads */
+typedef struct {
+    float  vfov, hfov;        /* removert/sequence_vfov, sequence_hfov (defaults 50, 360) */
+    double lidar2base[16];    /* removert/ExtrinsicLiDARtoPoseBase; its inverse is derived inside */
+    int    device;            /* HIP device ordinal (LOCAL_RANK for multi-process runs) */
+    int    max_kf_batch;      /* keyframes whose range images are resident at once; 0 = default (512) */
+} ltm_config;
+
+int         ltm_abi_version(void);
+int         ltm_create(const ltm_config* cfg, ltm_ctx** out);
+void        ltm_destroy(ltm_ctx* ctx);
+const char* ltm_last_error(const ltm_ctx* ctx);
+int         ltm_synchronize(ltm_ctx* ctx);
+/* the hipStream_t every kernel of this context is launched on (for events / interop) */
+void*       ltm_stream(ltm_ctx* ctx);
+
+/* ------------------------------------------------------------------ clouds ---- */
+int ltm_cloud_upload(ltm_ctx*, const void* pts, size_t n, size_t stride_bytes, ltm_cloud* out);
+int ltm_cloud_from_device(ltm_ctx*, const void* dev_xyzi, size_t n, ltm_cloud* out);  /* D2D copy of packed float4 */
+int ltm_cloud_size(ltm_ctx*, ltm_cloud, size_t* n);
+int ltm_cloud_download(ltm_ctx*, ltm_cloud, void* dst, size_t cap_pts, size_t stride_bytes);
+int ltm_cloud_device_ptr(ltm_ctx*, ltm_cloud, const void** dev_xyzi);                 /* borrowed, valid until free */
+int ltm_cloud_clone(ltm_ctx*, ltm_cloud, ltm_cloud* out);                              /* `*a = *b` deep copies */
+int ltm_cloud_concat(ltm_ctx*, const ltm_cloud* in, size_t n, ltm_cloud* out);         /* `*a += *b` (order kept) */
+int ltm_cloud_free(ltm_ctx*, ltm_cloud);
+
+/* ---------------------------------------------------------------- scan sets ---- */
+/* keyframe_scans_ and friends (Session.h:41-58): offsets[n_kf+1] in points */
+int ltm_scanset_upload(ltm_ctx*, const void* pts, size_t stride_bytes, const uint64_t* offsets, size_t n_kf, ltm_scanset* out);
+int ltm_scanset_from_device(ltm_ctx*, const void* dev_xyzi, const uint64_t* host_offsets, size_t n_kf, ltm_scanset* out);
+int ltm_scanset_info(ltm_ctx*, ltm_scanset, size_t* n_kf, size_t* n_points);
+int ltm_scanset_offsets(ltm_ctx*, ltm_scanset, uint64_t* offsets /* n_kf+1 */);
+int ltm_scanset_download(ltm_ctx*, ltm_scanset, void* dst, size_t cap_pts, size_t stride_bytes);
+int ltm_scanset_device_ptr(ltm_ctx*, ltm_scanset, const void** dev_xyzi);
+int ltm_scanset_as_cloud(ltm_ctx*, ltm_scanset, ltm_cloud* out);                       /* flat copy of all points */
+/* concatenate per-rank scan sets keyframe-wise (multi-GPU assembly): out has sum(n_kf) keyframes */
+int ltm_scanset_concat(ltm_ctx*, const ltm_scanset* in, size_t n, ltm_scanset* out);
+/* per-keyframe `a[i] += b[i] (+= c[i])` of Session.cpp:365-371 ; c may be 0 */
+int ltm_scanset_zip_concat(ltm_ctx*, ltm_scanset a, ltm_scanset b, ltm_scanset c, ltm_scanset* out);
+int ltm_scanset_free(ltm_ctx*, ltm_scanset);
+
+/* -------------------------------------------------------------------- poses ---- */
+/* keyframe_poses_ / keyframe_inverse_poses_ (Session.cpp:102-114).  inv may be NULL: then the
+ * inverse is computed in double by cofactor expansion (the reference uses Eigen's inverse()). */
+int ltm_poses_create(ltm_ctx*, size_t n_kf, const double* poses, const double* inv_or_null, ltm_poses* out);
+int ltm_poses_free(ltm_ctx*, ltm_poses);
+
+/* ------------------------------------------------- the hot path, one call per stage ---- */
+
+/* Session.cpp:506-533 precleaningKeyframes: drop points with range<radius & |z|<0.5 */
+int ltm_preclean(ltm_ctx*, ltm_scanset in, float radius, ltm_scanset* out);
+
+/* utility.cpp:170-192 mergeScansWithinGlobalCoordUtil / Session.cpp:186-202: local -> global concat */
+int ltm_merge_to_global(ltm_ctx*, ltm_scanset scans, ltm_poses poses, ltm_cloud* out);
+
+/* utility.cpp:204-219 octreeDownsampling (PCL OctreePointCloudVoxelCentroid): voxel centroids in octree DFS order */
+int ltm_voxel_centroid(ltm_ctx*, ltm_cloud in, float leaf, ltm_cloud* out);
+/* the same applied to every keyframe of a scan set (Session.cpp:362-380 updateScansScanwise) */
+int ltm_voxel_centroid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset* out);
+
+/* Visibility vote, keyframes [kf_begin,kf_end) of `scans`/`poses` against `map`:
+ *   scan2RangeImg (Removerter.cpp:109-156) + transformGlobalMapToLocal (utility.cpp:64-72) +
+ *   map2RangeImg (utility.cpp:92-142) + calcDescrepancyAndParseDynamicPointIdx (Removerter.cpp:381-413),
+ *   i.e. the loop body of calcDescrepancyAndParseDynamicPointIdxForEachScan[ForND|ForPD] (:429-593).
+ * mode 0: diff = scan - map (remove / revert / PD);  mode 1: diff = map - scan (ND).
+ * labels_dev: device buffer of M bytes; label 1 is OR-ed in for every flagged map point (the std::set
+ * union of :589-590).  The caller zeroes it; ranks combine theirs with a MAX all-reduce. */
+int ltm_visibility_vote(ltm_ctx*, ltm_cloud map, ltm_scanset scans, ltm_poses poses, size_t kf_begin, size_t kf_end,
+                        float res_alpha, float diff_thres, int mode, uint8_t* labels_dev);
+/* partitionCurrentMap tail (Removerter.cpp:816-824, :675-687, :933-946): index-ascending split */
+int ltm_partition_by_labels(ltm_ctx*, ltm_cloud map, const uint8_t* labels_dev, ltm_cloud* kept, ltm_cloud* flagged);
+/* vote over all keyframes + partition (single-GPU convenience).  host_labels (M bytes) may be NULL. */
+int ltm_visibility_partition(ltm_ctx*, ltm_cloud map, ltm_scanset scans, ltm_poses poses, float res_alpha,
+                             float diff_thres, int mode, ltm_cloud* kept, ltm_cloud* flagged, uint8_t* host_labels);
+
+/* parseProjectedPoints / Session::parseScansViaProjection (utility.cpp:74-89, Session.cpp:348-360):
+ * out has (kf_end-kf_begin) keyframes of local-frame points, row-major pixel order, ptidx==0 dropped. */
+int ltm_reproject(ltm_ctx*, ltm_cloud map, ltm_poses poses, size_t kf_begin, size_t kf_end, float res_alpha, ltm_scanset* out);
+
+/* extractLowDynPointsViaKnnDiff / extractHighDynPointsViaKnnDiff (Session.cpp:393-427, 487-504, 537-642):
+ * exact k-NN of every scan point (moved to the global frame) in `target`; coexist iff mean of the k squared
+ * distances < thr.  Outputs are in the local frame, input order kept.  Either output may be NULL. */
+int ltm_knn_partition(ltm_ctx*, ltm_cloud target, ltm_scanset scans, ltm_poses poses, size_t kf_begin, size_t kf_end,
+                      int k, float thr, ltm_scanset* coexist, ltm_scanset* diff);
+/* removeWeakNDMapPointsHavingStrongNDInNear (Session.cpp:452-484): split `query` by k-NN distance to `target` */
+int ltm_knn_split_cloud(ltm_ctx*, ltm_cloud target, ltm_cloud query, int k, float thr, ltm_cloud* near, ltm_cloud* far);
+
+/* ------------------------------------------------------ parity / debug helpers ---- */
+/* one range image of `pts` after optional transforms T1 then T2 (NULL = none); rimg R*C floats,
+ * ptidx R*C int32 or NULL.  Host output buffers. */
+int ltm_debug_range_image(ltm_ctx*, ltm_cloud pts, const double* T1, const double* T2, float res_alpha,
+                          float* rimg, int32_t* ptidx);
+/* element-wise device evaluation of the projection arithmetic: out_az_el_r (3n), out_row_col (2n) */
+int ltm_debug_project(ltm_ctx*, const float* xyz, size_t n, float res_alpha, float* out_az_el_r, int32_t* out_row_col);
+void ltm_rimg_size(float vfov, float hfov, float res_alpha, int* rows, int* cols);   /* utility.cpp:222-236 */
+
+/* ----------------------------------------------------------- measurement ---- */
+/* Per-kernel-class HIP-event timing on the context's stream.  Classes: "vote_map", "vote_scan",
+ * "vote_compare", "reproject_map", "knn_query", "voxel", .... */
+int ltm_profile_enable(ltm_ctx*, int on);
+int ltm_profile_reset(ltm_ctx*);
+/* returns number of classes; fills up to cap entries.  units = class-specific work count
+ * (point-projections for vote_map), bytes = algorithmic bytes, ms = sum of event durations */
+int ltm_profile_read(ltm_ctx*, const char** names, double* ms, uint64_t* launches, double* units, double* bytes, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

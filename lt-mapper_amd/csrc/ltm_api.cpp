@@ -1,0 +1,1084 @@
+// ltm_api.cpp -- C ABI of libltm_hip.so (include/ltm.h): context, device memory pool, handles and the
+// per-stage orchestration of the gfx950 kernels in ltm_kernels.hip.  No CPU fallback: every stage runs
+// on the device or fails with an error code.
+#include "ltm.h"
+#include "ltm_kernels.h"
+
+#include <hip/hip_runtime_api.h>
+
+#include <algorithm>
+#include <cfloat>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <memory>
+#include <new>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+using namespace ltm;
+
+namespace {
+
+struct Err { int code; std::string msg; };
+
+#define LTM_HIP(expr)                                                                               \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) throw Err{LTM_E_DEVICE, std::string(#expr) + ": " + hipGetErrorString(e__)}; \
+    } while (0)
+#define LTM_REQUIRE(cond, msg)                                  \
+    do {                                                        \
+        if (!(cond)) throw Err{LTM_E_INVALID, std::string(msg)}; \
+    } while (0)
+
+// Stream-ordered caching allocator: every kernel and copy of a context is issued on ONE stream, so a
+// block may be handed out again as soon as the host has released it.  hipMalloc/hipFree (which
+// synchronise the device) happen only on first use of a size class and at ltm_destroy().
+struct Pool {
+    std::multimap<size_t, void*> free_blocks;
+    std::unordered_map<void*, size_t> live;
+    size_t bytes_total = 0;
+    static size_t round_up(size_t b)
+    {
+        if (b < 512) return 512;
+        int e = 63 - __builtin_clzll(b);
+        size_t step = (size_t)1 << (e > 3 ? e - 3 : 0);   // 8 size classes per power of two
+        return (b + step - 1) / step * step;
+    }
+    void* alloc(size_t bytes)
+    {
+        if (bytes == 0) bytes = 1;
+        const size_t want = round_up(bytes);
+        auto it = free_blocks.lower_bound(want);
+        if (it != free_blocks.end() && it->first <= want + want / 4) {
+            void* p = it->second;
+            live[p] = it->first;
+            free_blocks.erase(it);
+            return p;
+        }
+        void* p = nullptr;
+        hipError_t e = hipMalloc(&p, want);
+        if (e != hipSuccess) {
+            release_cached();
+            e = hipMalloc(&p, want);
+            if (e != hipSuccess) throw Err{LTM_E_NOMEM, "hipMalloc of " + std::to_string(want) + " bytes failed"};
+        }
+        bytes_total += want;
+        live[p] = want;
+        return p;
+    }
+    void free(void* p)
+    {
+        if (!p) return;
+        auto it = live.find(p);
+        if (it == live.end()) return;
+        free_blocks.emplace(it->second, p);
+        live.erase(it);
+    }
+    void release_cached()
+    {
+        for (auto& kv : free_blocks) { (void)hipFree(kv.second); bytes_total -= kv.first; }
+        free_blocks.clear();
+    }
+    void release_all()
+    {
+        release_cached();
+        for (auto& kv : live) (void)hipFree(kv.first);
+        live.clear();
+    }
+};
+
+struct Cloud { float4* d = nullptr; size_t n = 0; };
+struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> off; uint64_t* off_dev = nullptr; size_t nkf() const { return off.size() - 1; } };
+struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; };
+
+struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0; };
+struct Pending { int cls; hipEvent_t a, b; };
+
+} // namespace
+
+struct ltm_ctx {
+    ltm_config cfg;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    HostMat34 L2B, B2L;
+    int l2b_identity = 1, b2l_identity = 1;
+    size_t kf_batch = 512;
+    Pool pool;
+    uint64_t next_handle = 1;
+    std::unordered_map<uint64_t, Cloud> clouds;
+    std::unordered_map<uint64_t, ScanSet> scansets;
+    std::unordered_map<uint64_t, Poses> poses;
+    std::string err;
+    // profiling
+    bool prof_on = false;
+    std::vector<std::string> prof_names;
+    std::vector<ProfClass> prof;
+    std::vector<Pending> pending;
+    std::vector<hipEvent_t> event_pool;
+};
+
+namespace {
+
+struct DevBuf {   // RAII pooled scratch
+    ltm_ctx* c; void* p;
+    DevBuf(ltm_ctx* c_, size_t bytes) : c(c_), p(c_->pool.alloc(bytes)) {}
+    ~DevBuf() { c->pool.free(p); }
+    DevBuf(const DevBuf&) = delete; DevBuf& operator=(const DevBuf&) = delete;
+    template <class T> T* as() const { return reinterpret_cast<T*>(p); }
+};
+
+void use_device(ltm_ctx* c) { LTM_HIP(hipSetDevice(c->device)); }
+
+int prof_class(ltm_ctx* c, const char* name)
+{
+    for (size_t i = 0; i < c->prof_names.size(); ++i) if (c->prof_names[i] == name) return (int)i;
+    c->prof_names.push_back(name); c->prof.push_back(ProfClass());
+    return (int)c->prof_names.size() - 1;
+}
+hipEvent_t get_event(ltm_ctx* c)
+{
+    if (!c->event_pool.empty()) { hipEvent_t e = c->event_pool.back(); c->event_pool.pop_back(); return e; }
+    hipEvent_t e; LTM_HIP(hipEventCreate(&e)); return e;
+}
+struct ProfScope {   // HIP-event bracket around one kernel class on the context's stream
+    ltm_ctx* c; int cls = -1; hipEvent_t a = nullptr;
+    ProfScope(ltm_ctx* c_, const char* name, double units, double bytes) : c(c_)
+    {
+        if (!c->prof_on) return;
+        cls = prof_class(c, name);
+        c->prof[cls].launches++; c->prof[cls].units += units; c->prof[cls].bytes += bytes;
+        a = get_event(c);
+        LTM_HIP(hipEventRecord(a, c->stream));
+    }
+    ~ProfScope()
+    {
+        if (cls < 0) return;
+        hipEvent_t b = nullptr;
+        if (hipEventCreate(&b) != hipSuccess) return;
+        (void)hipEventRecord(b, c->stream);
+        c->pending.push_back(Pending{cls, a, b});
+    }
+};
+void prof_collect(ltm_ctx* c)
+{
+    if (c->pending.empty()) return;
+    LTM_HIP(hipStreamSynchronize(c->stream));
+    for (Pending& p : c->pending) {
+        float ms = 0;
+        if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->prof[p.cls].ms += ms;
+        c->event_pool.push_back(p.a); c->event_pool.push_back(p.b);
+    }
+    c->pending.clear();
+}
+
+void sync(ltm_ctx* c) { LTM_HIP(hipStreamSynchronize(c->stream)); }
+void d2h(ltm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return;
+    LTM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+}
+void h2d(ltm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return;
+    LTM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
+    sync(c);   // the host buffer may be pageable and is not ours to keep
+}
+void d2d(ltm_ctx* c, void* dst, const void* src, size_t bytes)
+{
+    if (!bytes) return;
+    LTM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, c->stream));
+}
+
+Cloud& get_cloud(ltm_ctx* c, ltm_cloud h)
+{
+    auto it = c->clouds.find(h);
+    if (it == c->clouds.end()) throw Err{LTM_E_INVALID, "invalid cloud handle " + std::to_string(h)};
+    return it->second;
+}
+ScanSet& get_ss(ltm_ctx* c, ltm_scanset h)
+{
+    auto it = c->scansets.find(h);
+    if (it == c->scansets.end()) throw Err{LTM_E_INVALID, "invalid scanset handle " + std::to_string(h)};
+    return it->second;
+}
+Poses& get_poses(ltm_ctx* c, ltm_poses h)
+{
+    auto it = c->poses.find(h);
+    if (it == c->poses.end()) throw Err{LTM_E_INVALID, "invalid poses handle " + std::to_string(h)};
+    return it->second;
+}
+ltm_cloud new_cloud(ltm_ctx* c, float4* d, size_t n)
+{
+    const uint64_t h = c->next_handle++;
+    c->clouds[h] = Cloud{d, n};
+    return h;
+}
+ltm_cloud alloc_cloud(ltm_ctx* c, size_t n, float4** d)
+{
+    *d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(n, 1) * sizeof(float4)));
+    return new_cloud(c, *d, n);
+}
+ltm_scanset new_scanset(ltm_ctx* c, float4* d, std::vector<uint64_t> off)
+{
+    ScanSet s;
+    s.d = d; s.n_pts = off.back(); s.off = std::move(off);
+    s.off_dev = reinterpret_cast<uint64_t*>(c->pool.alloc(s.off.size() * sizeof(uint64_t)));
+    h2d(c, s.off_dev, s.off.data(), s.off.size() * sizeof(uint64_t));
+    const uint64_t h = c->next_handle++;
+    c->scansets[h] = std::move(s);
+    return h;
+}
+
+bool mat_is_identity(const double* m16)
+{
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) if (m16[4 * r + k] != (r == k ? 1.0 : 0.0)) return false;
+    return true;
+}
+HostMat34 to34(const double* m16) { HostMat34 h; memcpy(h.m, m16, 12 * sizeof(double)); return h; }
+
+// general 4x4 inverse, Gauss-Jordan with partial pivoting in double (stands in for Eigen's inverse())
+bool inverse4x4(const double* m, double* inv)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) { a[r][k] = m[4 * r + k]; a[r][4 + k] = (r == k) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) return false;
+        if (piv != col) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
+        const double d = a[col][col];
+        for (int k = 0; k < 8; ++k) a[col][k] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = a[r][4 + k];
+    return true;
+}
+
+// utility.cpp:222-236 resetRimgSize
+Geom geom_for(const ltm_ctx* c, float alpha)
+{
+    Geom g;
+    g.vfov = c->cfg.vfov; g.hfov = c->cfg.hfov;
+    g.rows = (int)roundf(c->cfg.vfov * alpha);
+    g.cols = (int)roundf(c->cfg.hfov * alpha);
+    return g;
+}
+
+void pack_from_host(const void* src, size_t n, size_t stride, std::vector<float>& out)
+{
+    out.resize(n * 4);
+    const unsigned char* s = static_cast<const unsigned char*>(src);
+    const size_t ioff = (stride >= 32) ? 16 : 12;   // pcl::PointXYZI keeps intensity in its second 16-byte lane
+    for (size_t i = 0; i < n; ++i) {
+        memcpy(&out[4 * i], s + i * stride, 12);
+        memcpy(&out[4 * i + 3], s + i * stride + ioff, 4);
+    }
+}
+void unpack_to_host(const float* packed, size_t n, size_t stride, void* dst)
+{
+    unsigned char* d = static_cast<unsigned char*>(dst);
+    const float one = 1.0f;
+    for (size_t i = 0; i < n; ++i) {
+        unsigned char* p = d + i * stride;
+        if (stride >= 32) {
+            memset(p, 0, 32);
+            memcpy(p, &packed[4 * i], 12); memcpy(p + 12, &one, 4); memcpy(p + 16, &packed[4 * i + 3], 4);
+        } else {
+            memcpy(p, &packed[4 * i], 16);
+        }
+    }
+}
+
+
+// count of set labels given the exclusive scan `pos` of `labels` (n > 0)
+size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, size_t n)
+{
+    uint32_t last_pos = 0; uint8_t last = 0;
+    LTM_HIP(hipMemcpyAsync(&last_pos, pos + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+    LTM_HIP(hipMemcpyAsync(&last, labels + (n - 1), 1, hipMemcpyDeviceToHost, c->stream));
+    sync(c);
+    return (size_t)last_pos + (last ? 1 : 0);
+}
+
+// --------------------------------------------------------------------------------- vote
+void do_vote(ltm_ctx* c, const Cloud& map, const ScanSet& ss, const Poses& ps, size_t kf_begin, size_t kf_end, float alpha, float thr,
+             int mode, uint8_t* labels_dev)
+{
+    LTM_REQUIRE(ss.nkf() == ps.n, "scan set and poses have different keyframe counts");
+    LTM_REQUIRE(kf_begin <= kf_end && kf_end <= ps.n, "keyframe range out of bounds");
+    LTM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (scan-map) or 1 (map-scan)");
+    LTM_REQUIRE(map.n < 0xffffffffull, "map too large for 32-bit point indices");
+    if (kf_begin == kf_end || map.n == 0) return;
+    const Geom g = geom_for(c, alpha);
+    LTM_REQUIRE(g.rows > 0 && g.cols > 0, "empty range image");
+    const size_t npx = (size_t)g.rows * g.cols;
+    const size_t KB = std::min(c->kf_batch, kf_end - kf_begin);
+    DevBuf scan_img(c, KB * npx * sizeof(uint32_t)), map_img(c, KB * npx * sizeof(uint64_t));
+    for (size_t kb = kf_begin; kb < kf_end; kb += KB) {
+        const size_t nb = std::min(KB, kf_end - kb);
+        const uint64_t first = ss.off[kb], npts = ss.off[kb + nb] - first;
+        {
+            ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 12));
+            LTM_HIP(fill_u32(scan_img.as<uint32_t>(), kNoPointBits, nb * npx, c->stream));
+            LTM_HIP(fill_u64(map_img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
+        }
+        {
+            ProfScope p(c, "vote_scan", (double)npts, (double)npts * 16 + (double)(nb * npx) * 4);
+            LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, scan_img.as<uint32_t>(), c->stream));
+        }
+        {
+            ProfScope p(c, "vote_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
+            LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, kb, nb, c->B2L, c->b2l_identity, g, map_img.as<uint64_t>(), c->stream));
+        }
+        {
+            ProfScope p(c, "vote_compare", (double)(nb * npx), (double)(nb * npx) * 12 + (double)nb * map.n / 8.0);
+            LTM_HIP(compare_and_flag(scan_img.as<uint32_t>(), map_img.as<uint64_t>(), nb * npx, thr, mode, labels_dev, c->stream));
+        }
+    }
+}
+
+void do_partition(ltm_ctx* c, const Cloud& map, const uint8_t* labels, ltm_cloud* kept, ltm_cloud* flagged)
+{
+    const size_t n = map.n;
+    if (n == 0) {
+        float4* d;
+        if (kept) *kept = alloc_cloud(c, 0, &d);
+        if (flagged) *flagged = alloc_cloud(c, 0, &d);
+        return;
+    }
+    DevBuf pos(c, n * sizeof(uint32_t));
+    const size_t tb = scan_temp_bytes(n);
+    DevBuf temp(c, tb);
+    ProfScope p(c, "partition", (double)n, (double)n * (16 + 1 + 4 + 4 + 16));
+    LTM_HIP(exclusive_scan_u8(labels, pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+    const size_t nf = scan_total_u8(c, labels, pos.as<uint32_t>(), n);
+    float4 *dk = nullptr, *df = nullptr;
+    ltm_cloud hk = 0, hf = 0;
+    if (kept) hk = alloc_cloud(c, n - nf, &dk);
+    if (flagged) hf = alloc_cloud(c, nf, &df);
+    LTM_HIP(partition_scatter(map.d, labels, pos.as<uint32_t>(), n, dk, df, c->stream));
+    if (kept) *kept = hk;
+    if (flagged) *flagged = hf;
+}
+
+// --------------------------------------------------------------------------- voxel centroid
+// PCL OctreePointCloud::defineBoundingBox() + getKeyBitSize() on an empty tree (octree_pointcloud.hpp);
+// see DESIGN.md "voxel lattice".  Returns false if the depth does not fit 21 bits per axis.
+bool octree_frame_from_bbox(const float mn[3], const float mx[3], float leaf, OctreeFrame* f)
+{
+    const float eps512 = FLT_EPSILON * 512.0f;
+    const float minValue = FLT_EPSILON;
+    double lo[3], hi[3];
+    for (int d = 0; d < 3; ++d) { lo[d] = (double)mn[d]; hi[d] = (double)(float)(mx[d] + eps512); }
+    const double res = (double)leaf;
+    unsigned mk = 2;
+    for (int d = 0; d < 3; ++d) mk = std::max(mk, (unsigned)std::ceil((hi[d] - lo[d] - minValue) / res));
+    const unsigned depth = std::min(32u, (unsigned)std::ceil(std::log2((double)mk) - minValue));
+    if (depth > 21) return false;
+    const double side = (double)(1u << depth) * res;
+    for (int d = 0; d < 3; ++d) {
+        const double over = (side - (hi[d] - lo[d])) / 2.0;
+        if (over > minValue) lo[d] -= over;
+    }
+    f->minx = lo[0]; f->miny = lo[1]; f->minz = lo[2]; f->res = res; f->depth = depth;
+    return true;
+}
+
+void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3])
+{
+    DevBuf bb(c, 6 * sizeof(uint32_t));
+    LTM_HIP(bbox_init(bb.as<uint32_t>(), c->stream));
+    LTM_HIP(bbox_reduce(pts, n, bb.as<uint32_t>(), c->stream));
+    uint32_t enc[6];
+    d2h(c, enc, bb.p, sizeof enc);
+    for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[d]); mx[d] = bbox_decode(enc[3 + d]); }
+}
+
+// voxel centroids of pts[0..n) into a freshly pooled array; returns count
+size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n, float leaf, float4** out)
+{
+    *out = nullptr;
+    if (n == 0) return 0;
+    LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
+    LTM_REQUIRE(n < 0xffffffffull, "cloud too large for 32-bit point indices");
+    ProfScope p(c, "voxel", (double)n, 64.0 * n);
+    float mn[3], mx[3];
+    bbox_of(c, pts, n, mn, mx);
+    OctreeFrame f;
+    if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+    DevBuf keys(c, n * 8), keys2(c, n * 8), idx(c, n * 4), idx2(c, n * 4);
+    LTM_HIP(morton_keys(pts, n, f, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
+    const size_t stb = sort_temp_bytes(n);
+    {
+        DevBuf stemp(c, stb);
+        LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, 3 * f.depth,
+                               stemp.p, stb, c->stream));
+    }
+    DevBuf heads(c, n), pos(c, n * 4);
+    LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
+    const size_t tb = scan_temp_bytes(n);
+    DevBuf temp(c, tb);
+    LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+    const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
+    DevBuf starts(c, nvox * 4);
+    LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
+    float4* o = reinterpret_cast<float4*>(c->pool.alloc(nvox * sizeof(float4)));
+    LTM_HIP(voxel_centroids(pts, idx2.as<uint32_t>(), starts.as<uint32_t>(), nvox, n, o, c->stream));
+    *out = o;
+    return nvox;
+}
+
+// ------------------------------------------------------------------------------------ kNN
+struct KnnIndex {
+    ltm_ctx* c;
+    float4* sorted = nullptr; HashEntry* table = nullptr; uint32_t mask = 0; KnnGrid g{}; float cell2_lo = 0; size_t Mt = 0;
+    explicit KnnIndex(ltm_ctx* c_) : c(c_) {}
+    ~KnnIndex() { c->pool.free(sorted); c->pool.free(table); }
+    void build(const Cloud& target, int k, float thr)
+    {
+        Mt = target.n;
+        LTM_REQUIRE(k >= 1 && k <= 16, "k must be in [1,16]");
+        LTM_REQUIRE(thr > 0.0f, "kNN threshold must be positive");
+        LTM_REQUIRE(Mt < 0xffffffffull, "target too large");
+        if (Mt == 0) return;
+        ProfScope p(c, "knn_build", (double)Mt, 20.0 * Mt);
+        sorted = reinterpret_cast<float4*>(c->pool.alloc(Mt * sizeof(float4)));
+        if (Mt <= 64) { d2d(c, sorted, target.d, Mt * sizeof(float4)); return; }   // brute force inside the query kernel
+        float mn[3], mx[3];
+        bbox_of(c, target.d, Mt, mn, mx);
+        // cell edge: every neighbour with d^2 < k*thr must fall in the 27-cell block (margin 1e-3, floor 1e-4 m)
+        double cell = std::sqrt((double)k * (double)thr) * (1.0 + 1e-3);
+        const double ext = std::max({(double)mx[0] - mn[0], (double)mx[1] - mn[1], (double)mx[2] - mn[2], 1e-3});
+        cell = std::max(cell, ext / 1.0e6);   // keeps every axis below 2^20 cells (id < 2^62)
+        g.ox = (double)mn[0] - cell; g.oy = (double)mn[1] - cell; g.oz = (double)mn[2] - cell;
+        g.inv_cell = 1.0 / cell;
+        g.nx = (long long)std::floor(((double)mx[0] - g.ox) * g.inv_cell) + 2;
+        g.ny = (long long)std::floor(((double)mx[1] - g.oy) * g.inv_cell) + 2;
+        g.nz = (long long)std::floor(((double)mx[2] - g.oz) * g.inv_cell) + 2;
+        cell2_lo = (float)(cell * cell * (1.0 - 1e-5));
+        const double ncells = (double)g.nx * (double)g.ny * (double)g.nz;
+        unsigned bits = 1;
+        while (bits < 64 && std::ldexp(1.0, (int)bits) < ncells) ++bits;
+        DevBuf keys(c, Mt * 8), keys2(c, Mt * 8), idx(c, Mt * 4), idx2(c, Mt * 4);
+        LTM_HIP(cell_keys(target.d, Mt, g, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
+        const size_t stb = sort_temp_bytes(Mt);
+        {
+            DevBuf stemp(c, stb);
+            LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), Mt, bits, stemp.p, stb, c->stream));
+        }
+        LTM_HIP(gather_points(target.d, idx2.as<uint32_t>(), Mt, sorted, c->stream));
+        DevBuf heads(c, Mt), pos(c, Mt * 4);
+        LTM_HIP(head_flags(keys2.as<uint64_t>(), Mt, heads.as<uint8_t>(), c->stream));
+        const size_t tb = scan_temp_bytes(Mt);
+        DevBuf temp(c, tb);
+        LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), Mt, temp.p, tb, c->stream));
+        const size_t ncell = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), Mt);
+        DevBuf starts(c, ncell * 4);
+        LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), Mt, starts.as<uint32_t>(), c->stream));
+        size_t tsize = 1024;
+        while (tsize < 2 * ncell) tsize <<= 1;
+        mask = (uint32_t)(tsize - 1);
+        table = reinterpret_cast<HashEntry*>(c->pool.alloc(tsize * sizeof(HashEntry)));
+        LTM_HIP(fill_u64(reinterpret_cast<uint64_t*>(table), ~0ull, tsize * 2, c->stream));
+        LTM_HIP(hash_build(keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, Mt, table, mask, c->stream));
+    }
+};
+
+// split pts[0..n) by flag (1 -> first output) keeping order; per-keyframe offsets from `bounds` (n_b+1 point positions)
+void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n, const std::vector<uint64_t>& bounds,
+                   float4** d_set, std::vector<uint64_t>* off_set, float4** d_unset, std::vector<uint64_t>* off_unset)
+{
+    const size_t nb = bounds.size() - 1;
+    off_set->assign(nb + 1, 0); off_unset->assign(nb + 1, 0);
+    *d_set = nullptr; *d_unset = nullptr;
+    size_t nset = 0;
+    if (n) {
+        DevBuf pos(c, n * 4);
+        const size_t tb = scan_temp_bytes(n);
+        DevBuf temp(c, tb);
+        LTM_HIP(exclusive_scan_u8(flag, pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+        nset = scan_total_u8(c, flag, pos.as<uint32_t>(), n);
+        DevBuf bdev(c, (nb + 1) * 8), bout(c, (nb + 1) * 4);
+        h2d(c, bdev.p, bounds.data(), (nb + 1) * 8);
+        LTM_HIP(gather_u32(pos.as<uint32_t>(), bdev.as<uint64_t>(), nb + 1, n, (uint32_t)nset, bout.as<uint32_t>(), c->stream));
+        std::vector<uint32_t> b(nb + 1);
+        d2h(c, b.data(), bout.p, (nb + 1) * 4);
+        for (size_t j = 0; j <= nb; ++j) { (*off_set)[j] = b[j]; (*off_unset)[j] = bounds[j] - b[j]; }
+        *d_set = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nset, 1) * sizeof(float4)));
+        *d_unset = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(n - nset, 1) * sizeof(float4)));
+        LTM_HIP(partition_scatter(pts, flag, pos.as<uint32_t>(), n, *d_unset, *d_set, c->stream));
+    } else {
+        *d_set = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+        *d_unset = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+    }
+}
+
+template <class F>
+int guarded(ltm_ctx* c, F&& f)
+{
+    if (!c) return LTM_E_INVALID;
+    try {
+        use_device(c);
+        f();
+        return LTM_OK;
+    } catch (const Err& e) {
+        c->err = e.msg;
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        c->err = "host allocation failed";
+        return LTM_E_NOMEM;
+    } catch (const std::exception& e) {
+        c->err = e.what();
+        return LTM_E_INVALID;
+    } catch (...) {
+        c->err = "unknown error";
+        return LTM_E_INVALID;
+    }
+}
+
+} // namespace
+
+// =========================================================================================== C ABI
+extern "C" {
+
+int ltm_abi_version(void) { return LTM_ABI_VERSION; }
+
+int ltm_create(const ltm_config* cfg, ltm_ctx** out)
+{
+    if (!cfg || !out) return LTM_E_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return LTM_E_DEVICE;
+    if (cfg->device < 0 || cfg->device >= ndev) return LTM_E_INVALID;
+    ltm_ctx* c = new (std::nothrow) ltm_ctx();
+    if (!c) return LTM_E_NOMEM;
+    c->cfg = *cfg;
+    c->device = cfg->device;
+    if (cfg->max_kf_batch > 0) c->kf_batch = (size_t)cfg->max_kf_batch;
+    double b2l[16];
+    if (!(cfg->vfov > 0.0f) || !(cfg->hfov > 0.0f) || !inverse4x4(cfg->lidar2base, b2l)) { delete c; return LTM_E_INVALID; }
+    c->l2b_identity = mat_is_identity(cfg->lidar2base);
+    if (c->l2b_identity) memcpy(b2l, cfg->lidar2base, sizeof b2l);   // the inverse of I is exactly I
+    c->b2l_identity = mat_is_identity(b2l);
+    c->L2B = to34(cfg->lidar2base); c->B2L = to34(b2l);
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete c;
+        return LTM_E_DEVICE;
+    }
+    *out = c;
+    return LTM_OK;
+}
+
+void ltm_destroy(ltm_ctx* c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    (void)hipStreamSynchronize(c->stream);
+    for (Pending& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
+    for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    c->pool.release_all();
+    (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+const char* ltm_last_error(const ltm_ctx* c) { return c ? c->err.c_str() : "null context"; }
+int ltm_synchronize(ltm_ctx* c) { return guarded(c, [&] { sync(c); }); }
+void* ltm_stream(ltm_ctx* c) { return c ? (void*)c->stream : nullptr; }
+
+void ltm_rimg_size(float vfov, float hfov, float alpha, int* rows, int* cols)
+{
+    if (rows) *rows = (int)roundf(vfov * alpha);
+    if (cols) *cols = (int)roundf(hfov * alpha);
+}
+
+// ------------------------------------------------------------------------------- clouds
+int ltm_cloud_upload(ltm_ctx* c, const void* pts, size_t n, size_t stride, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out && (pts || n == 0), "null argument");
+        LTM_REQUIRE(stride == 16 || stride >= 32 || n == 0, "stride must be 16 (packed) or >= 32 (pcl::PointXYZI)");
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, n, &d);
+        if (n) {
+            if (stride == 16) h2d(c, d, pts, n * 16);
+            else { std::vector<float> tmp; pack_from_host(pts, n, stride, tmp); h2d(c, d, tmp.data(), n * 16); }
+        }
+        *out = h;
+    });
+}
+int ltm_cloud_from_device(ltm_ctx* c, const void* dev, size_t n, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out && (dev || n == 0), "null argument");
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, n, &d);
+        d2d(c, d, dev, n * 16);
+        sync(c);
+        *out = h;
+    });
+}
+int ltm_cloud_size(ltm_ctx* c, ltm_cloud h, size_t* n)
+{
+    return guarded(c, [&] { LTM_REQUIRE(n, "null argument"); *n = get_cloud(c, h).n; });
+}
+int ltm_cloud_download(ltm_ctx* c, ltm_cloud h, void* dst, size_t cap, size_t stride)
+{
+    return guarded(c, [&] {
+        const Cloud& cl = get_cloud(c, h);
+        LTM_REQUIRE(dst || cl.n == 0, "null destination");
+        LTM_REQUIRE(cap >= cl.n, "destination too small");
+        LTM_REQUIRE(stride == 16 || stride >= 32, "stride must be 16 or >= 32");
+        if (!cl.n) return;
+        if (stride == 16) d2h(c, dst, cl.d, cl.n * 16);
+        else { std::vector<float> tmp(cl.n * 4); d2h(c, tmp.data(), cl.d, cl.n * 16); unpack_to_host(tmp.data(), cl.n, stride, dst); }
+    });
+}
+int ltm_cloud_device_ptr(ltm_ctx* c, ltm_cloud h, const void** p)
+{
+    return guarded(c, [&] { LTM_REQUIRE(p, "null argument"); *p = get_cloud(c, h).d; });
+}
+int ltm_cloud_clone(ltm_ctx* c, ltm_cloud h, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const Cloud src = get_cloud(c, h);
+        float4* d;
+        const ltm_cloud nh = alloc_cloud(c, src.n, &d);
+        d2d(c, d, src.d, src.n * 16);
+        *out = nh;
+    });
+}
+int ltm_cloud_concat(ltm_ctx* c, const ltm_cloud* in, size_t n, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out && (in || n == 0), "null argument");
+        size_t tot = 0;
+        for (size_t i = 0; i < n; ++i) tot += get_cloud(c, in[i]).n;
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, tot, &d);
+        size_t at = 0;
+        for (size_t i = 0; i < n; ++i) { const Cloud& s = get_cloud(c, in[i]); d2d(c, d + at, s.d, s.n * 16); at += s.n; }
+        *out = h;
+    });
+}
+int ltm_cloud_free(ltm_ctx* c, ltm_cloud h)
+{
+    return guarded(c, [&] { Cloud& cl = get_cloud(c, h); c->pool.free(cl.d); c->clouds.erase(h); });
+}
+
+// ---------------------------------------------------------------------------- scan sets
+static void check_offsets(const uint64_t* off, size_t n_kf)
+{
+    LTM_REQUIRE(off, "null offsets");
+    LTM_REQUIRE(off[0] == 0, "offsets[0] must be 0");
+    for (size_t i = 0; i < n_kf; ++i) LTM_REQUIRE(off[i] <= off[i + 1], "offsets must be non-decreasing");
+}
+int ltm_scanset_upload(ltm_ctx* c, const void* pts, size_t stride, const uint64_t* off, size_t n_kf, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        check_offsets(off, n_kf);
+        const size_t n = off[n_kf];
+        LTM_REQUIRE(pts || n == 0, "null points");
+        LTM_REQUIRE(stride == 16 || stride >= 32 || n == 0, "stride must be 16 or >= 32");
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(n, 1) * 16));
+        if (n) {
+            if (stride == 16) h2d(c, d, pts, n * 16);
+            else { std::vector<float> tmp; pack_from_host(pts, n, stride, tmp); h2d(c, d, tmp.data(), n * 16); }
+        }
+        *out = new_scanset(c, d, std::vector<uint64_t>(off, off + n_kf + 1));
+    });
+}
+int ltm_scanset_from_device(ltm_ctx* c, const void* dev, const uint64_t* off, size_t n_kf, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        check_offsets(off, n_kf);
+        const size_t n = off[n_kf];
+        LTM_REQUIRE(dev || n == 0, "null points");
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(n, 1) * 16));
+        d2d(c, d, dev, n * 16);
+        sync(c);
+        *out = new_scanset(c, d, std::vector<uint64_t>(off, off + n_kf + 1));
+    });
+}
+int ltm_scanset_info(ltm_ctx* c, ltm_scanset h, size_t* n_kf, size_t* n_pts)
+{
+    return guarded(c, [&] { const ScanSet& s = get_ss(c, h); if (n_kf) *n_kf = s.nkf(); if (n_pts) *n_pts = s.n_pts; });
+}
+int ltm_scanset_offsets(ltm_ctx* c, ltm_scanset h, uint64_t* off)
+{
+    return guarded(c, [&] { LTM_REQUIRE(off, "null argument"); const ScanSet& s = get_ss(c, h); memcpy(off, s.off.data(), s.off.size() * 8); });
+}
+int ltm_scanset_download(ltm_ctx* c, ltm_scanset h, void* dst, size_t cap, size_t stride)
+{
+    return guarded(c, [&] {
+        const ScanSet& s = get_ss(c, h);
+        LTM_REQUIRE(dst || s.n_pts == 0, "null destination");
+        LTM_REQUIRE(cap >= s.n_pts, "destination too small");
+        LTM_REQUIRE(stride == 16 || stride >= 32, "stride must be 16 or >= 32");
+        if (!s.n_pts) return;
+        if (stride == 16) d2h(c, dst, s.d, s.n_pts * 16);
+        else { std::vector<float> tmp(s.n_pts * 4); d2h(c, tmp.data(), s.d, s.n_pts * 16); unpack_to_host(tmp.data(), s.n_pts, stride, dst); }
+    });
+}
+int ltm_scanset_device_ptr(ltm_ctx* c, ltm_scanset h, const void** p)
+{
+    return guarded(c, [&] { LTM_REQUIRE(p, "null argument"); *p = get_ss(c, h).d; });
+}
+int ltm_scanset_as_cloud(ltm_ctx* c, ltm_scanset h, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const ScanSet& s = get_ss(c, h);
+        float4* d;
+        const ltm_cloud nh = alloc_cloud(c, s.n_pts, &d);
+        d2d(c, d, s.d, s.n_pts * 16);
+        *out = nh;
+    });
+}
+int ltm_scanset_concat(ltm_ctx* c, const ltm_scanset* in, size_t n, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out && (in || n == 0), "null argument");
+        std::vector<uint64_t> off(1, 0);
+        size_t tot = 0;
+        for (size_t i = 0; i < n; ++i) tot += get_ss(c, in[i]).n_pts;
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(tot, 1) * 16));
+        size_t at = 0;
+        for (size_t i = 0; i < n; ++i) {
+            const ScanSet& s = get_ss(c, in[i]);
+            d2d(c, d + at, s.d, s.n_pts * 16);
+            for (size_t k = 1; k < s.off.size(); ++k) off.push_back(at + s.off[k]);
+            at += s.n_pts;
+        }
+        *out = new_scanset(c, d, std::move(off));
+    });
+}
+int ltm_scanset_zip_concat(ltm_ctx* c, ltm_scanset ha, ltm_scanset hb, ltm_scanset hc, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const ScanSet* parts[3] = {&get_ss(c, ha), &get_ss(c, hb), hc ? &get_ss(c, hc) : nullptr};
+        const size_t nk = parts[0]->nkf();
+        size_t tot = 0;
+        for (const ScanSet* s : parts) if (s) { LTM_REQUIRE(s->nkf() == nk, "scan sets have different keyframe counts"); tot += s->n_pts; }
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(tot, 1) * 16));
+        std::vector<uint64_t> off(nk + 1, 0);
+        size_t at = 0;
+        for (size_t k = 0; k < nk; ++k) {
+            for (const ScanSet* s : parts) {
+                if (!s) continue;
+                const size_t cnt = s->off[k + 1] - s->off[k];
+                d2d(c, d + at, s->d + s->off[k], cnt * 16);
+                at += cnt;
+            }
+            off[k + 1] = at;
+        }
+        *out = new_scanset(c, d, std::move(off));
+    });
+}
+int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
+{
+    return guarded(c, [&] { ScanSet& s = get_ss(c, h); c->pool.free(s.d); c->pool.free(s.off_dev); c->scansets.erase(h); });
+}
+
+// -------------------------------------------------------------------------------- poses
+int ltm_poses_create(ltm_ctx* c, size_t n, const double* poses, const double* inv, ltm_poses* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out && (poses || n == 0), "null argument");
+        Poses p;
+        p.n = n;
+        p.pose.assign(poses, poses + 16 * n);
+        if (inv) p.inv.assign(inv, inv + 16 * n);
+        else {
+            p.inv.resize(16 * n);
+            for (size_t i = 0; i < n; ++i) LTM_REQUIRE(inverse4x4(&p.pose[16 * i], &p.inv[16 * i]), "singular pose");
+        }
+        std::vector<double> a(12 * std::max<size_t>(n, 1)), b(12 * std::max<size_t>(n, 1));
+        for (size_t i = 0; i < n; ++i) { memcpy(&a[12 * i], &p.pose[16 * i], 96); memcpy(&b[12 * i], &p.inv[16 * i], 96); }
+        p.pose_dev = reinterpret_cast<double*>(c->pool.alloc(a.size() * 8));
+        p.inv_dev = reinterpret_cast<double*>(c->pool.alloc(b.size() * 8));
+        h2d(c, p.pose_dev, a.data(), a.size() * 8);
+        h2d(c, p.inv_dev, b.data(), b.size() * 8);
+        const uint64_t h = c->next_handle++;
+        c->poses[h] = std::move(p);
+        *out = h;
+    });
+}
+int ltm_poses_free(ltm_ctx* c, ltm_poses h)
+{
+    return guarded(c, [&] { Poses& p = get_poses(c, h); c->pool.free(p.pose_dev); c->pool.free(p.inv_dev); c->poses.erase(h); });
+}
+
+// ------------------------------------------------------------------------------- stages
+int ltm_preclean(ltm_ctx* c, ltm_scanset hin, float radius, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const ScanSet& s = get_ss(c, hin);
+        DevBuf drop(c, std::max<size_t>(s.n_pts, 1));
+        LTM_HIP(preclean_flags(s.d, s.n_pts, radius, drop.as<uint8_t>(), c->stream));
+        float4 *d_drop, *d_keep;
+        std::vector<uint64_t> off_drop, off_keep;
+        split_by_flag(c, s.d, drop.as<uint8_t>(), s.n_pts, s.off, &d_drop, &off_drop, &d_keep, &off_keep);
+        c->pool.free(d_drop);
+        *out = new_scanset(c, d_keep, std::move(off_keep));
+    });
+}
+
+int ltm_merge_to_global(ltm_ctx* c, ltm_scanset hs, ltm_poses hp, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const ScanSet& s = get_ss(c, hs);
+        const Poses& p = get_poses(c, hp);
+        LTM_REQUIRE(s.nkf() == p.n, "scan set and poses have different keyframe counts");
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, s.n_pts, &d);
+        {
+            ProfScope ps(c, "merge", (double)s.n_pts, 32.0 * s.n_pts);
+            LTM_HIP(transform_scans(s.d, s.off_dev, s.nkf(), s.n_pts, c->L2B, c->l2b_identity, p.pose_dev, d, c->stream));
+        }
+        *out = h;
+    });
+}
+
+int ltm_voxel_centroid(ltm_ctx* c, ltm_cloud hin, float leaf, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const Cloud in = get_cloud(c, hin);
+        float4* d = nullptr;
+        const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d);
+        if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+        *out = new_cloud(c, d, nv);
+    });
+}
+
+int ltm_voxel_centroid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const ScanSet& s = get_ss(c, hin);
+        const size_t nk = s.nkf();
+        std::vector<float4*> parts(nk, nullptr);
+        std::vector<uint64_t> off(nk + 1, 0);
+        for (size_t k = 0; k < nk; ++k) {
+            const size_t nv = voxel_centroid_raw(c, s.d + s.off[k], s.off[k + 1] - s.off[k], leaf, &parts[k]);
+            off[k + 1] = off[k] + nv;
+        }
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(off[nk], 1) * 16));
+        for (size_t k = 0; k < nk; ++k) { d2d(c, d + off[k], parts[k], (off[k + 1] - off[k]) * 16); }
+        sync(c);
+        for (size_t k = 0; k < nk; ++k) c->pool.free(parts[k]);
+        *out = new_scanset(c, d, std::move(off));
+    });
+}
+
+int ltm_visibility_vote(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_poses hp, size_t kf_begin, size_t kf_end, float alpha,
+                        float thr, int mode, uint8_t* labels_dev)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(labels_dev, "null labels buffer");
+        do_vote(c, get_cloud(c, hmap), get_ss(c, hs), get_poses(c, hp), kf_begin, kf_end, alpha, thr, mode, labels_dev);
+        sync(c);   // the caller may hand labels_dev to a collective on another stream
+    });
+}
+
+int ltm_partition_by_labels(ltm_ctx* c, ltm_cloud hmap, const uint8_t* labels_dev, ltm_cloud* kept, ltm_cloud* flagged)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(labels_dev || get_cloud(c, hmap).n == 0, "null labels buffer");
+        const Cloud map = get_cloud(c, hmap);
+        do_partition(c, map, labels_dev, kept, flagged);
+    });
+}
+
+int ltm_visibility_partition(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_poses hp, float alpha, float thr, int mode,
+                             ltm_cloud* kept, ltm_cloud* flagged, uint8_t* host_labels)
+{
+    return guarded(c, [&] {
+        const Cloud map = get_cloud(c, hmap);
+        const Poses& p = get_poses(c, hp);
+        DevBuf labels(c, std::max<size_t>(map.n, 1));
+        LTM_HIP(hipMemsetAsync(labels.p, 0, std::max<size_t>(map.n, 1), c->stream));
+        do_vote(c, map, get_ss(c, hs), p, 0, p.n, alpha, thr, mode, labels.as<uint8_t>());
+        if (host_labels) d2h(c, host_labels, labels.p, map.n);
+        do_partition(c, map, labels.as<uint8_t>(), kept, flagged);
+    });
+}
+
+int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, size_t kf_end, float alpha, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const Cloud map = get_cloud(c, hmap);
+        const Poses& p = get_poses(c, hp);
+        LTM_REQUIRE(kf_begin <= kf_end && kf_end <= p.n, "keyframe range out of bounds");
+        LTM_REQUIRE(map.n < 0xffffffffull, "map too large for 32-bit point indices");
+        const Geom g = geom_for(c, alpha);
+        LTM_REQUIRE(g.rows > 0 && g.cols > 0, "empty range image");
+        const size_t npx = (size_t)g.rows * g.cols;
+        const size_t nk = kf_end - kf_begin;
+        std::vector<uint64_t> off(nk + 1, 0);
+        struct Piece { float4* d; size_t n; };
+        std::vector<Piece> pieces;
+        if (nk && map.n) {
+            const size_t KB = std::min(c->kf_batch, nk);
+            DevBuf img(c, KB * npx * 8), pos(c, KB * npx * 4);
+            const size_t tb = scan_temp_bytes(KB * npx);
+            DevBuf temp(c, tb), bdev(c, (KB + 1) * 8), bout(c, (KB + 1) * 4);
+            for (size_t kb = kf_begin; kb < kf_end; kb += KB) {
+                const size_t nb = std::min(KB, kf_end - kb);
+                LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
+                {
+                    ProfScope ps(c, "reproject_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
+                    LTM_HIP(map_range_images(map.d, map.n, p.inv_dev, kb, nb, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream));
+                }
+                ProfScope ps(c, "reproject_gather", (double)(nb * npx), (double)(nb * npx) * 12);
+                LTM_HIP(exclusive_scan_img_valid(img.as<uint64_t>(), pos.as<uint32_t>(), nb * npx, temp.p, tb, c->stream));
+                // per-keyframe boundaries = scan value at each image start; the total is the scan past the end
+                std::vector<uint64_t> bounds(nb + 1);
+                for (size_t j = 0; j <= nb; ++j) bounds[j] = j * npx;
+                uint32_t last_pos = 0; uint64_t last_img = 0;
+                LTM_HIP(hipMemcpyAsync(&last_pos, pos.as<uint32_t>() + (nb * npx - 1), 4, hipMemcpyDeviceToHost, c->stream));
+                LTM_HIP(hipMemcpyAsync(&last_img, img.as<uint64_t>() + (nb * npx - 1), 8, hipMemcpyDeviceToHost, c->stream));
+                sync(c);
+                const size_t total = (size_t)last_pos + (((uint32_t)last_img) ? 1 : 0);
+                h2d(c, bdev.p, bounds.data(), (nb + 1) * 8);
+                LTM_HIP(gather_u32(pos.as<uint32_t>(), bdev.as<uint64_t>(), nb + 1, nb * npx, (uint32_t)total, bout.as<uint32_t>(), c->stream));
+                std::vector<uint32_t> b(nb + 1);
+                d2h(c, b.data(), bout.p, (nb + 1) * 4);
+                const uint64_t base = off[kb - kf_begin];
+                for (size_t j = 1; j <= nb; ++j) off[kb - kf_begin + j] = base + b[j];
+                float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(total, 1) * 16));
+                LTM_HIP(reproject_gather(img.as<uint64_t>(), pos.as<uint32_t>(), npx, nb, map.d, p.inv_dev, kb, c->B2L, c->b2l_identity, d, c->stream));
+                pieces.push_back(Piece{d, total});
+            }
+        }
+        float4* d = nullptr;
+        if (pieces.size() == 1) d = pieces[0].d;
+        else {
+            d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(off[nk], 1) * 16));
+            size_t at = 0;
+            for (Piece& pc : pieces) { d2d(c, d + at, pc.d, pc.n * 16); at += pc.n; }
+            sync(c);
+            for (Piece& pc : pieces) c->pool.free(pc.d);
+        }
+        *out = new_scanset(c, d, std::move(off));
+    });
+}
+
+int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses hp, size_t kf_begin, size_t kf_end, int k, float thr,
+                      ltm_scanset* coexist, ltm_scanset* diff)
+{
+    return guarded(c, [&] {
+        const Cloud target = get_cloud(c, htarget);
+        const ScanSet& s = get_ss(c, hs);
+        const Poses& p = get_poses(c, hp);
+        LTM_REQUIRE(s.nkf() == p.n, "scan set and poses have different keyframe counts");
+        LTM_REQUIRE(kf_begin <= kf_end && kf_end <= p.n, "keyframe range out of bounds");
+        KnnIndex index(c);
+        index.build(target, k, thr);
+        const uint64_t first = s.off[kf_begin], n = s.off[kf_end] - first;
+        DevBuf flag(c, std::max<size_t>(n, 1)), local(c, std::max<size_t>(n, 1) * 16);
+        {
+            ProfScope ps(c, "knn_query", (double)n, (double)n * (16.0 + 16.0 * k + 1.0));
+            LTM_HIP(knn_query_scans(s.d, s.off_dev, kf_begin, kf_end, first, n, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.sorted,
+                                    index.Mt, index.g, index.table, index.mask, k, thr, index.cell2_lo, flag.as<uint8_t>(), local.as<float4>(), c->stream));
+        }
+        std::vector<uint64_t> bounds(kf_end - kf_begin + 1);
+        for (size_t j = 0; j < bounds.size(); ++j) bounds[j] = s.off[kf_begin + j] - first;
+        float4 *d_co, *d_di;
+        std::vector<uint64_t> off_co, off_di;
+        split_by_flag(c, local.as<float4>(), flag.as<uint8_t>(), n, bounds, &d_co, &off_co, &d_di, &off_di);
+        if (coexist) *coexist = new_scanset(c, d_co, std::move(off_co)); else c->pool.free(d_co);
+        if (diff) *diff = new_scanset(c, d_di, std::move(off_di)); else c->pool.free(d_di);
+    });
+}
+
+int ltm_knn_split_cloud(ltm_ctx* c, ltm_cloud htarget, ltm_cloud hquery, int k, float thr, ltm_cloud* near, ltm_cloud* far)
+{
+    return guarded(c, [&] {
+        const Cloud target = get_cloud(c, htarget);
+        const Cloud query = get_cloud(c, hquery);
+        KnnIndex index(c);
+        index.build(target, k, thr);
+        DevBuf flag(c, std::max<size_t>(query.n, 1));
+        {
+            ProfScope ps(c, "knn_query", (double)query.n, (double)query.n * (16.0 + 16.0 * k + 1.0));
+            LTM_HIP(knn_query_cloud(query.d, query.n, index.sorted, index.Mt, index.g, index.table, index.mask, k, thr, index.cell2_lo,
+                                    flag.as<uint8_t>(), c->stream));
+        }
+        do_partition(c, query, flag.as<uint8_t>(), far, near);
+    });
+}
+
+// ------------------------------------------------------------------------- debug / parity
+int ltm_debug_range_image(ltm_ctx* c, ltm_cloud h, const double* T1, const double* T2, float alpha, float* rimg, int32_t* ptidx)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(rimg, "null argument");
+        const Cloud cl = get_cloud(c, h);
+        const Geom g = geom_for(c, alpha);
+        const size_t npx = (size_t)g.rows * g.cols;
+        DevBuf img(c, npx * 8), r(c, npx * 4), ix(c, npx * 4);
+        LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, npx, c->stream));
+        HostMat34 a, b;
+        if (T1) a = to34(T1);
+        if (T2) b = to34(T2);
+        LTM_HIP(single_range_image(cl.d, cl.n, T1 ? &a : nullptr, T2 ? &b : nullptr, g, img.as<uint64_t>(), c->stream));
+        LTM_HIP(decode_image(img.as<uint64_t>(), npx, r.as<float>(), ix.as<int32_t>(), c->stream));
+        d2h(c, rimg, r.p, npx * 4);
+        if (ptidx) d2h(c, ptidx, ix.p, npx * 4);
+    });
+}
+
+int ltm_debug_project(ltm_ctx* c, const float* xyz, size_t n, float alpha, float* sph, int32_t* rc)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE((xyz && sph && rc) || n == 0, "null argument");
+        if (!n) return;
+        const Geom g = geom_for(c, alpha);
+        DevBuf in(c, n * 12), o1(c, n * 12), o2(c, n * 8);
+        h2d(c, in.p, xyz, n * 12);
+        LTM_HIP(debug_project(in.as<float>(), n, g, o1.as<float>(), o2.as<int32_t>(), c->stream));
+        d2h(c, sph, o1.p, n * 12);
+        d2h(c, rc, o2.p, n * 8);
+    });
+}
+
+// ---------------------------------------------------------------------------- profiling
+int ltm_profile_enable(ltm_ctx* c, int on) { return guarded(c, [&] { if (!on) prof_collect(c); c->prof_on = on != 0; }); }
+int ltm_profile_reset(ltm_ctx* c)
+{
+    return guarded(c, [&] { prof_collect(c); for (ProfClass& p : c->prof) p = ProfClass(); });
+}
+int ltm_profile_read(ltm_ctx* c, const char** names, double* ms, uint64_t* launches, double* units, double* bytes, int cap)
+{
+    if (!c) return LTM_E_INVALID;
+    const int rc = guarded(c, [&] { prof_collect(c); });
+    if (rc != LTM_OK) return rc;
+    const int n = (int)c->prof.size();
+    for (int i = 0; i < n && i < cap; ++i) {
+        if (names) names[i] = c->prof_names[i].c_str();
+        if (ms) ms[i] = c->prof[i].ms;
+        if (launches) launches[i] = c->prof[i].launches;
+        if (units) units[i] = c->prof[i].units;
+        if (bytes) bytes[i] = c->prof[i].bytes;
+    }
+    return n;
+}
+
+} // extern "C"

@@ -1,0 +1,180 @@
+// ltm_device_math.h -- gfx950 device arithmetic for the projection hot path.
+//
+// Everything here must reproduce, bit for bit, what the reference's generic x86-64 build computes
+// (ltremovert/src/utility.cpp:38-56 cart2sph/rad2deg, :114-125 pixel index, :64-72 transform):
+// binary32/binary64 IEEE arithmetic, round-to-nearest-even, NO fused multiply-add.  The translation
+// unit is compiled with -ffp-contract=off; f32 divide and sqrt are the correctly rounded forms
+// (hipcc default -fhip-fp32-correctly-rounded-divide-sqrt).  Explicit __builtin_fmaf is used only
+// where a proof of exactness is given next to it.
+//
+// atan2f follows the algorithm glibc ships for binary32 (flt-32 e_atan2f / s_atanf: 5-interval
+// reduction at 7/16, 11/16, 19/16, 39/16, odd degree-11 polynomial split in two halves, hi/lo
+// tables), restructured for a SIMT machine: one select-driven straight-line body for every finite
+// non-zero argument pair, and a never-inlined slow function for zeros/inf/NaN/extreme ratios.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace ltm {
+
+__device__ __forceinline__ uint32_t f2u(float f) { return __float_as_uint(f); }
+__device__ __forceinline__ float u2f(uint32_t u) { return __uint_as_float(u); }
+
+// atan(|x|) for finite |x| < 2^25 given as its bit pattern ix (sign stripped); returns >= 0.
+__device__ __forceinline__ float atanf_pos_core(float ax, uint32_t ix)
+{
+    // interval select: id = -1 (<7/16), 0 (<11/16), 1 (<19/16), 2 (<39/16), 3 (otherwise)
+    const bool lt0 = ix < 0x3ee00000u;
+    const bool lt1 = ix < 0x3f300000u;
+    const bool lt2 = ix < 0x3f980000u;
+    const bool lt3 = ix < 0x401c0000u;
+    // numerator / denominator of the reduced argument (one divide on every path; x/1 is exact)
+    //   id0: (2x-1)/(2+x)   id1: (x-1)/(x+1)   id2: (x-1.5)/(1+1.5x)   id3: -1/x   id-1: x/1
+    const float two_x = 2.0f * ax;
+    const float num = lt0 ? ax : (lt1 ? (two_x - 1.0f) : (lt2 ? (ax - 1.0f) : (lt3 ? (ax - 1.5f) : -1.0f)));
+    const float den = lt0 ? 1.0f : (lt1 ? (2.0f + ax) : (lt2 ? (ax + 1.0f) : (lt3 ? (1.0f + 1.5f * ax) : ax)));
+    const float hi = lt0 ? 0.0f : (lt1 ? 4.6364760399e-01f : (lt2 ? 7.8539812565e-01f : (lt3 ? 9.8279368877e-01f : 1.5707962513e+00f)));
+    const float lo = lt0 ? 0.0f : (lt1 ? 5.0121582440e-09f : (lt2 ? 3.7748947079e-08f : (lt3 ? 3.4473217170e-08f : 7.5497894159e-08f)));
+    const float t = num / den;
+    const float z = t * t;
+    const float w = z * z;
+    const float s1 = z * (3.3333334327e-01f + w * (1.4285714924e-01f + w * (9.0908870101e-02f + w * (6.6610731184e-02f +
+                     w * (4.9768779427e-02f + w * 1.6285819933e-02f)))));
+    const float s2 = w * (-2.0000000298e-01f + w * (-1.1111110449e-01f + w * (-7.6918758452e-02f + w * (-5.8335702866e-02f +
+                     w * -3.6531571299e-02f))));
+    // id>=0: hi - ((t*(s1+s2) - lo) - t).  With hi = lo = 0 the same expression is -(t*s - t) == t - t*s
+    // exactly (negation commutes with rounding), which is the id<0 formula.
+    return hi - ((t * (s1 + s2) - lo) - t);
+}
+
+// full atanf (used by the slow path and by debug entry points)
+__device__ __forceinline__ float atanf_exact(float x)
+{
+    const uint32_t hx = f2u(x), ix = hx & 0x7fffffffu;
+    if (ix >= 0x4c000000u) {
+        if (ix > 0x7f800000u) return x + x;
+        const float big = 1.5707962513e+00f + 7.5497894159e-08f;
+        return (hx >> 31) ? -big : big;
+    }
+    if (ix < 0x31000000u) return x;
+    const float r = atanf_pos_core(u2f(ix), ix);
+    return (hx >> 31) ? -r : r;
+}
+
+__device__ __noinline__ float atan2f_slow(float y, float x)
+{
+    const float tiny = 1.0e-30f, pi_o_4 = 7.8539818525e-01f, pi_o_2 = 1.5707963705e+00f;
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const uint32_t hx = f2u(x), hy = f2u(y), ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    if (ix > 0x7f800000u || iy > 0x7f800000u) return x + y;
+    if (hx == 0x3f800000u) return atanf_exact(y);
+    const int m = (int)((hy >> 31) & 1u) | (int)((hx >> 30) & 2u);
+    if (iy == 0) return (m < 2) ? y : ((m == 2) ? pi + tiny : -pi - tiny);
+    if (ix == 0) return (hy >> 31) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    if (ix == 0x7f800000u) {
+        if (iy == 0x7f800000u)
+            return (m == 0) ? pi_o_4 + tiny : (m == 1) ? -pi_o_4 - tiny : (m == 2) ? 3.0f * pi_o_4 + tiny : -3.0f * pi_o_4 - tiny;
+        return (m == 0) ? 0.0f : (m == 1) ? -0.0f : (m == 2) ? pi + tiny : -pi - tiny;
+    }
+    if (iy == 0x7f800000u) return (hy >> 31) ? -pi_o_2 - tiny : pi_o_2 + tiny;
+    const int k = ((int)iy - (int)ix) >> 23;
+    float z;
+    if (k > 60) z = pi_o_2 + 0.5f * pi_lo;
+    else if ((hx >> 31) && k < -60) z = 0.0f;
+    else z = atanf_exact(u2f(f2u(y / x) & 0x7fffffffu));
+    return (m == 0) ? z : (m == 1) ? u2f(f2u(z) ^ 0x80000000u) : (m == 2) ? pi - (z - pi_lo) : (z - pi_lo) - pi;
+}
+
+__device__ __forceinline__ float atan2f_exact(float y, float x)
+{
+    const uint32_t hx = f2u(x), hy = f2u(y), ix = hx & 0x7fffffffu, iy = hy & 0x7fffffffu;
+    const int k = ((int)iy - (int)ix) >> 23;
+    // fast domain: both finite and non-zero, exponent gap within +-60
+    const bool fast = (ix - 1u < 0x7f7fffffu) && (iy - 1u < 0x7f7fffffu) && (k <= 60) && (k >= -60);
+    if (__builtin_expect(!fast, 0)) return atan2f_slow(y, x);
+    const float q = u2f(f2u(y / x) & 0x7fffffffu);   // |y/x|, finite: |k|<=60 keeps it well inside the range
+    const uint32_t iq = f2u(q);
+    float z;
+    if (iq >= 0x4c000000u) z = 1.5707962513e+00f + 7.5497894159e-08f;
+    else if (iq < 0x31000000u) z = q;
+    else z = atanf_pos_core(q, iq);
+    const float pi = 3.1415927410e+00f, pi_lo = -8.7422776573e-08f;
+    const bool xneg = hx >> 31, yneg = hy >> 31;
+    const float zz = z - pi_lo;
+    // m = 2*xneg + yneg : 0 -> z ; 1 -> -z ; 2 -> pi-(z-pi_lo) ; 3 -> (z-pi_lo)-pi
+    return xneg ? (yneg ? (zz - pi) : (pi - zz)) : (yneg ? -z : z);
+}
+
+// utility.cpp:53-56  float rad2deg(float r) { return r * 180.0 / M_PI; }  -> (float)(((double)r*180.0)/pi)
+__device__ __forceinline__ float rad2deg_exact(float r)
+{
+    return (float)(((double)r * 180.0) / 3.14159265358979323846);
+}
+
+struct Sph { float az, el, r; };
+
+// utility.cpp:38-51
+__device__ __forceinline__ Sph cart2sph(float x, float y, float z)
+{
+    Sph s;
+    const float xx = x * x, yy = y * y, zz = z * z;
+    const float xy = xx + yy;
+    s.az = atan2f_exact(y, x);
+    s.el = atan2f_exact(z, __fsqrt_rn(xy));
+    s.r = __fsqrt_rn(xy + zz);
+    return s;
+}
+
+struct RimgGeom {
+    float vfov, hfov;   // degrees
+    float half_v, half_h;
+    int rows, cols;
+    float frows, fcols, row_max, col_max;
+};
+
+// utility.cpp:114-125
+__device__ __forceinline__ int pixel_index(const RimgGeom& g, float az, float el)
+{
+    const float el_deg = rad2deg_exact(el);
+    const float az_deg = rad2deg_exact(az);
+    float fr = roundf(g.frows * (1.0f - (el_deg + g.half_v) / g.vfov));
+    float fc = roundf(g.fcols * ((az_deg + g.half_h) / g.hfov));
+    // std::min(std::max(v, 0), hi): max(a,b) = (a<b)?b:a ; min(a,b) = (b<a)?b:a
+    fr = (fr < 0.0f) ? 0.0f : fr;  fr = (g.row_max < fr) ? g.row_max : fr;
+    fc = (fc < 0.0f) ? 0.0f : fc;  fc = (g.col_max < fc) ? g.col_max : fc;
+    return (int)fr * g.cols + (int)fc;
+}
+
+// PCL transformPointCloud<PointXYZI,double>: (float)(((m0*x + m1*y) + m2*z) + m3) per row, double math.
+struct Mat34 { double m[12]; };
+
+__device__ __forceinline__ float3 xform(const Mat34& T, float3 p)
+{
+    const double x = p.x, y = p.y, z = p.z;
+    float3 o;
+    o.x = (float)(((T.m[0] * x + T.m[1] * y) + T.m[2] * z) + T.m[3]);
+    o.y = (float)(((T.m[4] * x + T.m[5] * y) + T.m[6] * z) + T.m[7]);
+    o.z = (float)(((T.m[8] * x + T.m[9] * y) + T.m[10] * z) + T.m[11]);
+    return o;
+}
+
+// An identity matrix still executes ((1*x + 0*y) + 0*z) + 0 in the reference: that is x + 0.0, which maps
+// -0 to +0 and leaves everything else (finite) untouched.
+__device__ __forceinline__ float3 xform_identity(float3 p)
+{
+    float3 o;
+    o.x = p.x + 0.0f; o.y = p.y + 0.0f; o.z = p.z + 0.0f;
+    return o;
+}
+
+// FLANN L2_Simple<float>: result = 0; for d: diff = a[d]-b[d]; result += diff*diff
+__device__ __forceinline__ float sqdist_l2simple(float qx, float qy, float qz, float tx, float ty, float tz)
+{
+    const float dx = qx - tx, dy = qy - ty, dz = qz - tz;
+    float r = dx * dx;
+    r = r + dy * dy;
+    r = r + dz * dz;
+    return r;
+}
+
+} // namespace ltm

@@ -1,0 +1,98 @@
+// ltm_kernels.h -- host-callable launchers of the gfx950 kernels (definitions in ltm_kernels.hip).
+// All launchers enqueue on the given stream and return the hipError_t of the launch.
+#pragma once
+#include <hip/hip_runtime_api.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace ltm {
+
+struct Geom {            // range-image geometry (utility.cpp:222-236 resetRimgSize + fov)
+    float vfov, hfov;
+    int rows, cols;
+};
+
+// 3x4 row-major double (last row of the 4x4 is never used by PCL's se3 transformer)
+struct HostMat34 { double m[12]; };
+
+static const uint32_t kNoPointBits = 0x461C4000u;   // bit pattern of kFlagNoPOINT = 10000.0f (utility.h:93)
+
+// ---- fills ----
+hipError_t fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s);
+hipError_t fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
+
+// ---- projection / vote ----
+// scan2RangeImg for keyframes [kb, kb+nb): scan_img[(kf-kb)*npx + px] = min range bits
+hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb,
+                             uint64_t first_pt, uint64_t n_pts, Geom g, uint32_t* scan_img, hipStream_t s);
+// transformGlobalMapToLocal + map2RangeImg: map_img[(kf-kb)*npx+px] = min (range_bits<<32 | idx)
+// inv_poses_dev: 12 doubles per keyframe (3x4 row-major).  b2l: 12 doubles, b2l_identity skips the arithmetic.
+hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb,
+                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
+// calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
+hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
+                            uint8_t* labels, hipStream_t s);
+// generic single image with up to two explicit transforms (debug / parity)
+hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,
+                              uint64_t* img, hipStream_t s);
+hipError_t decode_image(const uint64_t* img, size_t npx, float* rimg, int32_t* ptidx, hipStream_t s);
+hipError_t debug_project(const float* xyz_dev, size_t n, Geom g, float* az_el_r, int32_t* row_col, hipStream_t s);
+
+// ---- compaction helpers (prefix sums via rocPRIM) ----
+size_t scan_temp_bytes(size_t n);
+// exclusive scan of (labels[i] != 0) into pos[i] (uint32); temp from scan_temp_bytes(n)
+hipError_t exclusive_scan_u8(const uint8_t* labels, uint32_t* pos, size_t n, void* temp, size_t temp_bytes, hipStream_t s);
+// exclusive scan of ((uint32)img[i] != 0)
+hipError_t exclusive_scan_img_valid(const uint64_t* img, uint32_t* pos, size_t n, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t s);
+// kept/flagged split in ascending index order: pos = exclusive scan of labels
+hipError_t partition_scatter(const float4* in, const uint8_t* labels, const uint32_t* pos, size_t n,
+                             float4* kept, float4* flagged, hipStream_t s);
+// reprojection gather: out[pos[i]] = local-frame map point of pixel i (if valid)
+hipError_t reproject_gather(const uint64_t* img, const uint32_t* pos, size_t npx, size_t nb, const float4* map,
+                            const double* inv_poses_dev, size_t kb, HostMat34 b2l, int b2l_identity,
+                            float4* out, hipStream_t s);
+// gather arbitrary positions of a u32 array: out[j] = (idx[j] < n ? in[idx[j]] : tail)
+hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, size_t n, uint32_t tail_value_index_n,
+                      uint32_t* out, hipStream_t s);
+
+// ---- transforms ----
+// out[i] = xform(second, xform(first, in[i])) with per-keyframe `second` (merge: first=L2B, second=pose[kf])
+hipError_t transform_scans(const float4* in, const uint64_t* offsets_dev, size_t n_kf, uint64_t n_pts,
+                           HostMat34 first, int first_identity, const double* per_kf_dev, float4* out, hipStream_t s);
+hipError_t preclean_flags(const float4* in, uint64_t n, float radius, uint8_t* keep, hipStream_t s);
+
+// ---- voxel centroid ----
+// bbox[6] device floats encoded as ordered uint32: minx,miny,minz,maxx,maxy,maxz (init by bbox_init)
+hipError_t bbox_init(uint32_t* bbox, hipStream_t s);
+hipError_t bbox_reduce(const float4* pts, size_t n, uint32_t* bbox, hipStream_t s);
+float      bbox_decode(uint32_t enc);
+struct OctreeFrame { double minx, miny, minz, res; unsigned depth; };
+hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* keys, uint32_t* idx, hipStream_t s);
+size_t sort_temp_bytes(size_t n);
+hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
+                          unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s);
+// starts[u] = j for every head j (u = pos[j])
+hipError_t segment_starts(const uint8_t* heads, const uint32_t* pos, size_t n, uint32_t* starts, hipStream_t s);
+hipError_t voxel_centroids(const float4* pts, const uint32_t* sorted_idx, const uint32_t* starts, size_t n_vox, size_t n,
+                           float4* out, hipStream_t s);
+
+// ---- kNN ----
+struct KnnGrid { double ox, oy, oz, inv_cell; long long nx, ny, nz; };
+hipError_t cell_keys(const float4* pts, size_t n, KnnGrid g, uint64_t* keys, uint32_t* idx, hipStream_t s);
+hipError_t gather_points(const float4* in, const uint32_t* idx, size_t n, float4* out, hipStream_t s);
+hipError_t gather_u64(const uint64_t* in, const uint32_t* idx, size_t n, uint64_t* out, hipStream_t s);
+struct HashEntry { uint64_t key; uint32_t start, end; };
+hipError_t hash_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, size_t n_pts,
+                      HashEntry* table, uint32_t table_mask, hipStream_t s);
+// queries in scan sets: g = pose*(first*p) ; label = coexist ; local = b2l*(inv*g)
+hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
+                           const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
+                           const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask,
+                           int k, float thr, float cell2_lo, uint8_t* coexist, float4* local_out, hipStream_t s);
+hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g,
+                           const HashEntry* table, uint32_t table_mask, int k, float thr, float cell2_lo,
+                           uint8_t* near, hipStream_t s);
+
+} // namespace ltm

@@ -1,0 +1,722 @@
+// ltm_kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels of the LT-removert / LT-map hot path.
+//
+// Build: hipcc --offload-arch=gfx950 -O3 -ffp-contract=off (bit-exact parity with the reference's
+// non-FMA x86-64 arithmetic; see ltm_device_math.h).
+//
+// Data layout in HBM: clouds are float4 XYZI arrays (16 B/pt, one coalesced dwordx4 load per lane);
+// a range image is ONE 64-bit word per pixel, (range_bits << 32) | point_index, so that the serial
+// reference rule "strictly smaller range wins, lowest index wins ties" (utility.cpp:134-138) is a
+// single order on uint64 and a single global_atomic_umin_x2; scan images only need the range (u32).
+// Images of a whole batch of keyframes are resident at once ([kf][row][col]); one launch covers
+// (map tiles) x (keyframes).
+#include "ltm_kernels.h"
+#include "ltm_device_math.h"
+
+#include <algorithm>
+#include <cstring>
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_radix_sort.hpp>
+#include <rocprim/device/device_scan.hpp>
+#include <rocprim/iterator/transform_iterator.hpp>
+
+namespace ltm {
+
+static constexpr int kBlock = 256;
+
+__host__ __device__ inline RimgGeom make_geom(Geom g)
+{
+    RimgGeom r;
+    r.vfov = g.vfov; r.hfov = g.hfov;
+    r.half_v = g.vfov / 2.0f; r.half_h = g.hfov / 2.0f;
+    r.rows = g.rows; r.cols = g.cols;
+    r.frows = (float)g.rows; r.fcols = (float)g.cols;
+    r.row_max = (float)(g.rows - 1); r.col_max = (float)(g.cols - 1);
+    return r;
+}
+
+static inline unsigned grid_for(size_t n, int block = kBlock)
+{
+    size_t b = (n + block - 1) / block;
+    return (unsigned)(b == 0 ? 1 : b);
+}
+
+// ------------------------------------------------------------------------------------ fills
+__global__ void k_fill_u32(uint32_t* p, uint32_t v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+__global__ void k_fill_u64(uint64_t* p, uint64_t v, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += stride) p[i] = v;
+}
+hipError_t fill_u32(uint32_t* p, uint32_t v, size_t n, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_fill_u32<<<dim3((unsigned)std::min<size_t>(grid_for(n), 8192)), dim3(kBlock), 0, s>>>(p, v, n);
+    return hipGetLastError();
+}
+hipError_t fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_fill_u64<<<dim3((unsigned)std::min<size_t>(grid_for(n), 8192)), dim3(kBlock), 0, s>>>(p, v, n);
+    return hipGetLastError();
+}
+
+// --------------------------------------------------------------------------- projection / vote
+__device__ __forceinline__ Mat34 load_mat(const double* p)
+{
+    Mat34 T;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T.m[i] = p[i];
+    return T;
+}
+__device__ __forceinline__ Mat34 to_dev(const HostMat34& h)
+{
+    Mat34 T;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) T.m[i] = h.m[i];
+    return T;
+}
+
+// range-min with a relaxed pre-test: the image only ever decreases, so a stale (larger) value read
+// can only let a redundant atomic through, never suppress a needed one.
+__device__ __forceinline__ void img_min_u64(uint64_t* p, uint64_t v)
+{
+    const uint64_t cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v < cur) atomicMin(reinterpret_cast<unsigned long long*>(p), (unsigned long long)v);
+}
+__device__ __forceinline__ void img_min_u32(uint32_t* p, uint32_t v)
+{
+    const uint32_t cur = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (v < cur) atomicMin(p, v);
+}
+
+// Removerter.cpp:109-156 scan2RangeImg, all keyframes of a batch in one launch.
+__global__ void __launch_bounds__(kBlock)
+k_scan_rimg(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t nb,
+            uint64_t first_pt, uint64_t n_pts, Geom gg, uint32_t* __restrict__ img)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts) return;
+    const uint64_t gi = first_pt + i;
+    // keyframe of this point: largest kf in [kb, kb+nb) with offsets[kf] <= gi
+    size_t lo = kb, hi = kb + nb;
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= gi) lo = mid; else hi = mid;
+    }
+    const RimgGeom g = make_geom(gg);
+    const float4 p = scans[gi];
+    const Sph s = cart2sph(p.x, p.y, p.z);
+    const int px = pixel_index(g, s.az, s.el);
+    img_min_u32(img + (lo - kb) * (size_t)(g.rows * g.cols) + px, f2u(s.r));
+}
+
+hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t first_pt,
+                             uint64_t n_pts, Geom g, uint32_t* scan_img, hipStream_t s)
+{
+    if (!n_pts) return hipSuccess;
+    k_scan_rimg<<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, nb, first_pt, n_pts, g, scan_img);
+    return hipGetLastError();
+}
+
+// utility.cpp:64-72 + :92-142.  grid = (map tiles, keyframes of the batch)
+template <bool B2L_IDENTITY>
+__global__ void __launch_bounds__(kBlock)
+k_map_rimg(const float4* __restrict__ map, size_t M, const double* __restrict__ inv_poses, size_t kb,
+           HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= M) return;
+    const size_t kf = kb + blockIdx.y;
+    const Mat34 Tinv = load_mat(inv_poses + 12 * kf);
+    const RimgGeom g = make_geom(gg);
+    const float4 p4 = map[i];
+    float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+    const Sph s = cart2sph(p.x, p.y, p.z);
+    const int px = pixel_index(g, s.az, s.el);
+    const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)(uint32_t)i;
+    img_min_u64(img + (size_t)blockIdx.y * (size_t)(g.rows * g.cols) + px, v);
+}
+
+hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb, HostMat34 b2l,
+                            int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s)
+{
+    if (!M || !nb) return hipSuccess;
+    dim3 grid(grid_for(M), (unsigned)nb);
+    if (b2l_identity) k_map_rimg<true><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+    else k_map_rimg<false><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+    return hipGetLastError();
+}
+
+// Removerter.cpp:381-413 (+ the diff of :458 / :515 / :572)
+__global__ void __launch_bounds__(kBlock)
+k_compare_flag(const uint32_t* __restrict__ scan_img, const uint64_t* __restrict__ map_img, size_t n, float thr, int mode,
+               uint8_t* __restrict__ labels)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t mv = map_img[i];
+    const float map_r = u2f((uint32_t)(mv >> 32));
+    const float scan_r = u2f(scan_img[i]);
+    const float diff = (mode == 0) ? (scan_r - map_r) : (map_r - scan_r);
+    if (diff < 200.0f /* kValidDiffUpperBound, utility.h:94 */ && diff > thr) labels[(uint32_t)mv] = 1;
+}
+
+hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n, float thr, int mode, uint8_t* labels,
+                            hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_compare_flag<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(scan_img, map_img, n, thr, mode, labels);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_single_rimg(const float4* __restrict__ pts, size_t n, HostMat34 T1, int has1, HostMat34 T2, int has2, Geom gg,
+              uint64_t* __restrict__ img)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RimgGeom g = make_geom(gg);
+    const float4 p4 = pts[i];
+    float3 p = make_float3(p4.x, p4.y, p4.z);
+    if (has1) p = xform(to_dev(T1), p);
+    if (has2) p = xform(to_dev(T2), p);
+    const Sph s = cart2sph(p.x, p.y, p.z);
+    const int px = pixel_index(g, s.az, s.el);
+    img_min_u64(img + px, ((uint64_t)f2u(s.r) << 32) | (uint64_t)(uint32_t)i);
+}
+
+hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g, uint64_t* img,
+                              hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    HostMat34 z{};
+    k_single_rimg<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, T1 ? *T1 : z, T1 != nullptr, T2 ? *T2 : z, T2 != nullptr, g, img);
+    return hipGetLastError();
+}
+
+__global__ void k_decode_image(const uint64_t* img, size_t npx, float* rimg, int32_t* ptidx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= npx) return;
+    const uint64_t v = img[i];
+    rimg[i] = u2f((uint32_t)(v >> 32));
+    if (ptidx) ptidx[i] = (int32_t)(uint32_t)v;
+}
+hipError_t decode_image(const uint64_t* img, size_t npx, float* rimg, int32_t* ptidx, hipStream_t s)
+{
+    k_decode_image<<<dim3(grid_for(npx)), dim3(kBlock), 0, s>>>(img, npx, rimg, ptidx);
+    return hipGetLastError();
+}
+
+__global__ void k_debug_project(const float* xyz, size_t n, Geom gg, float* sph, int32_t* rc)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RimgGeom g = make_geom(gg);
+    const Sph s = cart2sph(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2]);
+    sph[3 * i] = s.az; sph[3 * i + 1] = s.el; sph[3 * i + 2] = s.r;
+    const int px = pixel_index(g, s.az, s.el);
+    rc[2 * i] = px / g.cols; rc[2 * i + 1] = px % g.cols;
+}
+hipError_t debug_project(const float* xyz_dev, size_t n, Geom g, float* az_el_r, int32_t* row_col, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_debug_project<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(xyz_dev, n, g, az_el_r, row_col);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------ scans
+struct U8Flag { __host__ __device__ uint32_t operator()(uint8_t v) const { return v ? 1u : 0u; } };
+struct ImgValid { __host__ __device__ uint32_t operator()(uint64_t v) const { return ((uint32_t)v) ? 1u : 0u; } };
+
+size_t scan_temp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    uint32_t* d = nullptr;
+    (void)rocprim::exclusive_scan(nullptr, bytes, d, d, 0u, n ? n : 1, rocprim::plus<uint32_t>());
+    return bytes + 256;
+}
+hipError_t exclusive_scan_u8(const uint8_t* labels, uint32_t* pos, size_t n, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    auto it = rocprim::make_transform_iterator(labels, U8Flag());
+    return rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, n, rocprim::plus<uint32_t>(), s);
+}
+hipError_t exclusive_scan_img_valid(const uint64_t* img, uint32_t* pos, size_t n, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    auto it = rocprim::make_transform_iterator(img, ImgValid());
+    return rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, n, rocprim::plus<uint32_t>(), s);
+}
+hipError_t exclusive_scan_u32(const uint32_t* in, uint32_t* out, size_t n, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    return rocprim::exclusive_scan(temp, temp_bytes, in, out, 0u, n, rocprim::plus<uint32_t>(), s);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_partition_scatter(const float4* __restrict__ in, const uint8_t* __restrict__ labels, const uint32_t* __restrict__ pos, size_t n,
+                    float4* __restrict__ kept, float4* __restrict__ flagged)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const uint32_t f = pos[i];
+    if (labels[i]) { if (flagged) flagged[f] = p; }
+    else if (kept) kept[i - f] = p;
+}
+hipError_t partition_scatter(const float4* in, const uint8_t* labels, const uint32_t* pos, size_t n, float4* kept, float4* flagged,
+                             hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_partition_scatter<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(in, labels, pos, n, kept, flagged);
+    return hipGetLastError();
+}
+
+template <bool B2L_IDENTITY>
+__global__ void __launch_bounds__(kBlock)
+k_reproject_gather(const uint64_t* __restrict__ img, const uint32_t* __restrict__ pos, size_t npx, size_t total,
+                   const float4* __restrict__ map, const double* __restrict__ inv_poses, size_t kb, HostMat34 b2l_h,
+                   float4* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const uint32_t idx = (uint32_t)img[i];
+    if (idx == 0) return;                                   // utility.cpp:82 -- 0 doubles as "no point"
+    const size_t kf = kb + i / npx;
+    const Mat34 Tinv = load_mat(inv_poses + 12 * kf);
+    const float4 p4 = map[idx];
+    float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+    out[pos[i]] = make_float4(p.x, p.y, p.z, p4.w);
+}
+hipError_t reproject_gather(const uint64_t* img, const uint32_t* pos, size_t npx, size_t nb, const float4* map,
+                            const double* inv_poses_dev, size_t kb, HostMat34 b2l, int b2l_identity, float4* out, hipStream_t s)
+{
+    const size_t total = npx * nb;
+    if (!total) return hipSuccess;
+    if (b2l_identity) k_reproject_gather<true><<<dim3(grid_for(total)), dim3(kBlock), 0, s>>>(img, pos, npx, total, map, inv_poses_dev, kb, b2l, out);
+    else k_reproject_gather<false><<<dim3(grid_for(total)), dim3(kBlock), 0, s>>>(img, pos, npx, total, map, inv_poses_dev, kb, b2l, out);
+    return hipGetLastError();
+}
+
+__global__ void k_gather_u32(const uint32_t* in, const uint64_t* idx, size_t m, size_t n, uint32_t tail, uint32_t* out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= m) return;
+    const uint64_t i = idx[j];
+    out[j] = (i < n) ? in[i] : tail;
+}
+hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, size_t n, uint32_t tail, uint32_t* out, hipStream_t s)
+{
+    if (!m) return hipSuccess;
+    k_gather_u32<<<dim3(grid_for(m)), dim3(kBlock), 0, s>>>(in, idx_dev, m, n, tail, out);
+    return hipGetLastError();
+}
+
+// -------------------------------------------------------------------------------- transforms
+__device__ __forceinline__ size_t find_kf(const uint64_t* __restrict__ offsets, size_t lo, size_t hi, uint64_t gi)
+{
+    while (hi - lo > 1) {
+        const size_t mid = (lo + hi) >> 1;
+        if (offsets[mid] <= gi) lo = mid; else hi = mid;
+    }
+    return lo;
+}
+
+template <bool FIRST_IDENTITY>
+__global__ void __launch_bounds__(kBlock)
+k_transform_scans(const float4* __restrict__ in, const uint64_t* __restrict__ offsets, size_t n_kf, uint64_t n_pts,
+                  HostMat34 first_h, const double* __restrict__ per_kf, float4* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts) return;
+    const size_t kf = find_kf(offsets, 0, n_kf, i);
+    const float4 p4 = in[i];
+    float3 p = make_float3(p4.x, p4.y, p4.z);
+    if (FIRST_IDENTITY) p = xform_identity(p); else p = xform(to_dev(first_h), p);
+    p = xform(load_mat(per_kf + 12 * kf), p);
+    out[i] = make_float4(p.x, p.y, p.z, p4.w);
+}
+hipError_t transform_scans(const float4* in, const uint64_t* offsets_dev, size_t n_kf, uint64_t n_pts, HostMat34 first,
+                           int first_identity, const double* per_kf_dev, float4* out, hipStream_t s)
+{
+    if (!n_pts) return hipSuccess;
+    if (first_identity) k_transform_scans<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(in, offsets_dev, n_kf, n_pts, first, per_kf_dev, out);
+    else k_transform_scans<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(in, offsets_dev, n_kf, n_pts, first, per_kf_dev, out);
+    return hipGetLastError();
+}
+
+// Session.cpp:506-533: drop iff (range < radius) & (z < 0.5) & (-0.5 < z)
+__global__ void __launch_bounds__(kBlock)
+k_preclean_flags(const float4* __restrict__ in, uint64_t n, float radius, uint8_t* __restrict__ drop)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = in[i];
+    const float r = __fsqrt_rn((p.x * p.x + p.y * p.y) + p.z * p.z);
+    drop[i] = ((r < radius) & (p.z < 0.5f) & (-0.5f < p.z)) ? 1 : 0;
+}
+hipError_t preclean_flags(const float4* in, uint64_t n, float radius, uint8_t* drop, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_preclean_flags<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(in, n, radius, drop);
+    return hipGetLastError();
+}
+
+// ----------------------------------------------------------------------------- voxel centroid
+// order-preserving float <-> uint32 encoding for atomic min/max
+__host__ __device__ inline uint32_t enc_f32(float f)
+{
+    const uint32_t u = __builtin_bit_cast(uint32_t, f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+float bbox_decode(uint32_t e)
+{
+    uint32_t u = (e & 0x80000000u) ? (e & 0x7fffffffu) : ~e;
+    float f; memcpy(&f, &u, 4);
+    return f;
+}
+__global__ void k_bbox_init(uint32_t* b)
+{
+    if (threadIdx.x < 3) b[threadIdx.x] = 0xffffffffu;
+    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
+}
+hipError_t bbox_init(uint32_t* bbox, hipStream_t s)
+{
+    k_bbox_init<<<dim3(1), dim3(64), 0, s>>>(bbox);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(kBlock)
+k_bbox_reduce(const float4* __restrict__ pts, size_t n, uint32_t* __restrict__ bbox)
+{
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
+        const float4 p = pts[i];
+        const uint32_t e[3] = {enc_f32(p.x), enc_f32(p.y), enc_f32(p.z)};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = min(mn[d], e[d]); mx[d] = max(mx[d], e[d]); }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[d] = min(mn[d], (uint32_t)__shfl_xor((int)mn[d], off, 64));
+            mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], off, 64));
+        }
+    }
+    if ((threadIdx.x & 63) == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { atomicMin(bbox + d, mn[d]); atomicMax(bbox + 3 + d, mx[d]); }
+    }
+}
+hipError_t bbox_reduce(const float4* pts, size_t n, uint32_t* bbox, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_bbox_reduce<<<dim3((unsigned)std::min<size_t>(grid_for(n), 2048)), dim3(kBlock), 0, s>>>(pts, n, bbox);
+    return hipGetLastError();
+}
+
+// PCL genOctreeKeyforPoint: key = (unsigned)(((double)p - min) / resolution); Morton code with x as the
+// most significant bit of each level triple (child index = x<<2 | y<<1 | z).
+__device__ __forceinline__ uint64_t spread3(uint32_t v)   // 21 bits -> every third bit
+{
+    uint64_t x = v & 0x1fffffu;
+    x = (x | x << 32) & 0x1f00000000ffffull;
+    x = (x | x << 16) & 0x1f0000ff0000ffull;
+    x = (x | x << 8) & 0x100f00f00f00f00full;
+    x = (x | x << 4) & 0x10c30c30c30c30c3ull;
+    x = (x | x << 2) & 0x1249249249249249ull;
+    return x;
+}
+__global__ void __launch_bounds__(kBlock)
+k_morton_keys(const float4* __restrict__ pts, size_t n, OctreeFrame f, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const uint32_t kx = (uint32_t)(((double)p.x - f.minx) / f.res);
+    const uint32_t ky = (uint32_t)(((double)p.y - f.miny) / f.res);
+    const uint32_t kz = (uint32_t)(((double)p.z - f.minz) / f.res);
+    keys[i] = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+    idx[i] = (uint32_t)i;
+}
+hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* keys, uint32_t* idx, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_morton_keys<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, f, keys, idx);
+    return hipGetLastError();
+}
+
+size_t sort_temp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    uint64_t* k = nullptr; uint32_t* v = nullptr;
+    (void)rocprim::radix_sort_pairs(nullptr, bytes, k, k, v, v, n ? n : 1, 0, 64);
+    return bytes + 256;
+}
+hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
+                          unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    if (end_bit < 1) end_bit = 1;
+    if (end_bit > 64) end_bit = 64;
+    return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, val_in, val_out, n, 0, end_bit, s);
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_head_flags(const uint64_t* __restrict__ keys, size_t n, uint8_t* __restrict__ heads)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    heads[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_head_flags<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(keys, n, heads);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(kBlock)
+k_segment_starts(const uint8_t* __restrict__ heads, const uint32_t* __restrict__ pos, size_t n, uint32_t* __restrict__ starts)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (heads[i]) starts[pos[i]] = (uint32_t)i;
+}
+hipError_t segment_starts(const uint8_t* heads, const uint32_t* pos, size_t n, uint32_t* starts, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_segment_starts<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(heads, pos, n, starts);
+    return hipGetLastError();
+}
+
+// PCL OctreePointCloudVoxelCentroidContainer: float sums in input order, divided by (float)count.
+// One lane per voxel walks its (stably sorted => input-ordered) points sequentially so the float sum is
+// the reference's left-to-right sum, bit for bit.
+__global__ void __launch_bounds__(kBlock)
+k_voxel_centroids(const float4* __restrict__ pts, const uint32_t* __restrict__ sorted_idx, const uint32_t* __restrict__ starts,
+                  size_t n_vox, size_t n, float4* __restrict__ out)
+{
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vox) return;
+    const uint32_t a = starts[v];
+    const uint32_t b = (v + 1 < n_vox) ? starts[v + 1] : (uint32_t)n;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+    for (uint32_t j = a; j < b; ++j) {
+        const float4 p = pts[sorted_idx[j]];
+        sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
+    }
+    const float cnt = (float)(b - a);
+    out[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+}
+hipError_t voxel_centroids(const float4* pts, const uint32_t* sorted_idx, const uint32_t* starts, size_t n_vox, size_t n,
+                           float4* out, hipStream_t s)
+{
+    if (!n_vox) return hipSuccess;
+    k_voxel_centroids<<<dim3(grid_for(n_vox)), dim3(kBlock), 0, s>>>(pts, sorted_idx, starts, n_vox, n, out);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------- kNN
+// Uniform grid with cell edge >= sqrt(k*thr)*(1+1e-3): every neighbour that can make a query "coexist"
+// lies in the 27 cells around the query's cell (see DESIGN.md for the exactness argument).
+__device__ __forceinline__ bool cell_of(const KnnGrid& g, float x, float y, float z, long long& cx, long long& cy, long long& cz)
+{
+    cx = (long long)floor(((double)x - g.ox) * g.inv_cell);
+    cy = (long long)floor(((double)y - g.oy) * g.inv_cell);
+    cz = (long long)floor(((double)z - g.oz) * g.inv_cell);
+    return cx >= 0 && cy >= 0 && cz >= 0 && cx < g.nx && cy < g.ny && cz < g.nz;
+}
+__device__ __forceinline__ uint64_t cell_id(const KnnGrid& g, long long cx, long long cy, long long cz)
+{
+    return (uint64_t)((cx * g.ny + cy) * g.nz + cz);
+}
+__global__ void __launch_bounds__(kBlock)
+k_cell_keys(const float4* __restrict__ pts, size_t n, KnnGrid g, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    long long cx, cy, cz;
+    cell_of(g, p.x, p.y, p.z, cx, cy, cz);
+    cx = min(max(cx, 0ll), g.nx - 1); cy = min(max(cy, 0ll), g.ny - 1); cz = min(max(cz, 0ll), g.nz - 1);
+    keys[i] = cell_id(g, cx, cy, cz);
+    idx[i] = (uint32_t)i;
+}
+hipError_t cell_keys(const float4* pts, size_t n, KnnGrid g, uint64_t* keys, uint32_t* idx, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_cell_keys<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, g, keys, idx);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(kBlock)
+k_gather_points(const float4* __restrict__ in, const uint32_t* __restrict__ idx, size_t n, float4* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+hipError_t gather_points(const float4* in, const uint32_t* idx, size_t n, float4* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_gather_points<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(in, idx, n, out);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(kBlock)
+k_gather_u64(const uint64_t* __restrict__ in, const uint32_t* __restrict__ idx, size_t n, uint64_t* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+hipError_t gather_u64(const uint64_t* in, const uint32_t* idx, size_t n, uint64_t* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_gather_u64<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(in, idx, n, out);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint32_t hash64(uint64_t k)
+{
+    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
+    return (uint32_t)k;
+}
+static constexpr uint64_t kEmptyKey = ~0ull;
+
+__global__ void __launch_bounds__(kBlock)
+k_hash_build(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ starts, size_t n_cells, size_t n_pts,
+             HashEntry* __restrict__ table, uint32_t mask)
+{
+    const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_cells) return;
+    const uint32_t a = starts[u];
+    const uint32_t b = (u + 1 < n_cells) ? starts[u + 1] : (uint32_t)n_pts;
+    const uint64_t key = sorted_keys[a];
+    uint32_t h = hash64(key) & mask;
+    while (true) {
+        const unsigned long long prev = atomicCAS(reinterpret_cast<unsigned long long*>(&table[h].key), (unsigned long long)kEmptyKey,
+                                                  (unsigned long long)key);
+        if (prev == kEmptyKey) { table[h].start = a; table[h].end = b; return; }
+        h = (h + 1) & mask;
+    }
+}
+hipError_t hash_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, size_t n_pts, HashEntry* table,
+                      uint32_t table_mask, hipStream_t s)
+{
+    if (!n_cells) return hipSuccess;
+    k_hash_build<<<dim3(grid_for(n_cells)), dim3(kBlock), 0, s>>>(sorted_keys, starts, n_cells, n_pts, table, table_mask);
+    return hipGetLastError();
+}
+
+static constexpr int kMaxK = 16;
+
+// returns the coexist/near predicate of Session.cpp:590-599 for a global-frame query point
+__device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const float4* __restrict__ tgt, size_t Mt, const KnnGrid& g,
+                                         const HashEntry* __restrict__ table, uint32_t mask, int k_param, float thr, float cell2_lo)
+{
+    if (Mt == 0) return false;                        // reference: undefined; defined here as "far"
+    const int k = (int)min((size_t)k_param, Mt);      // pcl::KdTreeFLANN::nearestKSearch clamps k
+    float best[kMaxK];
+    int cnt = 0;
+    auto push = [&](float d) {
+        if (cnt == k && !(d < best[k - 1])) return;
+        int j = (cnt < k) ? cnt++ : k - 1;
+        while (j > 0 && best[j - 1] > d) { best[j] = best[j - 1]; --j; }
+        best[j] = d;
+    };
+    if (Mt <= 64 || (size_t)k_param > Mt) {
+        for (size_t j = 0; j < Mt; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
+    } else {
+        long long cx, cy, cz;
+        cell_of(g, qx, qy, qz, cx, cy, cz);
+        for (long long dx = -1; dx <= 1; ++dx)
+            for (long long dy = -1; dy <= 1; ++dy)
+                for (long long dz = -1; dz <= 1; ++dz) {
+                    const long long x = cx + dx, y = cy + dy, z = cz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) continue;
+                    const uint64_t key = cell_id(g, x, y, z);
+                    uint32_t h = hash64(key) & mask;
+                    uint32_t a = 0, b = 0;
+                    while (true) {
+                        const uint64_t kk = table[h].key;
+                        if (kk == key) { a = table[h].start; b = table[h].end; break; }
+                        if (kk == kEmptyKey) break;
+                        h = (h + 1) & mask;
+                    }
+                    for (uint32_t j = a; j < b; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
+                }
+        // fewer than k neighbours inside the provably-complete radius => the k-th neighbour is >= cell away => "diff"
+        if (cnt < k || !(best[k - 1] < cell2_lo)) return false;
+    }
+    // float sum = accumulate(begin, end, 0.0): double accumulation in ascending order, narrowed to float
+    double acc = 0.0;
+    for (int j = 0; j < cnt; ++j) acc = acc + (double)best[j];
+    const float sum = (float)acc;
+    const float avg = sum / (float)k_param;
+    return fabsf(avg) < thr;
+}
+
+template <bool B2L_IDENTITY>
+__global__ void __launch_bounds__(kBlock)
+k_knn_query_scans(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
+                  uint64_t n_pts, const double* __restrict__ poses, const double* __restrict__ inv_poses, HostMat34 b2l_h,
+                  const float4* __restrict__ tgt, size_t Mt, KnnGrid g, const HashEntry* __restrict__ table, uint32_t mask,
+                  int k, float thr, float cell2_lo, uint8_t* __restrict__ coexist, float4* __restrict__ local_out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_pts) return;
+    const uint64_t gi = first_pt + i;
+    const size_t kf = find_kf(offsets, kb, ke, gi);
+    const float4 p4 = scans[gi];
+    float3 p = make_float3(p4.x, p4.y, p4.z);
+    // Session.cpp:545 / :618: local2global(scan, pose, kSE3MatExtrinsicPoseBasetoLiDAR)  (sic, quirk Q7)
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+    const float3 gp = xform(load_mat(poses + 12 * kf), p);
+    // :603-604 global2local(.., inverse pose, base2lidar)
+    float3 l = xform(load_mat(inv_poses + 12 * kf), gp);
+    if (B2L_IDENTITY) l = xform_identity(l); else l = xform(to_dev(b2l_h), l);
+    local_out[i] = make_float4(l.x, l.y, l.z, p4.w);
+    coexist[i] = knn_near(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
+}
+hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
+                           const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
+                           const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask,
+                           int k, float thr, float cell2_lo, uint8_t* coexist, float4* local_out, hipStream_t s)
+{
+    if (!n_pts) return hipSuccess;
+    if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
+    if (b2l_identity)
+        k_knn_query_scans<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, ke, first_pt, n_pts, poses_dev, inv_poses_dev,
+                                                                            b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, coexist, local_out);
+    else
+        k_knn_query_scans<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, ke, first_pt, n_pts, poses_dev, inv_poses_dev,
+                                                                             b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, coexist, local_out);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_knn_query_cloud(const float4* __restrict__ query, size_t Q, const float4* __restrict__ tgt, size_t Mt, KnnGrid g,
+                  const HashEntry* __restrict__ table, uint32_t mask, int k, float thr, float cell2_lo, uint8_t* __restrict__ near)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= Q) return;
+    const float4 q = query[i];
+    near[i] = knn_near(q.x, q.y, q.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
+}
+hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table,
+                           uint32_t table_mask, int k, float thr, float cell2_lo, uint8_t* near, hipStream_t s)
+{
+    if (!Q) return hipSuccess;
+    if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
+    k_knn_query_cloud<<<dim3(grid_for(Q)), dim3(kBlock), 0, s>>>(query, Q, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, near);
+    return hipGetLastError();
+}
+
+} // namespace ltm

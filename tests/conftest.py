@@ -1,0 +1,60 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run through gpurun)")
+    config.addinivalue_line("markers", "slow: takes more than ~30 s on CPU")
+
+
+@pytest.fixture(scope="session")
+def orc():
+    """the CPU oracle (test infrastructure)"""
+    from oracle import oracle_py
+    oracle_py.lib()
+    return oracle_py
+
+
+@pytest.fixture(scope="session")
+def ltm():
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd import capi
+    return capi
+
+
+@pytest.fixture(scope="session")
+def gpu_ctx(ltm):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU test selected but no GPU is visible (there is no CPU fallback)")
+    ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    yield ctx
+    ctx.close()
+
+
+@pytest.fixture(scope="session")
+def small_pair():
+    """two small synthetic sessions (CPU generated, deterministic)"""
+    from tools import synth
+    C = synth.to_numpy(synth.make_session(1, 6, "small"))
+    Q = synth.to_numpy(synth.make_session(2, 6, "small"))
+    return C, Q
+
+
+def assert_clouds_equal(a, b, what="", xyz_tol=0.0):
+    a = np.asarray(a, dtype=np.float32).reshape(-1, 4)
+    b = np.asarray(b, dtype=np.float32).reshape(-1, 4)
+    assert a.shape == b.shape, f"{what}: point counts differ {a.shape[0]} vs {b.shape[0]}"
+    if xyz_tol == 0.0:
+        bad = np.nonzero((a.view(np.uint32) != b.view(np.uint32)).any(axis=1))[0]
+        assert bad.size == 0, f"{what}: {bad.size} of {a.shape[0]} points differ bitwise, first at {bad[:5]}: {a[bad[:3]]} vs {b[bad[:3]]}"
+    else:
+        d = np.abs(a[:, :3] - b[:, :3]).max() if a.size else 0.0
+        assert d <= xyz_tol, f"{what}: max |xyz| deviation {d} > {xyz_tol}"

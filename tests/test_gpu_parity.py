@@ -1,0 +1,220 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same seeded inputs.
+
+Bars (BASELINE.json north_star): integer labels / pixel indices / range images bit-exact; output XYZ within
+1e-4 m -- in practice every float below is compared BITWISE because the kernels reproduce the reference's
+non-FMA arithmetic exactly; the tolerance is only quoted where the north star states one.
+"""
+import numpy as np
+import pytest
+
+from conftest import assert_clouds_equal
+
+pytestmark = pytest.mark.gpu
+
+XYZ_TOL = 1e-4   # metres, north_star
+VFOV, HFOV = 50.0, 360.0
+I4 = np.eye(4)
+
+
+def _random_points(n, seed, scale=40.0):
+    rng = np.random.default_rng(seed)
+    p = rng.normal(0, scale, size=(n, 4)).astype(np.float32)
+    p[:, 2] = rng.normal(0, 3.0, size=n)
+    p[:, 3] = rng.uniform(0, 255, size=n)
+    return p
+
+
+def _random_pose(rng):
+    yaw, pitch, roll = rng.uniform(-np.pi, np.pi), rng.uniform(-0.1, 0.1), rng.uniform(-0.1, 0.1)
+    cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+    R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+    T = np.eye(4)
+    T[:3, :3] = R
+    T[:3, 3] = rng.uniform(-30, 30, 3)
+    return T
+
+
+def test_device_projection_arithmetic_matches_oracle(gpu_ctx, orc):
+    """atan2f / sqrtf / rad2deg / pixel index on the device vs the (glibc-pinned) oracle, elementwise"""
+    rng = np.random.default_rng(1)
+    n = 2_000_000
+    xyz = rng.normal(0, 30, size=(n, 3)).astype(np.float32)
+    # adversarial rows: axes, zeros, signed zeros, denormals, huge ratios, interval breakpoints of atanf
+    special = np.array([[1, 0, 0], [-1, 0, 0], [-1, -0.0, 0], [0, 0, 1], [0, 0, -1], [0, 0, 0], [-0.0, -0.0, 0], [0, 1, 0], [0, -1, 0],
+                        [1e-42, 1, 0], [1, 1e-42, 0], [-1, 1e-42, 0], [1e-30, 1e30, 1], [1e30, 1e-30, 1], [-1e30, 1e-30, 1], [3, 3, 3],
+                        [1, 0.4375, 0], [1, 0.6875, 0], [1, 1.1875, 0], [1, 2.4375, 0], [1, 1, 2 ** 0.5], [1e-20, 1e-20, 1e-20],
+                        [-5, 1e-7, 0.1], [-5, -1e-7, 0.1], [100, 0, 100], [100, 0, -100]], dtype=np.float32)
+    xyz[: special.shape[0]] = special
+    for alpha in (2.5, 3.0):
+        sph, rc = gpu_ctx.debug_project(xyz, alpha)
+        R, C = orc.rimg_size(VFOV, HFOV, alpha)
+        az = orc.atan2f(xyz[:, 1], xyz[:, 0])
+        el = orc.atan2f(xyz[:, 2], np.sqrt((xyz[:, 0] * xyz[:, 0] + xyz[:, 1] * xyz[:, 1]).astype(np.float32)).astype(np.float32))
+        assert (sph[:, 0].view(np.uint32) == az.view(np.uint32)).all(), "azimuth bits differ"
+        assert (sph[:, 1].view(np.uint32) == el.view(np.uint32)).all(), "elevation bits differ"
+        k = 20000
+        orc_rc, orc_r = orc.pixel(xyz[:k], VFOV, HFOV, R, C)
+        assert (rc[:k] == orc_rc).all(), "pixel indices differ"
+        assert (sph[:k, 2].view(np.uint32) == orc_r.view(np.uint32)).all(), "range bits differ"
+
+
+def test_range_image_bit_exact(gpu_ctx, orc):
+    rng = np.random.default_rng(2)
+    pts = _random_points(300_000, 3)
+    pts[:50] = pts[50:100]          # duplicates: lowest index must win the tie
+    T = _random_pose(rng)
+    Tinv = np.linalg.inv(T)
+    B2L = np.linalg.inv(_random_pose(np.random.default_rng(5)))
+    cloud = gpu_ctx.upload(pts)
+    for alpha, t1, t2 in ((2.5, None, None), (2.375, Tinv, None), (3.0, Tinv, B2L), (1.5, Tinv, I4)):
+        R, C = orc.rimg_size(VFOV, HFOV, alpha)
+        g_r, g_i = gpu_ctx.debug_range_image(cloud, alpha, t1, t2)
+        o_r, o_i = orc.range_image(pts, VFOV, HFOV, R, C, t1, t2)
+        assert g_r.shape == (R, C)
+        assert (g_r.view(np.uint32) == o_r.view(np.uint32)).all(), f"range image differs at alpha={alpha}"
+        assert (g_i == o_i).all(), f"arg-min image differs at alpha={alpha}"
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+def test_vote_labels_and_partition(gpu_ctx, orc, small_pair, mode):
+    C, Q = small_pair
+    b2l = I4
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), 0.05)
+    src = C if mode == 0 else Q
+    labels_o = orc.vote_labels(cmap, src["scans"], src["offsets"], src["inv"], b2l, VFOV, HFOV, 2.5, 0.1, mode)
+    g_map = gpu_ctx.upload(cmap)
+    g_scans = gpu_ctx.upload_scans(src["scans"], src["offsets"])
+    g_poses = gpu_ctx.poses(src["poses"], src["inv"])
+    kept, flagged, labels_g = gpu_ctx.visibility_partition(g_map, g_scans, g_poses, 2.5, 0.1, mode, want_labels=True)
+    assert labels_o.sum() > 0, "degenerate test: nothing flagged"
+    assert (labels_g == labels_o).all(), f"{(labels_g != labels_o).sum()} labels differ"
+    assert_clouds_equal(kept.download(), cmap[labels_o == 0], "kept")
+    assert_clouds_equal(flagged.download(), cmap[labels_o == 1], "flagged")
+
+
+def test_vote_keyframe_batches_and_shards_union(gpu_ctx, orc, small_pair, ltm):
+    """sharding keyframes over ranks and OR-ing labels == one pass (the multi-GPU exchange contract)"""
+    import torch
+    C, _ = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), 0.05)
+    ctx2 = ltm.Context(vfov=VFOV, hfov=HFOV, device=0, max_kf_batch=2)   # force several image batches
+    g_map = ctx2.upload(cmap)
+    g_scans = ctx2.upload_scans(C["scans"], C["offsets"])
+    g_poses = ctx2.poses(C["poses"], C["inv"])
+    nk = g_poses.n
+    full = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda")
+    ctx2.visibility_vote(g_map, g_scans, g_poses, 0, nk, 2.5, 0.1, 0, full.data_ptr())
+    parts = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda")
+    for a, b in ((0, 1), (1, 4), (4, nk)):
+        shard = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda")
+        ctx2.visibility_vote(g_map, g_scans, g_poses, a, b, 2.5, 0.1, 0, shard.data_ptr())
+        parts = torch.maximum(parts, shard)
+    labels_o = orc.vote_labels(cmap, C["scans"], C["offsets"], C["inv"], I4, VFOV, HFOV, 2.5, 0.1, 0)
+    assert (full.cpu().numpy() == labels_o).all()
+    assert (parts.cpu().numpy() == labels_o).all()
+    kept, flagged = ctx2.partition_by_labels(g_map, full.data_ptr())
+    assert len(kept) + len(flagged) == len(cmap) and len(flagged) == int(labels_o.sum())
+    ctx2.close()
+
+
+def test_voxel_centroid_matches_oracle(gpu_ctx, orc, small_pair):
+    C, _ = small_pair
+    merged = orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4)
+    for leaf in (0.05, 0.4, 1.0):
+        o = orc.voxel_centroid(merged, leaf)
+        g = gpu_ctx.voxel_centroid(gpu_ctx.upload(merged), leaf).download()
+        assert_clouds_equal(g, o, f"voxel centroid leaf={leaf}")
+    # idempotence-like property at full size independence: a second pass keeps the count non-increasing
+    g1 = gpu_ctx.voxel_centroid(gpu_ctx.upload(merged), 0.05)
+    g2 = gpu_ctx.voxel_centroid(g1, 0.05)
+    assert len(g2) <= len(g1)
+    assert_clouds_equal(g2.download(), orc.voxel_centroid(g1.download(), 0.05), "second voxel pass")
+    # degenerate inputs
+    assert len(gpu_ctx.voxel_centroid(gpu_ctx.upload(np.zeros((0, 4), np.float32)), 0.05)) == 0
+    one = np.array([[1, 2, 3, 4]], np.float32)
+    assert_clouds_equal(gpu_ctx.voxel_centroid(gpu_ctx.upload(one), 0.05).download(), orc.voxel_centroid(one, 0.05), "single point")
+    same = np.repeat(one, 1000, axis=0)
+    assert_clouds_equal(gpu_ctx.voxel_centroid(gpu_ctx.upload(same), 0.05).download(), orc.voxel_centroid(same, 0.05), "all in one voxel")
+
+
+def test_merge_and_preclean(gpu_ctx, orc, small_pair):
+    C, _ = small_pair
+    g_scans = gpu_ctx.upload_scans(C["scans"], C["offsets"])
+    g_poses = gpu_ctx.poses(C["poses"], C["inv"])
+    assert_clouds_equal(gpu_ctx.merge_to_global(g_scans, g_poses).download(), orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), "merge")
+    cleaned = gpu_ctx.preclean(g_scans, 2.5)
+    pts, off = cleaned.download()
+    for k in range(len(C["offsets"]) - 1):
+        a, b = int(C["offsets"][k]), int(C["offsets"][k + 1])
+        assert_clouds_equal(pts[int(off[k]):int(off[k + 1])], orc.preclean(C["scans"][a:b], 2.5), f"preclean kf {k}")
+
+
+def test_reproject_matches_oracle(gpu_ctx, orc, small_pair):
+    C, _ = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), 0.05)
+    g = gpu_ctx.reproject(gpu_ctx.upload(cmap), gpu_ctx.poses(C["poses"], C["inv"]), 3.0)
+    g_pts, g_off = g.download()
+    o_pts, o_off = orc.reproject(cmap, C["inv"], I4, VFOV, HFOV, 3.0)
+    assert (g_off == o_off).all(), "per-keyframe counts differ"
+    assert_clouds_equal(g_pts, o_pts, "reprojected scans")
+    # quirk Q3: map point 0 is never emitted
+    two = np.array([[5, 0, 0, 1], [0, 5, 0, 2]], np.float32)
+    gp, go = gpu_ctx.reproject(gpu_ctx.upload(two), gpu_ctx.poses(I4.reshape(1, 16), I4.reshape(1, 16)), 3.0).download()
+    assert gp.shape[0] == 1 and gp[0, 3] == 2.0
+
+
+@pytest.mark.parametrize("k,thr", [(2, 0.01), (3, 0.1), (1, 0.05)])
+def test_knn_partition_matches_oracle(gpu_ctx, orc, small_pair, k, thr):
+    C, Q = small_pair
+    target = orc.voxel_centroid(orc.merge_to_global(Q["scans"], Q["offsets"], Q["poses"], I4), 0.05)
+    co_o, loc_o = orc.knn_labels(target, C["scans"], C["offsets"], C["poses"], C["inv"], I4, k, thr)
+    g_co, g_di = gpu_ctx.knn_partition(gpu_ctx.upload(target), gpu_ctx.upload_scans(C["scans"], C["offsets"]),
+                                       gpu_ctx.poses(C["poses"], C["inv"]), k, thr)
+    assert 0 < co_o.sum() < co_o.size, "degenerate test"
+    co_pts, co_off = g_co.download()
+    di_pts, di_off = g_di.download()
+    for kf in range(len(C["offsets"]) - 1):
+        a, b = int(C["offsets"][kf]), int(C["offsets"][kf + 1])
+        m = co_o[a:b] == 1
+        assert_clouds_equal(co_pts[int(co_off[kf]):int(co_off[kf + 1])], loc_o[a:b][m], f"coexist kf {kf}")
+        assert_clouds_equal(di_pts[int(di_off[kf]):int(di_off[kf + 1])], loc_o[a:b][~m], f"diff kf {kf}")
+
+
+def test_knn_kat_and_small_targets(gpu_ctx, orc):
+    """SURVEY Appendix B KAT: neighbours at 0.1 m and 0.1 m, thr 0.01 => avg == 0.01 => diff (strict <)"""
+    q = np.array([[0, 0, 0, 0]], np.float32)
+    t = np.array([[0.1, 0, 0, 0], [0, 0.1, 0, 0], [3, 3, 3, 0]], np.float32)
+    for tt in (t, np.vstack([t, _random_points(500, 9, 50.0) + 100])):
+        for thr in (0.01, 0.0101, 0.0099):
+            near_o = orc.knn_split(tt, q, 2, thr)
+            near_g, far_g = gpu_ctx.knn_split_cloud(gpu_ctx.upload(tt), gpu_ctx.upload(q), 2, thr)
+            assert len(near_g) == int(near_o.sum()) and len(far_g) == 1 - int(near_o.sum())
+    # k larger than the target (PCL clamps k, the divisor stays k)
+    t1 = np.array([[0.05, 0, 0, 0]], np.float32)
+    assert len(gpu_ctx.knn_split_cloud(gpu_ctx.upload(t1), gpu_ctx.upload(q), 2, 0.01)[0]) == int(orc.knn_split(t1, q, 2, 0.01).sum())
+    # weak->strong ND parameters (k=2, thr=1.0) on random clouds, brute-force oracle
+    tgt, qry = _random_points(4000, 11, 5.0), _random_points(3000, 12, 5.0)
+    near_o = orc.knn_split(tgt, qry, 2, 1.0, use_kdtree=False)
+    near_g, far_g = gpu_ctx.knn_split_cloud(gpu_ctx.upload(tgt), gpu_ctx.upload(qry), 2, 1.0)
+    assert_clouds_equal(near_g.download(), qry[near_o == 1], "near")
+    assert_clouds_equal(far_g.download(), qry[near_o == 0], "far")
+
+
+def test_empty_and_ragged_inputs(gpu_ctx, orc):
+    empty = np.zeros((0, 4), np.float32)
+    pts = _random_points(1000, 21)
+    off = np.array([0, 0, 400, 400, 1000], dtype=np.uint64)      # empty keyframes in the middle
+    poses = np.stack([np.eye(4)] * 4).reshape(4, 16)
+    g_scans = gpu_ctx.upload_scans(pts, off)
+    g_poses = gpu_ctx.poses(poses, poses)
+    cmap = _random_points(5000, 22)
+    kept, flagged, lab = gpu_ctx.visibility_partition(gpu_ctx.upload(cmap), g_scans, g_poses, 2.5, 0.1, 0, want_labels=True)
+    lab_o = orc.vote_labels(cmap, pts, off, poses, I4, VFOV, HFOV, 2.5, 0.1, 0)
+    assert (lab == lab_o).all()
+    k2, f2 = gpu_ctx.visibility_partition(gpu_ctx.upload(empty), g_scans, g_poses, 2.5)
+    assert len(k2) == 0 and len(f2) == 0
+    rp, ro = gpu_ctx.reproject(gpu_ctx.upload(empty), g_poses, 3.0).download()
+    assert rp.shape[0] == 0 and (ro == 0).all()
+    co, di = gpu_ctx.knn_partition(gpu_ctx.upload(empty), g_scans, g_poses, 2, 0.01)
+    assert co.info()[1] == 0 and di.info()[1] == 1000            # nothing coexists with an empty map
+    assert (di.offsets() == off).all()

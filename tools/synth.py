@@ -1,0 +1,193 @@
+"""synth-v1: synthetic LiDAR sessions in the reference's in-memory shape.
+
+No dataset is reachable offline (README.md:104 points to a download), so every config of BASELINE.json
+is restated as a seeded synthetic scene.  This generator is device agnostic torch code: on the GPU box it
+produces the 2x500-keyframe benchmark sessions in about a second, on CPU it produces the small parity
+fixtures.  It is tooling, not product: nothing in lt-mapper_amd/ imports it.
+
+Scene `lot` (ParkingLot-like): ground z=0, perimeter walls of a 120 x 80 m lot (10 m high), 6 rows x 40
+parking bays; a bay is occupied in session s with probability 0.6 and a quarter of the bays are re-drawn
+between consecutive sessions (low-dynamic change => ND/PD); 10 movers (pedestrians, cars) whose position is
+a function of the keyframe index (high-dynamic points).  The sensor drives a rounded-rectangle loop at 1 m
+keyframe spacing, 1.9 m above ground; session s starts 37*s m further along the loop.
+Sensors: `os1-64` 64 x 1024, `hdl-64e` 64 x 1900, `mls` 128 x 8192, or any (rings, az, el_lo, el_hi).
+Analytic ray casting (slab tests), max range 120 m, range noise N(0, 0.02 m), 5 % dropout, intensity U[0,255).
+Poses are reported in the shared frame with a small SE(2) residual and 6 significant digits, like the text
+files LT-SLAM writes (ltslam/src/utility.cpp:190-200).
+"""
+import math
+
+import numpy as np
+import torch
+
+SENSORS = {
+    "os1-64": (64, 1024, -22.5, 22.5),
+    "hdl-64e": (64, 1900, -24.9, 2.0),
+    "mls": (128, 8192, -25.0, 25.0),
+    "tiny": (16, 180, -22.5, 22.5),
+    "small": (32, 512, -22.5, 22.5),
+}
+
+MASTER_SEED = 20250224
+
+
+def _hash01(*keys):
+    """deterministic uniform [0,1) from integer keys (splitmix64)"""
+    z = 0x9E3779B97F4A7C15
+    for k in keys:
+        z = (z ^ (int(k) & 0xFFFFFFFFFFFFFFFF)) * 0xBF58476D1CE4E5B9 & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 30
+        z = z * 0x94D049BB133111EB & 0xFFFFFFFFFFFFFFFF
+        z ^= z >> 31
+    return (z >> 11) / float(1 << 53)
+
+
+def _bay_boxes(session, seed):
+    """AABBs [x0,y0,z0,x1,y1,z1] of the cars parked in `session`"""
+    rows_y = [-30.0, -18.0, -6.0, 6.0, 18.0, 30.0]
+    boxes = []
+    for r, y in enumerate(rows_y):
+        for b in range(40):
+            bay = r * 40 + b
+            epoch = 0
+            for s in range(1, session + 1):
+                if _hash01(seed, 7, bay, s) < 0.25:
+                    epoch = s
+            if _hash01(seed, 11, bay, epoch) < 0.6:
+                cx = -48.75 + 2.5 * b
+                boxes.append([cx - 0.9, y - 2.25, 0.0, cx + 0.9, y + 2.25, 1.5])
+    return boxes
+
+
+def _mover_boxes(kf_global, seed):
+    """10 movers; kf_global = arc position in metres (1 keyframe per metre, ~1 s per keyframe)"""
+    t = float(kf_global)
+    boxes = []
+    for m in range(10):
+        lane_y = [-24.0, -12.0, 0.0, 12.0, 24.0][m % 5] + (1.5 if m < 5 else -1.5)
+        x0 = -50.0 + 100.0 * _hash01(seed, 13, m)
+        if m < 6:   # pedestrian 0.6 x 0.6 x 1.7 at 1.4 m/s
+            v, hx, hy, hz = 1.4 * (1 if m % 2 == 0 else -1), 0.3, 0.3, 1.7
+        else:       # car 4.5 x 1.8 x 1.5 at 4 m/s
+            v, hx, hy, hz = 4.0 * (1 if m % 2 == 0 else -1), 2.25, 0.9, 1.5
+        x = ((x0 + v * t + 50.0) % 100.0) - 50.0
+        boxes.append([x - hx, lane_y - hy, 0.0, x + hx, lane_y + hy, hz])
+    return boxes
+
+
+def _loop_pose(s):
+    """rounded-rectangle loop, half extents (45, 12), corner radius 4; s = arc length"""
+    hx, hy, r = 45.0, 12.0, 4.0
+    sx, sy = 2 * (hx - r), 2 * (hy - r)
+    arc = 0.5 * math.pi * r
+    per = 2 * sx + 2 * sy + 4 * arc
+    s = s % per
+    segs = [
+        ("l", sx, (-(hx - r), -hy), 0.0), ("a", arc, (hx - r, -hy + r), -0.5 * math.pi),
+        ("l", sy, (hx, -(hy - r)), 0.5 * math.pi), ("a", arc, (hx - r, hy - r), 0.0),
+        ("l", sx, (hx - r, hy), math.pi), ("a", arc, (-(hx - r), hy - r), 0.5 * math.pi),
+        ("l", sy, (-hx, hy - r), -0.5 * math.pi), ("a", arc, (-(hx - r), -hy + r), math.pi),
+    ]
+    for kind, length, p, ang in segs:
+        if s <= length:
+            if kind == "l":
+                return p[0] + s * math.cos(ang), p[1] + s * math.sin(ang), ang
+            a = ang + s / r
+            return p[0] + r * math.cos(a), p[1] + r * math.sin(a), a + 0.5 * math.pi
+        s -= length
+    return -(hx - r), -hy, 0.0
+
+
+def _round_sig(x, sig=6):
+    x = np.asarray(x, dtype=np.float64)
+    out = np.zeros_like(x)
+    nz = x != 0
+    mag = np.floor(np.log10(np.abs(x[nz])))
+    scale = 10.0 ** (sig - 1 - mag)
+    out[nz] = np.round(x[nz] * scale) / scale
+    return out
+
+
+def _cast(o, d, boxes):
+    """o (3,), d (R,3) float64, boxes (B,6): nearest positive slab hit per ray -> (R,) range (inf if none)"""
+    inv = 1.0 / d                                   # (R,3); zeros give inf, handled by min/max
+    t0 = (boxes[None, :, 0:3] - o[None, None, :]) * inv[:, None, :]
+    t1 = (boxes[None, :, 3:6] - o[None, None, :]) * inv[:, None, :]
+    tn = torch.minimum(t0, t1).amax(dim=2)
+    tf = torch.maximum(t0, t1).amin(dim=2)
+    hit = (tn <= tf) & (tn > 0.5)
+    tn = torch.where(hit, tn, torch.full_like(tn, float("inf")))
+    return tn.amin(dim=1)
+
+
+def make_session(session, n_kf, sensor="os1-64", seed=MASTER_SEED, device="cpu", scene="lot", kf_spacing=1.0,
+                 max_range=120.0, noise=0.02, dropout=0.05, pose_noise=True):
+    """returns dict(scans (P,4) f32, offsets (n_kf+1) u64, poses (n_kf,16) f64, inv (n_kf,16) f64, names)
+    with scans/offsets as torch tensors on `device` and poses as numpy."""
+    assert scene == "lot"
+    rings, n_az, el_lo, el_hi = SENSORS[sensor] if isinstance(sensor, str) else sensor
+    dev = torch.device(device)
+    f64 = torch.float64
+    el = torch.deg2rad(torch.linspace(el_lo, el_hi, rings, dtype=f64, device=dev))
+    az0 = torch.arange(n_az, dtype=f64, device=dev) * (2 * math.pi / n_az) - math.pi
+    room = torch.tensor([[-60.0, -40.0, 0.0, 60.0, 40.0, 10.0]], dtype=f64, device=dev)
+    static_boxes = _bay_boxes(session, seed)
+    gen = torch.Generator(device=dev)
+    scans, offsets, poses = [], [0], []
+    for kf in range(n_kf):
+        gen.manual_seed((seed * 1000003 + session * 65537 + kf) & 0x7FFFFFFFFFFF)
+        s_arc = 37.0 * session + kf_spacing * kf
+        x, y, yaw = _loop_pose(s_arc)
+        o = torch.tensor([x, y, 1.9], dtype=f64, device=dev)
+        phase = float(_hash01(seed, 17, session, kf)) * (2 * math.pi / n_az)
+        az = az0 + phase
+        ce, se = torch.cos(el)[:, None], torch.sin(el)[:, None]
+        dl = torch.stack([(ce * torch.cos(az)[None, :]), (ce * torch.sin(az)[None, :]), se.expand(rings, n_az)], dim=2).reshape(-1, 3)
+        cy, sy = math.cos(yaw), math.sin(yaw)
+        dw = torch.stack([cy * dl[:, 0] - sy * dl[:, 1], sy * dl[:, 0] + cy * dl[:, 1], dl[:, 2]], dim=1)
+        # room: exit distance of the enclosing box; a ceiling exit is sky (no return)
+        inv = 1.0 / dw
+        t0 = (room[0, 0:3][None, :] - o[None, :]) * inv
+        t1 = (room[0, 3:6][None, :] - o[None, :]) * inv
+        tmax = torch.maximum(t0, t1)
+        t_exit, axis = tmax.min(dim=1)
+        sky = (axis == 2) & (dw[:, 2] > 0)
+        rng = torch.where(sky, torch.full_like(t_exit, float("inf")), t_exit)
+        boxes = torch.tensor(static_boxes + _mover_boxes(s_arc, seed), dtype=f64, device=dev)
+        rng = torch.minimum(rng, _cast(o, dw, boxes))
+        u = torch.rand(rng.shape[0], 3, generator=gen, device=dev, dtype=f64)
+        g4 = torch.rand(rng.shape[0], 4, generator=gen, device=dev, dtype=f64).sum(dim=1)   # Irwin-Hall(4): var 1/3
+        rng = rng + noise * (g4 - 2.0) * math.sqrt(3.0)
+        keep = torch.isfinite(rng) & (rng < max_range) & (rng > 0.3) & (u[:, 0] >= dropout)
+        pts = (dl * rng[:, None])[keep]
+        inten = (u[:, 1] * 255.0)[keep]
+        scans.append(torch.cat([pts, inten[:, None]], dim=1).to(torch.float32))
+        offsets.append(offsets[-1] + int(scans[-1].shape[0]))
+        # reported pose: truth + small SE(2) residual, 6 significant digits
+        if pose_noise:
+            ex = 0.02 * (2 * _hash01(seed, 19, session, kf) - 1)
+            ey = 0.02 * (2 * _hash01(seed, 23, session, kf) - 1)
+            eyaw = math.radians(0.05) * (2 * _hash01(seed, 29, session, kf) - 1)
+        else:
+            ex = ey = eyaw = 0.0
+        c2, s2 = math.cos(yaw + eyaw), math.sin(yaw + eyaw)
+        T = np.array([[c2, -s2, 0, x + ex], [s2, c2, 0, y + ey], [0, 0, 1, 1.9], [0, 0, 0, 1]], dtype=np.float64)
+        T[:3, :] = _round_sig(T[:3, :], 6)
+        poses.append(T)
+    poses = np.stack(poses) if poses else np.zeros((0, 4, 4))
+    inv_p = np.linalg.inv(poses) if n_kf else poses.copy()
+    scans_t = torch.cat(scans, dim=0) if scans else torch.zeros((0, 4), dtype=torch.float32, device=dev)
+    return dict(scans=scans_t.contiguous(), offsets=torch.tensor(offsets, dtype=torch.int64), poses=poses.reshape(-1, 16),
+                inv=inv_p.reshape(-1, 16), names=[f"{i:06d}.pcd" for i in range(n_kf)])
+
+
+def to_numpy(sess):
+    return dict(scans=sess["scans"].cpu().numpy(), offsets=sess["offsets"].cpu().numpy().astype(np.uint64),
+                poses=sess["poses"], inv=sess["inv"], names=sess["names"])
+
+
+if __name__ == "__main__":
+    import time
+    t = time.time()
+    s = make_session(1, 4, "small")
+    print(s["scans"].shape, s["offsets"], time.time() - t)
