@@ -120,8 +120,8 @@ __device__ __forceinline__ Sph cart2sph(float x, float y, float z)
     const float xx = x * x, yy = y * y, zz = z * z;
     const float xy = xx + yy;
     s.az = atan2f_exact(y, x);
-    s.el = atan2f_exact(z, __fsqrt_rn(xy));
-    s.r = __fsqrt_rn(xy + zz);
+    s.el = atan2f_exact(z, __builtin_sqrtf(xy));
+    s.r = __builtin_sqrtf(xy + zz);
     return s;
 }
 

@@ -361,7 +361,7 @@ k_preclean_flags(const float4* __restrict__ in, uint64_t n, float radius, uint8_
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const float4 p = in[i];
-    const float r = __fsqrt_rn((p.x * p.x + p.y * p.y) + p.z * p.z);
+    const float r = __builtin_sqrtf((p.x * p.x + p.y * p.y) + p.z * p.z);
     drop[i] = ((r < radius) & (p.z < 0.5f) & (-0.5f < p.z)) ? 1 : 0;
 }
 hipError_t preclean_flags(const float4* in, uint64_t n, float radius, uint8_t* drop, hipStream_t s)
