@@ -1,0 +1,266 @@
+"""Python mirror of the reference's `Removerter` / `Session` pipeline over the C ABI (include/ltm.h).
+
+Method and member names follow ltremovert/include/removert/{Removerter.h,Session.h} so that the parity
+tests read like the reference; every method cites the reference lines it stands for.  All heavy work is
+a call into libltm_hip.so through an `ops` object (HipOps below); nothing here computes on points.
+
+The orchestration is written against a small ops interface so the keyframe-sharded multi-GPU variant
+(dist.ShardedOps) wraps the same pipeline: per-keyframe stages run on this rank's block of keyframes and
+label masks / per-keyframe clouds are exchanged with torch.distributed (RCCL on GPUs).
+"""
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional
+
+import numpy as np
+
+
+@dataclass
+class Params:
+    """the removert/ ROS parameters the hot path reads (RosParamServer.cpp:7-59)"""
+    sequence_vfov: float = 50.0
+    sequence_hfov: float = 360.0
+    remove_resolution_list: List[float] = field(default_factory=lambda: [2.5])
+    num_nn_points_within: int = 2            # yaml value; code default 3
+    dist_nn_points_within: float = 0.01      # yaml value; code default 0.1
+    downsample_voxel_size: float = 0.05
+    repeat_removert_iter: int = 1
+    ExtrinsicLiDARtoPoseBase: Optional[np.ndarray] = None
+    # new optional keys (prefix gpu_): off = exactly the shipped behaviour
+    gpu_use_self_removert: bool = False      # enable the selfRemovert() call that is commented out at Removerter.cpp:1582,1586
+    gpu_skip_hd_knn: bool = False            # skip the visualisation-only HD kNN (Removerter.cpp:1590-1601)
+
+
+class HipOps:
+    """stage operations on one GPU: thin forwarding to capi.Context"""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    # clouds
+    def clone(self, c): return c.clone()
+    def concat(self, cs): return self.ctx.concat(cs)
+    def size(self, c): return len(c)
+    def empty_cloud(self): return self.ctx.upload(np.zeros((0, 4), np.float32))
+    # stages
+    def merge_to_global(self, scans, poses): return self.ctx.merge_to_global(scans, poses)
+    def voxel(self, c, leaf): return self.ctx.voxel_centroid(c, leaf)
+    def voxel_scanset(self, s, leaf): return self.ctx.voxel_centroid_scanset(s, leaf)
+    def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
+    def reproject(self, cmap, poses, alpha): return self.ctx.reproject(cmap, poses, alpha)
+    def knn_partition(self, target, scans, poses, k, thr): return self.ctx.knn_partition(target, scans, poses, k, thr)
+    def knn_split(self, target, query, k, thr): return self.ctx.knn_split_cloud(target, query, k, thr)
+    def zip_concat(self, a, b, c): return self.ctx.zip_concat(a, b, c)
+    def sync(self): self.ctx.synchronize()
+
+
+class Session:
+    """ltremovert::Session state (Session.h:9-136): everything is a device handle"""
+
+    def __init__(self, sess_type, scans, poses):
+        self.sess_type_ = sess_type
+        self.keyframe_scans_ = scans            # scan set (after load + pre-clean)
+        self.keyframe_poses = poses             # poses handle (keyframe_poses_ + keyframe_inverse_poses_)
+        self.map_global_orig_ = None
+        self.map_global_curr_ = None
+        self.map_global_curr_static_ = None
+        self.map_global_curr_dynamic_ = None
+        self.keyframe_scans_static_projected_ = None
+        self.keyframe_scans_dynamic_ = None
+        self.scans_knn_coexist_ = None
+        self.scans_knn_diff_ = None
+        self.map_global_nd_ = self.map_global_nd_strong_ = self.map_global_nd_weak_ = None
+        self.map_global_pd_ = self.map_global_pd_orig_ = self.map_global_pd_strong_ = self.map_global_pd_weak_ = None
+        self.map_global_updated_ = self.map_global_updated_strong_ = None
+        self.keyframe_scans_updated_ = self.keyframe_scans_updated_strong_ = None
+        self.keyframe_scans_pd_ = self.keyframe_scans_strong_pd_ = None
+        self.keyframe_scans_strong_nd_ = self.keyframe_scans_weak_nd_ = None
+
+
+class Removerter:
+    kReprojectionAlpha = 3.0     # Session.h:13
+
+    def __init__(self, ops, params: Params, central: Session, query: Session):
+        self.ops, self.P = ops, params
+        self.central_sess_, self.query_sess_ = central, query
+        self.outputs = {}        # name -> cloud handle, the *.pcd maps of the output protocol
+        self.timings = {}
+
+    # ------------------------------------------------------------------ helpers
+    def _tick(self, name, t0):
+        self.ops.sync()
+        self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
+
+    def octreeDownsampling(self, cloud, leaf):          # utility.cpp:204-219
+        return self.ops.voxel(cloud, leaf)
+
+    def _append(self, a, b):                            # `*a += *b`
+        if a is None:
+            return self.ops.clone(b)
+        return self.ops.concat([a, b])
+
+    # ------------------------------------------------------------------ Step 0
+    def makeGlobalMap(self):                            # Removerter.cpp:213-252 (+ Session.cpp:186-202)
+        for s in (self.central_sess_, self.query_sess_):
+            s.map_global_orig_ = self.ops.merge_to_global(s.keyframe_scans_, s.keyframe_poses)
+            s.map_global_curr_ = self.octreeDownsampling(s.map_global_orig_, self.P.downsample_voxel_size)
+            self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_curr_
+            s.map_global_orig_ = None   # only ever read by makeGlobalMap
+
+    # ------------------------------------------------------------------ Step 1
+    def removeOnce(self, target, source, res_alpha):    # Removerter.cpp:882-905
+        static_tt, dynamic_tt = self.ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
+        target.map_global_curr_static_ = self.octreeDownsampling(static_tt, 0.05)
+        target.map_global_curr_ = target.map_global_curr_static_
+        target.map_global_curr_dynamic_ = self.octreeDownsampling(self._append(target.map_global_curr_dynamic_, dynamic_tt), 0.05)
+
+    def revertOnce(self, target, source, res_alpha):    # Removerter.cpp:908-931
+        static_tt, dynamic_tt = self.ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
+        target.map_global_curr_dynamic_ = self.octreeDownsampling(dynamic_tt, 0.05)
+        target.map_global_curr_ = target.map_global_curr_dynamic_
+        target.map_global_curr_static_ = self.octreeDownsampling(self._append(target.map_global_curr_static_, static_tt), 0.05)
+
+    def selfRemovert(self, sess, repeat=1):             # Removerter.cpp:1378-1393
+        for res in self.P.remove_resolution_list:
+            res = float(np.float32(res))
+            for _ in range(max(1, repeat)):
+                self.removeOnce(sess, sess, res)
+                sess.map_global_curr_ = sess.map_global_curr_dynamic_          # resetCurrrentMapAsDynamic :714-737
+                self.revertOnce(sess, sess, float(np.float32(0.95 * res)))     # :1385 double product narrowed to float
+                sess.map_global_curr_ = sess.map_global_curr_static_           # resetCurrrentMapAsStatic
+                self.removeOnce(sess, sess, res)
+
+    def removeHighDynamicPoints(self):                  # Removerter.cpp:1580-1604
+        t0 = time.perf_counter()
+        C, Q = self.central_sess_, self.query_sess_
+        if self.P.gpu_use_self_removert and len(self.P.remove_resolution_list) > 0:
+            self.selfRemovert(C, self.P.repeat_removert_iter)
+            self.selfRemovert(Q, self.P.repeat_removert_iter)
+        else:
+            self.removeOnce(C, C, 2.5)
+            self.removeOnce(Q, Q, 2.5)
+        self._tick("remove_high_dynamic", t0)
+        if not self.P.gpu_skip_hd_knn:
+            t0 = time.perf_counter()
+            k, thr = self.P.num_nn_points_within, self.P.dist_nn_points_within
+            for s, name in ((C, "central_sess_high_dyn"), (Q, "query_sess_high_dyn")):
+                _, s.keyframe_scans_dynamic_ = self.ops.knn_partition(s.map_global_curr_static_, s.keyframe_scans_, s.keyframe_poses, k, thr)  # Session.cpp:487-504
+                self.outputs[name] = self.octreeDownsampling(self.ops.merge_to_global(s.keyframe_scans_dynamic_, s.keyframe_poses), 0.05)
+            self._tick("hd_knn", t0)
+
+    def parseStaticScansViaProjection(self):            # Removerter.cpp:1527-1538, Session.cpp:305-309
+        t0 = time.perf_counter()
+        for s in (self.central_sess_, self.query_sess_):
+            s.keyframe_scans_static_projected_ = self.ops.reproject(s.map_global_curr_, s.keyframe_poses, self.kReprojectionAlpha)
+        self._tick("reproject_static", t0)
+
+    # ------------------------------------------------------------------ Step 2
+    def _removeOnceLD(self, target_maps, source, res_alpha, mode):   # iremoveOnceForND :831-854 / removeOnceForPD :856-880
+        cur, strong, weak = target_maps
+        static_tt, dynamic_tt = self.ops.vote_partition(cur, source.keyframe_scans_static_projected_, source.keyframe_poses, res_alpha, 0.1, mode)
+        strong = self.octreeDownsampling(static_tt, 0.05)
+        cur = strong
+        weak = self.octreeDownsampling(self._append(weak, dynamic_tt), 0.05)
+        return cur, strong, weak
+
+    def detectLowDynamicPoints(self):                   # Removerter.cpp:1413-1481
+        C, Q = self.central_sess_, self.query_sess_
+        k, thr = self.P.num_nn_points_within, self.P.dist_nn_points_within
+        t0 = time.perf_counter()
+        # Session.cpp:393-427 (the 0.4 m octree for the disabled ICP at :401 has no observable effect and is not run)
+        C.scans_knn_coexist_, C.scans_knn_diff_ = self.ops.knn_partition(Q.map_global_curr_static_, C.keyframe_scans_static_projected_, C.keyframe_poses, k, thr)
+        Q.scans_knn_coexist_, Q.scans_knn_diff_ = self.ops.knn_partition(C.map_global_curr_static_, Q.keyframe_scans_static_projected_, Q.keyframe_poses, k, thr)
+        self._tick("ld_knn", t0)
+        t0 = time.perf_counter()
+        # strong ND: constructGlobalNDMap (Session.cpp:430-435), filterStrongND (:1403-1411), weak->strong propagation (Session.cpp:452-484)
+        C.map_global_nd_ = self.octreeDownsampling(self.ops.merge_to_global(C.scans_knn_diff_, C.keyframe_poses), 0.05)
+        maps = (C.map_global_nd_, None, None)
+        for _ in range(3):
+            maps = self._removeOnceLD(maps, Q, 2.5, 1)
+        C.map_global_nd_, C.map_global_nd_strong_, C.map_global_nd_weak_ = maps
+        if self.ops.size(C.map_global_nd_strong_) != 0:
+            add, new_weak = self.ops.knn_split(C.map_global_nd_strong_, C.map_global_nd_weak_, 2, 1.0)
+            C.map_global_nd_strong_ = self.ops.concat([C.map_global_nd_strong_, add])
+            C.map_global_nd_weak_ = new_weak
+        # strong PD: constructGlobalPDMap (Session.cpp:437-445), filterStrongPD (:1395-1401)
+        Q.map_global_pd_ = self.octreeDownsampling(self.ops.merge_to_global(Q.scans_knn_diff_, Q.keyframe_poses), 0.05)
+        Q.map_global_pd_orig_ = Q.map_global_pd_
+        maps = (Q.map_global_pd_, None, None)
+        for _ in range(3):
+            maps = self._removeOnceLD(maps, C, 2.5, 0)
+        Q.map_global_pd_, Q.map_global_pd_strong_, Q.map_global_pd_weak_ = maps
+        C.map_global_pd_, C.map_global_pd_orig_, C.map_global_pd_strong_ = Q.map_global_pd_, Q.map_global_pd_orig_, Q.map_global_pd_strong_   # :1435-1437
+        self._tick("ld_filter", t0)
+        t0 = time.perf_counter()
+        # :1443-1480 merged maps "for visual debug" -- several of these re-voxelise state that Step 3 reads
+        o = self.outputs
+        self._union_q = o["union_map_queryside"] = self.octreeDownsampling(self.ops.merge_to_global(Q.scans_knn_coexist_, Q.keyframe_poses), 0.05)
+        self._union_c = o["union_map_centralside"] = self.octreeDownsampling(self.ops.merge_to_global(C.scans_knn_coexist_, C.keyframe_poses), 0.05)
+        o["pd_map"] = self.octreeDownsampling(self.ops.merge_to_global(Q.scans_knn_diff_, Q.keyframe_poses), 0.05)
+        o["nd_map"] = self.octreeDownsampling(self.ops.merge_to_global(C.scans_knn_diff_, C.keyframe_poses), 0.05)
+        if self.ops.size(C.map_global_nd_strong_) != 0:
+            C.map_global_nd_strong_ = o["strong_nd_map"] = self.octreeDownsampling(C.map_global_nd_strong_, 0.05)
+        C.map_global_nd_weak_ = o["weak_nd_map"] = self.octreeDownsampling(C.map_global_nd_weak_, 0.05)
+        Q.map_global_pd_strong_ = o["strong_pd_map"] = self.octreeDownsampling(Q.map_global_pd_strong_, 0.05)
+        Q.map_global_pd_weak_ = o["weak_pd_map"] = self.octreeDownsampling(Q.map_global_pd_weak_, 0.05)
+        self._tick("ld_maps", t0)
+
+    # ------------------------------------------------------------------ Step 3
+    def updateCurrentMap(self):                         # Removerter.cpp:1483-1524
+        t0 = time.perf_counter()
+        C = self.central_sess_
+        # the two union maps are recomputed at :1489-1493 from unchanged inputs: identical to the ones of :1445-1451
+        updated = self.ops.concat([self._union_q, self._union_c, C.map_global_nd_weak_])
+        C.map_global_updated_strong_ = self.octreeDownsampling(self.ops.concat([updated, C.map_global_pd_strong_]), 0.05)
+        C.map_global_updated_ = self.octreeDownsampling(self.ops.concat([updated, C.map_global_pd_orig_]), 0.05)
+        self.outputs["updated_map"] = C.map_global_updated_
+        self.outputs["updated_map_strong"] = C.map_global_updated_strong_
+        self._tick("update_map", t0)
+
+    def parseUpdatedStaticScansViaProjection(self):     # Removerter.cpp:1551-1562
+        t0 = time.perf_counter()
+        C = self.central_sess_
+        C.keyframe_scans_updated_ = self.ops.reproject(C.map_global_updated_, C.keyframe_poses, self.kReprojectionAlpha)
+        C.keyframe_scans_updated_strong_ = self.ops.reproject(C.map_global_updated_strong_, C.keyframe_poses, self.kReprojectionAlpha)
+        self._tick("reproject_updated", t0)
+
+    def parseLDScansViaProjection(self):                # Removerter.cpp:1564-1577
+        t0 = time.perf_counter()
+        C = self.central_sess_
+        C.keyframe_scans_pd_ = self.ops.reproject(C.map_global_pd_orig_, C.keyframe_poses, self.kReprojectionAlpha)
+        C.keyframe_scans_strong_pd_ = self.ops.reproject(C.map_global_pd_strong_, C.keyframe_poses, self.kReprojectionAlpha)
+        C.keyframe_scans_weak_nd_ = self.ops.reproject(C.map_global_nd_weak_, C.keyframe_poses, self.kReprojectionAlpha)
+        nd_strong = C.map_global_nd_strong_ if C.map_global_nd_strong_ is not None else self.ops.empty_cloud()
+        C.keyframe_scans_strong_nd_ = self.ops.reproject(nd_strong, C.keyframe_poses, self.kReprojectionAlpha)
+        self._tick("reproject_ld", t0)
+
+    def updateScansScanwise(self):                      # Removerter.cpp:1540-1549, Session.cpp:362-380
+        t0 = time.perf_counter()
+        C = self.central_sess_
+        merged = self.ops.zip_concat(C.keyframe_scans_updated_, C.keyframe_scans_weak_nd_, C.keyframe_scans_pd_)
+        C.keyframe_scans_updated_ = self.ops.voxel_scanset(merged, 0.05)
+        self._tick("update_scans", t0)
+
+    def scan_outputs(self):
+        """the five per-keyframe output directories (Removerter.cpp:1607-1650)"""
+        C = self.central_sess_
+        return {"scans_updated": C.keyframe_scans_updated_, "scans_updated_strong": C.keyframe_scans_updated_strong_,
+                "scans_pd": C.keyframe_scans_pd_, "scans_pd_strong": C.keyframe_scans_strong_pd_,
+                "scans_nd_strong": C.keyframe_scans_strong_nd_}
+
+    # ------------------------------------------------------------------ run()
+    def run_steps_1_to_3(self):                         # Removerter.cpp:1664-1675 (file I/O excluded)
+        self.removeHighDynamicPoints()
+        self.parseStaticScansViaProjection()
+        self.detectLowDynamicPoints()
+        self.updateCurrentMap()
+        self.parseUpdatedStaticScansViaProjection()
+        self.parseLDScansViaProjection()
+        self.updateScansScanwise()
+        C, Q = self.central_sess_, self.query_sess_
+        self.outputs.update(central_map_static=C.map_global_curr_static_, central_map_dynamic=C.map_global_curr_dynamic_,
+                            query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
+
+    def run(self):
+        self.makeGlobalMap()
+        self.run_steps_1_to_3()
