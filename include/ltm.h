@@ -142,6 +142,10 @@ int ltm_debug_range_image(ltm_ctx*, ltm_cloud pts, const double* T1, const doubl
 /* element-wise device evaluation of the projection arithmetic: out_az_el_r (3n), out_row_col (2n) */
 int ltm_debug_project(ltm_ctx*, const float* xyz, size_t n, float res_alpha, float* out_az_el_r, int32_t* out_row_col);
 void ltm_rimg_size(float vfov, float hfov, float res_alpha, int* rows, int* cols);   /* utility.cpp:222-236 */
+/* result of the create-time exhaustive device self-check of the fast arithmetic forms (rad2deg by multiplication,
+ * division by the FOV constants) against plain IEEE division over all 2^32 binary32 inputs:
+ * mismatches3 = {rad2deg, /vfov, /hfov}; the fast forms are used only when all three are zero. */
+int ltm_debug_selfcheck(ltm_ctx*, uint64_t* mismatches3, int* fast_math_enabled);
 
 /* ----------------------------------------------------------- measurement ---- */
 /* Per-kernel-class HIP-event timing on the context's stream.  Classes: "vote_map", "vote_scan",

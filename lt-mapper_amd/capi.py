@@ -71,6 +71,7 @@ SIGNATURES = {
     "ltm_knn_split_cloud": (_i, [_vp, _u64, _u64, _i, _f, _pu64, _pu64]),
     "ltm_debug_range_image": (_i, [_vp, _u64, _vp, _vp, _f, _vp, _vp]),
     "ltm_debug_project": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
+    "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
     "ltm_rimg_size": (None, [_f, _f, _f, C.POINTER(_i), C.POINTER(_i)]),
     "ltm_profile_enable": (_i, [_vp, _i]),
     "ltm_profile_reset": (_i, [_vp]),
@@ -270,6 +271,12 @@ class Context:
         rc = np.empty((a.shape[0], 2), dtype=np.int32)
         self._ck(self.lib.ltm_debug_project(self.h, a.ctypes.data, a.shape[0], alpha, sph.ctypes.data, rc.ctypes.data))
         return sph, rc
+
+    def selfcheck(self):
+        m = (C.c_uint64 * 3)()
+        on = _i()
+        self._ck(self.lib.ltm_debug_selfcheck(self.h, m, C.byref(on)))
+        return [int(x) for x in m], bool(on.value)
 
     # ---- measurement
     def synchronize(self):

@@ -10,6 +10,7 @@
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <map>
 #include <memory>
@@ -107,6 +108,8 @@ struct ltm_ctx {
     HostMat34 L2B, B2L;
     int l2b_identity = 1, b2l_identity = 1;
     size_t kf_batch = 512;
+    int fast_math = 0;   // set by the create-time self-check of the fast arithmetic forms for this FOV
+    unsigned long long selfcheck[3] = {0, 0, 0};
     Pool pool;
     uint64_t next_handle = 1;
     std::unordered_map<uint64_t, Cloud> clouds;
@@ -270,6 +273,7 @@ Geom geom_for(const ltm_ctx* c, float alpha)
     g.vfov = c->cfg.vfov; g.hfov = c->cfg.hfov;
     g.rows = (int)roundf(c->cfg.vfov * alpha);
     g.cols = (int)roundf(c->cfg.hfov * alpha);
+    g.fast = c->fast_math;
     return g;
 }
 
@@ -574,6 +578,20 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         delete c;
         return LTM_E_DEVICE;
     }
+    if (const char* v = getenv("LTM_MAP_KERNEL")) set_map_kernel_variant(atoi(v));   // A/B switch for profiling
+    // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's
+    // constants; they are enabled only if they reproduce the exact IEEE results for every input.
+    {
+        unsigned long long* d = nullptr;
+        bool ok = hipMalloc(&d, 3 * sizeof(unsigned long long)) == hipSuccess && hipMemsetAsync(d, 0, 24, c->stream) == hipSuccess &&
+                  selfcheck_fast_math(cfg->vfov, cfg->hfov, d, c->stream) == hipSuccess &&
+                  hipMemcpyAsync(c->selfcheck, d, 24, hipMemcpyDeviceToHost, c->stream) == hipSuccess &&
+                  hipStreamSynchronize(c->stream) == hipSuccess;
+        if (d) (void)hipFree(d);
+        if (!ok) { (void)hipStreamDestroy(c->stream); delete c; return LTM_E_DEVICE; }
+        c->fast_math = (c->selfcheck[0] == 0 && c->selfcheck[1] == 0 && c->selfcheck[2] == 0) ? 1 : 0;
+        if (const char* v = getenv("LTM_FAST_MATH")) c->fast_math = c->fast_math && atoi(v);
+    }
     *out = c;
     return LTM_OK;
 }
@@ -870,19 +888,62 @@ int ltm_voxel_centroid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scan
 {
     return guarded(c, [&] {
         LTM_REQUIRE(out, "null argument");
+        LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
         const ScanSet& s = get_ss(c, hin);
         const size_t nk = s.nkf();
-        std::vector<float4*> parts(nk, nullptr);
+        const size_t n = s.n_pts;
+        LTM_REQUIRE(n < 0xffffffffull, "scan set too large for 32-bit point indices");
         std::vector<uint64_t> off(nk + 1, 0);
-        for (size_t k = 0; k < nk; ++k) {
-            const size_t nv = voxel_centroid_raw(c, s.d + s.off[k], s.off[k + 1] - s.off[k], leaf, &parts[k]);
-            off[k + 1] = off[k] + nv;
+        if (n == 0 || nk == 0) {
+            *out = new_scanset(c, reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4))), std::move(off));
+            return;
         }
-        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(off[nk], 1) * 16));
-        for (size_t k = 0; k < nk; ++k) { d2d(c, d + off[k], parts[k], (off[k + 1] - off[k]) * 16); }
-        sync(c);
-        for (size_t k = 0; k < nk; ++k) c->pool.free(parts[k]);
-        *out = new_scanset(c, d, std::move(off));
+        ProfScope ps(c, "voxel_scanset", (double)n, 64.0 * n);
+        // every keyframe gets its own octree frame (bounding box re-derived per cloud, as octreeDownsampling does)
+        DevBuf bb(c, nk * 6 * sizeof(uint32_t));
+        LTM_HIP(bbox_reduce_seg(s.d, s.off_dev, nk, n, bb.as<uint32_t>(), c->stream));
+        std::vector<uint32_t> enc(nk * 6);
+        d2h(c, enc.data(), bb.p, enc.size() * 4);
+        std::vector<OctreeFrame> frames(nk);
+        unsigned dmax = 1;
+        for (size_t k = 0; k < nk; ++k) {
+            frames[k] = OctreeFrame{0, 0, 0, (double)leaf, 1};
+            if (s.off[k + 1] == s.off[k]) continue;
+            float mn[3], mx[3];
+            for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]); }
+            if (!octree_frame_from_bbox(mn, mx, leaf, &frames[k])) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+            dmax = std::max(dmax, frames[k].depth);
+        }
+        unsigned kf_bits = 1;
+        while ((1ull << kf_bits) < nk) ++kf_bits;
+        const unsigned shift = 3 * dmax;
+        if (shift + kf_bits > 64) throw Err{LTM_E_UNSUPPORTED, "scan set: keyframe id + Morton code exceed 64 key bits"};
+        DevBuf fdev(c, nk * sizeof(OctreeFrame));
+        h2d(c, fdev.p, frames.data(), nk * sizeof(OctreeFrame));
+        DevBuf keys(c, n * 8), keys2(c, n * 8), idx(c, n * 4), idx2(c, n * 4);
+        LTM_HIP(morton_keys_seg(s.d, s.off_dev, nk, n, fdev.as<OctreeFrame>(), shift, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
+        const size_t stb = sort_temp_bytes(n);
+        {
+            DevBuf stemp(c, stb);
+            LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, shift + kf_bits, stemp.p, stb, c->stream));
+        }
+        DevBuf heads(c, n), pos(c, n * 4);
+        LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
+        const size_t tb = scan_temp_bytes(n);
+        DevBuf temp(c, tb);
+        LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+        const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
+        // the sort key leads with the keyframe id, so keyframe k still occupies sorted positions [off[k], off[k+1])
+        DevBuf bout(c, (nk + 1) * 4);
+        LTM_HIP(gather_u32(pos.as<uint32_t>(), s.off_dev, nk + 1, n, (uint32_t)nvox, bout.as<uint32_t>(), c->stream));
+        std::vector<uint32_t> b(nk + 1);
+        d2h(c, b.data(), bout.p, (nk + 1) * 4);
+        for (size_t k = 0; k <= nk; ++k) off[k] = b[k];
+        DevBuf starts(c, nvox * 4);
+        LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
+        float4* o = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nvox, 1) * sizeof(float4)));
+        LTM_HIP(voxel_centroids(s.d, idx2.as<uint32_t>(), starts.as<uint32_t>(), nvox, n, o, c->stream));
+        *out = new_scanset(c, o, std::move(off));
     });
 }
 
@@ -1056,6 +1117,14 @@ int ltm_debug_project(ltm_ctx* c, const float* xyz, size_t n, float alpha, float
         LTM_HIP(debug_project(in.as<float>(), n, g, o1.as<float>(), o2.as<int32_t>(), c->stream));
         d2h(c, sph, o1.p, n * 12);
         d2h(c, rc, o2.p, n * 8);
+    });
+}
+
+int ltm_debug_selfcheck(ltm_ctx* c, uint64_t* mismatches3, int* fast_math_enabled)
+{
+    return guarded(c, [&] {
+        if (mismatches3) for (int i = 0; i < 3; ++i) mismatches3[i] = c->selfcheck[i];
+        if (fast_math_enabled) *fast_math_enabled = c->fast_math;
     });
 }
 

@@ -111,6 +111,36 @@ __device__ __forceinline__ float rad2deg_exact(float r)
     return (float)(((double)r * 180.0) / 3.14159265358979323846);
 }
 
+// Fast form: q = (double)r * K with K = RN64(180 / M_PI_d) = 0x1.ca5dc1a63c1f8p+5.  q is within 3 ulp64 of the
+// reference's RN64((r*180.0)/M_PI) (r*180.0 is exact: 24 x 8 significant bits), so RN32(q) equals the reference
+// result unless a binary32 rounding midpoint (low 29 mantissa bits == 0x10000000) lies within those few ulp of q;
+// that case (about 2e-8 of inputs) and results below the binary32 normal range take the exact division.
+// ltm_debug_selfcheck() compares this function with rad2deg_exact over all 2^32 inputs on the device.
+__device__ __forceinline__ float rad2deg_fast(float r)
+{
+    const double q = (double)r * 0x1.ca5dc1a63c1f8p+5;
+    const uint64_t b = (uint64_t)__double_as_longlong(q);
+    const uint32_t lo = (uint32_t)b & 0x1fffffffu;
+    const uint32_t hi = (uint32_t)(b >> 32) & 0x7fffffffu;
+    const bool near_mid = (lo - 0x0ffffff8u) <= 16u;            // |low29 - 2^28| <= 8
+    const bool tiny = (hi < 0x39b00000u) & ((hi | (uint32_t)b) != 0u);   // 0 < |q| < 2^-100
+    if (__builtin_expect(near_mid | tiny, 0)) return rad2deg_exact(r);
+    return (float)q;
+}
+
+// a / b for a loop-invariant b: q0 = RN(a*y), r = a - q0*b (exact in an FMA), q = RN(q0 + r*y) with y = RN(1/b).
+// This is the correctly rounded quotient (Markstein) when b's significand is not all ones and nothing under/overflows;
+// outside 2^-60 <= |a| <= 2^60 the plain division is used.  Validity for the context's FOV constants is established
+// by ltm_debug_selfcheck() (exhaustive over every binary32 `a`); a context whose constants fail it uses plain division.
+__device__ __forceinline__ float div_by_const(float a, float b, float inv_b, bool fast_ok)
+{
+    const uint32_t ia = f2u(a) & 0x7fffffffu;
+    if (__builtin_expect(!fast_ok | (ia - 0x21800000u > 0x3c000000u), 0)) return a / b;   // |a| outside [2^-60, 2^60]
+    const float q0 = a * inv_b;
+    const float r = __builtin_fmaf(-q0, b, a);
+    return __builtin_fmaf(r, inv_b, q0);
+}
+
 struct Sph { float az, el, r; };
 
 // utility.cpp:38-51
@@ -128,21 +158,28 @@ __device__ __forceinline__ Sph cart2sph(float x, float y, float z)
 struct RimgGeom {
     float vfov, hfov;   // degrees
     float half_v, half_h;
+    float inv_v, inv_h; // RN32(1/vfov), RN32(1/hfov)
     int rows, cols;
     float frows, fcols, row_max, col_max;
+    bool fast;          // the fast forms were verified for these constants
 };
 
 // utility.cpp:114-125
-__device__ __forceinline__ int pixel_index(const RimgGeom& g, float az, float el)
+__device__ __forceinline__ void pixel_row_col(const RimgGeom& g, float az, float el, int& row, int& col)
 {
-    const float el_deg = rad2deg_exact(el);
-    const float az_deg = rad2deg_exact(az);
-    float fr = roundf(g.frows * (1.0f - (el_deg + g.half_v) / g.vfov));
-    float fc = roundf(g.fcols * ((az_deg + g.half_h) / g.hfov));
-    // std::min(std::max(v, 0), hi): max(a,b) = (a<b)?b:a ; min(a,b) = (b<a)?b:a
+    const float el_deg = g.fast ? rad2deg_fast(el) : rad2deg_exact(el);
+    const float az_deg = g.fast ? rad2deg_fast(az) : rad2deg_exact(az);
+    float fr = roundf(g.frows * (1.0f - div_by_const(el_deg + g.half_v, g.vfov, g.inv_v, g.fast)));
+    float fc = roundf(g.fcols * div_by_const(az_deg + g.half_h, g.hfov, g.inv_h, g.fast));
     fr = (fr < 0.0f) ? 0.0f : fr;  fr = (g.row_max < fr) ? g.row_max : fr;
     fc = (fc < 0.0f) ? 0.0f : fc;  fc = (g.col_max < fc) ? g.col_max : fc;
-    return (int)fr * g.cols + (int)fc;
+    row = (int)fr; col = (int)fc;
+}
+__device__ __forceinline__ int pixel_index(const RimgGeom& g, float az, float el)
+{
+    int row, col;
+    pixel_row_col(g, az, el, row, col);
+    return row * g.cols + col;
 }
 
 // PCL transformPointCloud<PointXYZI,double>: (float)(((m0*x + m1*y) + m2*z) + m3) per row, double math.

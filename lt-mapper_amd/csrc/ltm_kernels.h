@@ -10,6 +10,7 @@ namespace ltm {
 struct Geom {            // range-image geometry (utility.cpp:222-236 resetRimgSize + fov)
     float vfov, hfov;
     int rows, cols;
+    int fast;            // 1: use the self-checked fast arithmetic forms (ltm_device_math.h), 0: plain IEEE divisions
 };
 
 // 3x4 row-major double (last row of the 4x4 is never used by PCL's se3 transformer)
@@ -32,11 +33,15 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
 hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
                             uint8_t* labels, hipStream_t s);
+void set_map_kernel_variant(int v);   // 0 = per-point global atomics, 1 = LDS pre-reduction (default)
 // generic single image with up to two explicit transforms (debug / parity)
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,
                               uint64_t* img, hipStream_t s);
 hipError_t decode_image(const uint64_t* img, size_t npx, float* rimg, int32_t* ptidx, hipStream_t s);
 hipError_t debug_project(const float* xyz_dev, size_t n, Geom g, float* az_el_r, int32_t* row_col, hipStream_t s);
+// exhaustive device self-check of the fast arithmetic forms against their exact definitions for (vfov, hfov):
+// counts[0] rad2deg mismatches, counts[1] /vfov mismatches, counts[2] /hfov mismatches over all 2^32 binary32 inputs
+hipError_t selfcheck_fast_math(float vfov, float hfov, unsigned long long* counts_dev, hipStream_t s);
 
 // ---- compaction helpers (prefix sums via rocPRIM) ----
 size_t scan_temp_bytes(size_t n);
@@ -69,6 +74,10 @@ hipError_t bbox_reduce(const float4* pts, size_t n, uint32_t* bbox, hipStream_t 
 float      bbox_decode(uint32_t enc);
 struct OctreeFrame { double minx, miny, minz, res; unsigned depth; };
 hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* keys, uint32_t* idx, hipStream_t s);
+// scan-set (segmented) forms: one bbox / octree frame per keyframe, composite sort key (kf << shift) | morton
+hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, uint32_t* bbox, hipStream_t s);
+hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const OctreeFrame* frames_dev,
+                           unsigned shift, uint64_t* keys, uint32_t* idx, hipStream_t s);
 size_t sort_temp_bytes(size_t n);
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
                           unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);

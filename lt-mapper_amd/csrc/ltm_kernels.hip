@@ -28,6 +28,8 @@ __host__ __device__ inline RimgGeom make_geom(Geom g)
     RimgGeom r;
     r.vfov = g.vfov; r.hfov = g.hfov;
     r.half_v = g.vfov / 2.0f; r.half_h = g.hfov / 2.0f;
+    r.inv_v = 1.0f / g.vfov; r.inv_h = 1.0f / g.hfov;
+    r.fast = g.fast != 0;
     r.rows = g.rows; r.cols = g.cols;
     r.frows = (float)g.rows; r.fcols = (float)g.cols;
     r.row_max = (float)(g.rows - 1); r.col_max = (float)(g.cols - 1);
@@ -144,10 +146,88 @@ k_map_rimg(const float4* __restrict__ map, size_t M, const double* __restrict__ 
     img_min_u64(img + (size_t)blockIdx.y * (size_t)(g.rows * g.cols) + px, v);
 }
 
+// Same contract as k_map_rimg, with a per-workgroup LDS pre-reduction.  Map points are stored in octree (Morton)
+// order, so the 4096 consecutive points of a workgroup cover a compact patch of the range image and many of
+// them share a pixel: they are first min-reduced in a 2048-slot direct-mapped LDS table (slot = low bits of
+// row/col, 64-bit ds_min), and only one global atomic per touched pixel leaves the CU.  A point whose slot
+// is owned by another pixel goes straight to the global image.  uint64 min is associative and commutative,
+// so the final image is identical to the serial reference result.
+static constexpr int kLdsSlots = 2048;
+static constexpr int kPtsPerThread = 16;
+static constexpr uint32_t kEmptyTag = 0xffffffffu;
+
+template <bool B2L_IDENTITY, int ABL = 0>
+__global__ void __launch_bounds__(kBlock)
+k_map_rimg_lds(const float4* __restrict__ map, size_t M, const double* __restrict__ inv_poses, size_t kb,
+               HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img)
+{
+    __shared__ uint64_t vals[kLdsSlots];
+    __shared__ uint32_t tags[kLdsSlots];
+    for (int s = threadIdx.x; s < kLdsSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
+    __syncthreads();
+    const size_t kf = kb + blockIdx.y;
+    const Mat34 Tinv = load_mat(inv_poses + 12 * kf);
+    const RimgGeom g = make_geom(gg);
+    uint64_t* __restrict__ imgk = img + (size_t)blockIdx.y * (size_t)(g.rows * g.cols);
+    const size_t base = (size_t)blockIdx.x * (size_t)(kBlock * kPtsPerThread) + threadIdx.x;
+#pragma unroll 2
+    for (int j = 0; j < kPtsPerThread; ++j) {
+        const size_t i = base + (size_t)j * kBlock;
+        if (i >= M) break;
+        const float4 p4 = map[i];
+        int row, col;
+        Sph s;
+        if (ABL == 2) {   // fake, cheap projection with similar locality
+            const float fx = p4.x - (float)Tinv.m[3], fy = p4.y - (float)Tinv.m[7];
+            s.r = fabsf(fx) + fabsf(fy) + fabsf(p4.z);
+            row = min(max((int)(p4.z * 8.0f) + 40, 0), g.rows - 1);
+            col = min(max((int)((fx + fy) * 3.0f) + g.cols / 2, 0), g.cols - 1);
+        } else {
+            float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+            if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+            s = cart2sph(p.x, p.y, p.z);
+            pixel_row_col(g, s.az, s.el, row, col);
+        }
+        const uint32_t px = (uint32_t)(row * g.cols + col);
+        const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)(uint32_t)i;
+        const int slot = ((row & 15) << 7) | (col & 127);
+        if (ABL == 1) { if (v == 0x123456789ull) imgk[px] = v; continue; }
+        uint32_t t = tags[slot];
+        if (t == kEmptyTag) {
+            const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+            t = (old == kEmptyTag) ? px : old;
+        }
+        if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+        else img_min_u64(imgk + px, v);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kLdsSlots; s += kBlock) {
+        const uint32_t t = tags[s];
+        if (t != kEmptyTag) img_min_u64(imgk + t, vals[s]);
+    }
+}
+
+static int g_map_kernel_variant = 1;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction
+void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
+
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb, HostMat34 b2l,
                             int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s)
 {
     if (!M || !nb) return hipSuccess;
+    if (g_map_kernel_variant == 1) {
+        const size_t per_block = (size_t)kBlock * kPtsPerThread;
+        dim3 grid((unsigned)((M + per_block - 1) / per_block), (unsigned)nb);
+        if (b2l_identity) k_map_rimg_lds<true><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+        else k_map_rimg_lds<false><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+        return hipGetLastError();
+    }
+    if (g_map_kernel_variant == 2 || g_map_kernel_variant == 3) {
+        const size_t per_block = (size_t)kBlock * kPtsPerThread;
+        dim3 grid((unsigned)((M + per_block - 1) / per_block), (unsigned)nb);
+        if (g_map_kernel_variant == 2) k_map_rimg_lds<true, 1><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+        else k_map_rimg_lds<true, 2><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+        return hipGetLastError();
+    }
     dim3 grid(grid_for(M), (unsigned)nb);
     if (b2l_identity) k_map_rimg<true><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
     else k_map_rimg<false><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
@@ -229,6 +309,32 @@ hipError_t debug_project(const float* xyz_dev, size_t n, Geom g, float* az_el_r,
 {
     if (!n) return hipSuccess;
     k_debug_project<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(xyz_dev, n, g, az_el_r, row_col);
+    return hipGetLastError();
+}
+
+__global__ void __launch_bounds__(kBlock)
+k_selfcheck(float vfov, float hfov, unsigned long long* __restrict__ counts)
+{
+    const float inv_v = 1.0f / vfov, inv_h = 1.0f / hfov;
+    unsigned long long bad0 = 0, bad1 = 0, bad2 = 0;
+    const uint64_t stride = (uint64_t)gridDim.x * blockDim.x;
+    for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < (1ull << 32); i += stride) {
+        const float a = u2f((uint32_t)i);
+        const float e0 = rad2deg_exact(a), f0 = rad2deg_fast(a);
+        const float e1 = a / vfov, f1 = div_by_const(a, vfov, inv_v, true);
+        const float e2 = a / hfov, f2 = div_by_const(a, hfov, inv_h, true);
+        // NaN payloads are irrelevant (NaN never reaches a pixel index in a defined way): compare as "both NaN"
+        bad0 += !((f2u(e0) == f2u(f0)) | ((e0 != e0) & (f0 != f0)));
+        bad1 += !((f2u(e1) == f2u(f1)) | ((e1 != e1) & (f1 != f1)));
+        bad2 += !((f2u(e2) == f2u(f2)) | ((e2 != e2) & (f2 != f2)));
+    }
+    if (bad0) atomicAdd(counts + 0, bad0);
+    if (bad1) atomicAdd(counts + 1, bad1);
+    if (bad2) atomicAdd(counts + 2, bad2);
+}
+hipError_t selfcheck_fast_math(float vfov, float hfov, unsigned long long* counts_dev, hipStream_t s)
+{
+    k_selfcheck<<<dim3(8192), dim3(kBlock), 0, s>>>(vfov, hfov, counts_dev);
     return hipGetLastError();
 }
 
@@ -397,6 +503,7 @@ hipError_t bbox_init(uint32_t* bbox, hipStream_t s)
 __global__ void __launch_bounds__(kBlock)
 k_bbox_reduce(const float4* __restrict__ pts, size_t n, uint32_t* __restrict__ bbox)
 {
+    __shared__ uint32_t smn[3][kBlock / 64], smx[3][kBlock / 64];
     uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
     const size_t stride = (size_t)gridDim.x * blockDim.x;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
@@ -413,15 +520,98 @@ k_bbox_reduce(const float4* __restrict__ pts, size_t n, uint32_t* __restrict__ b
             mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], off, 64));
         }
     }
+    const int wave = threadIdx.x >> 6;
     if ((threadIdx.x & 63) == 0) {
 #pragma unroll
-        for (int d = 0; d < 3; ++d) { atomicMin(bbox + d, mn[d]); atomicMax(bbox + 3 + d, mx[d]); }
+        for (int d = 0; d < 3; ++d) { smn[d][wave] = mn[d]; smx[d][wave] = mx[d]; }
+    }
+    __syncthreads();
+    if (threadIdx.x < 3) {          // one set of 6 atomics per workgroup
+        const int d = threadIdx.x;
+        uint32_t a = smn[d][0], b = smx[d][0];
+        for (int w = 1; w < kBlock / 64; ++w) { a = min(a, smn[d][w]); b = max(b, smx[d][w]); }
+        atomicMin(bbox + d, a); atomicMax(bbox + 3 + d, b);
     }
 }
 hipError_t bbox_reduce(const float4* pts, size_t n, uint32_t* bbox, hipStream_t s)
 {
     if (!n) return hipSuccess;
-    k_bbox_reduce<<<dim3((unsigned)std::min<size_t>(grid_for(n), 2048)), dim3(kBlock), 0, s>>>(pts, n, bbox);
+    k_bbox_reduce<<<dim3((unsigned)std::min<size_t>(grid_for(n, kBlock * 8), 1024)), dim3(kBlock), 0, s>>>(pts, n, bbox);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t spread3(uint32_t v);
+
+// per-keyframe bounding boxes of a scan set: bbox[kf][6], same encoding
+__global__ void k_bbox_init_seg(uint32_t* b, size_t n_kf)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_kf * 6) b[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
+}
+__global__ void __launch_bounds__(kBlock)
+k_bbox_reduce_seg(const float4* __restrict__ pts, const uint64_t* __restrict__ offsets, size_t n_kf, uint64_t n, uint32_t* __restrict__ bbox)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const bool live = i < n;
+    size_t kf = 0;
+    uint32_t e[3] = {0, 0, 0};
+    if (live) {
+        size_t lo = 0, hi = n_kf;
+        while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+        kf = lo;
+        const float4 p = pts[i];
+        e[0] = enc_f32(p.x); e[1] = enc_f32(p.y); e[2] = enc_f32(p.z);
+    }
+    // wave-uniform keyframe (the common case: ~1e5 points per keyframe): reduce in the wave, one lane writes
+    const size_t kf0 = (size_t)__shfl((int)kf, 0, 64);
+    const bool uniform = __all(live && kf == kf0);
+    if (uniform) {
+        uint32_t mn[3] = {e[0], e[1], e[2]}, mx[3] = {e[0], e[1], e[2]};
+#pragma unroll
+        for (int d = 0; d < 3; ++d)
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                mn[d] = min(mn[d], (uint32_t)__shfl_xor((int)mn[d], off, 64));
+                mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], off, 64));
+            }
+        if ((threadIdx.x & 63) == 0)
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { atomicMin(bbox + 6 * kf + d, mn[d]); atomicMax(bbox + 6 * kf + 3 + d, mx[d]); }
+    } else if (live) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { atomicMin(bbox + 6 * kf + d, e[d]); atomicMax(bbox + 6 * kf + 3 + d, e[d]); }
+    }
+}
+hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, uint32_t* bbox, hipStream_t s)
+{
+    if (!n_kf) return hipSuccess;
+    k_bbox_init_seg<<<dim3(grid_for(n_kf * 6)), dim3(kBlock), 0, s>>>(bbox, n_kf);
+    if (n) k_bbox_reduce_seg<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, offsets_dev, n_kf, n, bbox);
+    return hipGetLastError();
+}
+
+// composite key = (keyframe << shift) | Morton code in that keyframe's own octree frame
+__global__ void __launch_bounds__(kBlock)
+k_morton_keys_seg(const float4* __restrict__ pts, const uint64_t* __restrict__ offsets, size_t n_kf, uint64_t n,
+                  const OctreeFrame* __restrict__ frames, unsigned shift, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    size_t lo = 0, hi = n_kf;
+    while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+    const OctreeFrame f = frames[lo];
+    const float4 p = pts[i];
+    const uint32_t kx = (uint32_t)(((double)p.x - f.minx) / f.res);
+    const uint32_t ky = (uint32_t)(((double)p.y - f.miny) / f.res);
+    const uint32_t kz = (uint32_t)(((double)p.z - f.minz) / f.res);
+    keys[i] = ((uint64_t)lo << shift) | (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+    idx[i] = (uint32_t)i;
+}
+hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const OctreeFrame* frames_dev,
+                           unsigned shift, uint64_t* keys, uint32_t* idx, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_morton_keys_seg<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, offsets_dev, n_kf, n, frames_dev, shift, keys, idx);
     return hipGetLastError();
 }
 
@@ -636,22 +826,34 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
     } else {
         long long cx, cy, cz;
         cell_of(g, qx, qy, qz, cx, cy, cz);
-        for (long long dx = -1; dx <= 1; ++dx)
-            for (long long dy = -1; dy <= 1; ++dy)
-                for (long long dz = -1; dz <= 1; ++dz) {
-                    const long long x = cx + dx, y = cy + dy, z = cz + dz;
-                    if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) continue;
-                    const uint64_t key = cell_id(g, x, y, z);
-                    uint32_t h = hash64(key) & mask;
-                    uint32_t a = 0, b = 0;
-                    while (true) {
-                        const uint64_t kk = table[h].key;
-                        if (kk == key) { a = table[h].start; b = table[h].end; break; }
-                        if (kk == kEmptyKey) break;
-                        h = (h + 1) & mask;
-                    }
-                    for (uint32_t j = a; j < b; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
-                }
+        // 27 cells, centre first, then faces, edges, corners.  Early exit: as soon as the current k best already
+        // satisfy the predicate the answer is final -- further neighbours can only lower the (monotonically
+        // rounded) sum, so "coexist" cannot flip back.  Most queries of a static scene stop after the first cell.
+        constexpr int8_t kOrder[27][3] = {
+            {0, 0, 0},
+            {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
+            {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1}, {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
+            {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
+        for (int c = 0; c < 27; ++c) {
+            const long long x = cx + kOrder[c][0], y = cy + kOrder[c][1], z = cz + kOrder[c][2];
+            if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) continue;
+            const uint64_t key = cell_id(g, x, y, z);
+            uint32_t h = hash64(key) & mask;
+            uint32_t a = 0, b = 0;
+            while (true) {
+                const uint64_t kk = table[h].key;
+                if (kk == key) { a = table[h].start; b = table[h].end; break; }
+                if (kk == kEmptyKey) break;
+                h = (h + 1) & mask;
+            }
+            if (a == b) continue;
+            for (uint32_t j = a; j < b; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
+            if (cnt == k && best[k - 1] < cell2_lo) {
+                double acc = 0.0;
+                for (int j = 0; j < k; ++j) acc = acc + (double)best[j];
+                if (fabsf((float)acc / (float)k_param) < thr) return true;
+            }
+        }
         // fewer than k neighbours inside the provably-complete radius => the k-th neighbour is >= cell away => "diff"
         if (cnt < k || !(best[k - 1] < cell2_lo)) return false;
     }

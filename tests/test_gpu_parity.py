@@ -218,3 +218,31 @@ def test_empty_and_ragged_inputs(gpu_ctx, orc):
     co, di = gpu_ctx.knn_partition(gpu_ctx.upload(empty), g_scans, g_poses, 2, 0.01)
     assert co.info()[1] == 0 and di.info()[1] == 1000            # nothing coexists with an empty map
     assert (di.offsets() == off).all()
+
+
+def test_fast_math_selfcheck_is_exhaustive_and_clean(gpu_ctx, ltm):
+    """the create-time device self-check compares the fast rad2deg / divide-by-FOV forms with plain IEEE division over
+    all 2^32 binary32 inputs; the fast forms are only enabled when no input differs"""
+    mism, enabled = gpu_ctx.selfcheck()
+    assert mism == [0, 0, 0] and enabled, f"fast arithmetic forms rejected for fov (50,360): {mism}"
+    for vfov, hfov in ((45.0, 360.0), (26.9, 360.0), (30.5, 120.25)):
+        c = ltm.Context(vfov=vfov, hfov=hfov, device=0)
+        m, on = c.selfcheck()
+        assert on == (m == [0, 0, 0])     # whatever the verdict, it must be the one that gates the fast path
+        c.close()
+
+
+def test_voxel_centroid_scanset_matches_per_keyframe_oracle(gpu_ctx, orc, small_pair):
+    C, _ = small_pair
+    off = C["offsets"].copy()
+    pts = C["scans"].copy()
+    # make it ragged: an empty keyframe, a single-point keyframe
+    off2 = np.array([0, 0, int(off[2]), int(off[2]) + 1, int(off[4]), int(off[-1])], dtype=np.uint64)
+    g = gpu_ctx.voxel_centroid_scanset(gpu_ctx.upload_scans(pts, off2), 0.05)
+    g_pts, g_off = g.download()
+    at = 0
+    for k in range(len(off2) - 1):
+        want = orc.voxel_centroid(pts[int(off2[k]):int(off2[k + 1])], 0.05)
+        assert int(g_off[k]) == at and int(g_off[k + 1]) == at + len(want)
+        assert_clouds_equal(g_pts[at:at + len(want)], want, f"scanwise voxel kf {k}")
+        at += len(want)
