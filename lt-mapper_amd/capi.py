@@ -122,7 +122,7 @@ class Context:
         l2b = _mat16(np.eye(4) if lidar2base is None else lidar2base)
         for i in range(16):
             cfg.lidar2base[i] = l2b[i]
-        self.vfov, self.hfov = float(vfov), float(hfov)
+        self.vfov, self.hfov, self.device = float(vfov), float(hfov), int(device)
         h = _vp()
         rc = self.lib.ltm_create(C.byref(cfg), C.byref(h))
         if rc != LTM_OK:

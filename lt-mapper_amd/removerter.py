@@ -53,6 +53,48 @@ class HipOps:
     def zip_concat(self, a, b, c): return self.ctx.zip_concat(a, b, c)
     def sync(self): self.ctx.synchronize()
 
+    # ---- pieces used by dist.ShardedOps (keyframe ranges + tensors for the collectives)
+    def n_keyframes(self, poses): return poses.n
+
+    def new_labels(self, n):
+        import torch
+        return torch.zeros(max(n, 1), dtype=torch.uint8, device=f"cuda:{self.ctx.device}")[:n]
+
+    def vote(self, cmap, scans, poses, kb, ke, alpha, thr, mode, labels):
+        if labels.numel():
+            self.ctx.visibility_vote(cmap, scans, poses, kb, ke, alpha, thr, mode, labels.data_ptr())
+
+    def partition(self, cmap, labels):
+        import torch
+        torch.cuda.current_stream().synchronize()      # the all-reduce ran on torch's stream
+        return self.ctx.partition_by_labels(cmap, labels.data_ptr() if labels.numel() else None)
+
+    def reproject_range(self, cmap, poses, alpha, kb, ke): return self.ctx.reproject(cmap, poses, alpha, kb, ke)
+    def knn_partition_range(self, target, scans, poses, k, thr, kb, ke): return self.ctx.knn_partition(target, scans, poses, k, thr, kb, ke)
+    def concat_scansets(self, sets): return self.ctx.concat_scansets(sets)
+
+    def scanset_to_tensors(self, ss):
+        import torch
+        n_kf, n = ss.info()
+        off = ss.offsets()
+        self.ctx.synchronize()
+        if n == 0:
+            return torch.zeros((0, 4), dtype=torch.float32, device=f"cuda:{self.ctx.device}"), off
+        view = _DeviceArray(ss.device_ptr(), (n, 4), "<f4")
+        return torch.as_tensor(view, device=f"cuda:{self.ctx.device}").clone(), off
+
+    def scanset_from_tensors(self, pts, offsets):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        return self.ctx.scans_from_device(pts.data_ptr() if pts.numel() else None, np.asarray(offsets, dtype=np.uint64))
+
+
+class _DeviceArray:
+    """zero-copy view of library-owned device memory for torch (CUDA array interface v2)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (int(ptr), False), "version": 2}
+
 
 class Session:
     """ltremovert::Session state (Session.h:9-136): everything is a device handle"""

@@ -1,0 +1,113 @@
+"""TEST INFRASTRUCTURE: the stage interface of ltmapper_amd.removerter.HipOps implemented with the CPU oracle, so the
+host logic (Removerter orchestration, dist.ShardedOps exchange) can be exercised on CPU / gloo.  Never shipped."""
+import numpy as np
+import torch
+
+from oracle import oracle_py as orc
+
+
+class OPoses:
+    def __init__(self, poses, inv):
+        self.poses = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+        self.inv = np.ascontiguousarray(inv, dtype=np.float64).reshape(-1, 16)
+        self.n = self.poses.shape[0]
+
+
+class OScans:
+    def __init__(self, pts, off):
+        self.pts = np.ascontiguousarray(pts, dtype=np.float32).reshape(-1, 4)
+        self.off = np.ascontiguousarray(off, dtype=np.uint64)
+
+    def download(self):
+        return self.pts, self.off
+
+
+class OCloud(np.ndarray):
+    def download(self):
+        return np.asarray(self)
+
+
+def _c(a):
+    return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4).view(OCloud)
+
+
+class OracleOps:
+    def __init__(self, vfov=50.0, hfov=360.0, l2b=None, threads=1):
+        self.vfov, self.hfov = vfov, hfov
+        self.l2b = np.eye(4) if l2b is None else np.asarray(l2b, dtype=np.float64)
+        self.b2l = np.eye(4) if l2b is None else orc.inverse4x4(self.l2b)
+        self.threads = threads
+
+    def clone(self, c): return _c(np.array(c))
+    def concat(self, cs): return _c(np.concatenate([np.asarray(c).reshape(-1, 4) for c in cs]))
+    def size(self, c): return len(c)
+    def empty_cloud(self): return _c(np.zeros((0, 4), np.float32))
+    def sync(self): pass
+    def merge_to_global(self, s, p): return _c(orc.merge_to_global(s.pts, s.off, p.poses, self.l2b))
+    def voxel(self, c, leaf): return _c(orc.voxel_centroid(c, leaf))
+
+    def voxel_scanset(self, s, leaf):
+        parts = [orc.voxel_centroid(s.pts[int(s.off[k]):int(s.off[k + 1])], leaf) for k in range(len(s.off) - 1)]
+        return self._pack(parts)
+
+    @staticmethod
+    def _pack(parts):
+        off = np.cumsum([0] + [len(p) for p in parts]).astype(np.uint64)
+        pts = np.concatenate(parts) if parts else np.zeros((0, 4), np.float32)
+        return OScans(pts, off)
+
+    # ---- sharding pieces
+    def n_keyframes(self, p): return p.n
+    def new_labels(self, n): return torch.zeros(n, dtype=torch.uint8)
+
+    def vote(self, cmap, scans, poses, kb, ke, alpha, thr, mode, labels):
+        if labels.numel():
+            lab = labels.numpy()
+            orc.vote_labels(cmap, scans.pts, scans.off, poses.inv, self.b2l, self.vfov, self.hfov, alpha, thr, mode, kb, ke, self.threads, lab)
+
+    def partition(self, cmap, labels):
+        lab = labels.numpy().astype(bool)
+        m = np.asarray(cmap).reshape(-1, 4)
+        return _c(m[~lab]), _c(m[lab])
+
+    def vote_partition(self, cmap, scans, poses, alpha, thr, mode):
+        labels = self.new_labels(len(cmap))
+        self.vote(cmap, scans, poses, 0, poses.n, alpha, thr, mode, labels)
+        return self.partition(cmap, labels)
+
+    def reproject_range(self, cmap, poses, alpha, kb, ke):
+        pts, off = orc.reproject(cmap, poses.inv, self.b2l, self.vfov, self.hfov, alpha, kb, ke, self.threads)
+        return OScans(pts, off)
+
+    def reproject(self, cmap, poses, alpha): return self.reproject_range(cmap, poses, alpha, 0, poses.n)
+
+    def knn_partition_range(self, target, scans, poses, k, thr, kb, ke):
+        co, loc = orc.knn_labels(target, scans.pts, scans.off, poses.poses, poses.inv, self.b2l, k, thr, kb, ke, self.threads)
+        cos, dis = [], []
+        for kf in range(kb, ke):
+            a, b = int(scans.off[kf]), int(scans.off[kf + 1])
+            m = co[a:b] == 1
+            cos.append(loc[a:b][m]); dis.append(loc[a:b][~m])
+        return self._pack(cos), self._pack(dis)
+
+    def knn_partition(self, target, scans, poses, k, thr): return self.knn_partition_range(target, scans, poses, k, thr, 0, poses.n)
+
+    def knn_split(self, target, query, k, thr):
+        near = orc.knn_split(target, query, k, thr).astype(bool)
+        q = np.asarray(query).reshape(-1, 4)
+        return _c(q[near]), _c(q[~near])
+
+    def zip_concat(self, a, b, c):
+        parts = []
+        for k in range(len(a.off) - 1):
+            parts.append(np.concatenate([s.pts[int(s.off[k]):int(s.off[k + 1])] for s in (a, b, c) if s is not None]))
+        return self._pack(parts)
+
+    def concat_scansets(self, sets):
+        parts = []
+        for s in sets:
+            parts += [s.pts[int(s.off[k]):int(s.off[k + 1])] for k in range(len(s.off) - 1)]
+        return self._pack(parts)
+
+    def scanset_to_tensors(self, s): return torch.from_numpy(np.array(s.pts)), s.off
+    def scanset_from_tensors(self, pts, off): return OScans(pts.numpy(), np.asarray(off, dtype=np.uint64))

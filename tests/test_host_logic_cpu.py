@@ -1,0 +1,102 @@
+"""CPU tests of the host logic: the Python Removerter orchestration (product code, lt-mapper_amd/removerter.py) driven by
+oracle-backed stage ops must reproduce the independent C++ oracle pipeline; and the keyframe-sharded exchange
+(lt-mapper_amd/dist.py) over gloo with world_size 2 must reproduce the single-process result bit for bit."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import assert_clouds_equal
+
+MAPS = ["OriginalNoisyCentralMapGlobal", "OriginalNoisyQueryMapGlobal", "central_map_static", "central_map_dynamic", "query_map_static",
+        "query_map_dynamic", "central_sess_high_dyn", "query_sess_high_dyn", "union_map_queryside", "union_map_centralside", "pd_map",
+        "nd_map", "strong_nd_map", "weak_nd_map", "strong_pd_map", "weak_pd_map", "updated_map", "updated_map_strong"]
+
+
+def _tiny_pair():
+    from tools import synth
+    return (synth.to_numpy(synth.make_session(1, 4, "tiny")), synth.to_numpy(synth.make_session(2, 4, "tiny")))
+
+
+def _run(ops, C, Q, **kw):
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.removerter import Params, Removerter, Session
+    from oracle_ops import OPoses, OScans
+    sessions = [Session(n, OScans(S["scans"], S["offsets"]), OPoses(S["poses"], S["inv"])) for n, S in (("Central", C), ("Query", Q))]
+    rm = Removerter(ops, Params(**kw), *sessions)
+    rm.run()
+    out = {k: np.asarray(v.download()) for k, v in rm.outputs.items()}
+    scans = {k: v.download() for k, v in rm.scan_outputs().items()}
+    return out, scans
+
+
+def _check_against_oracle_pipeline(out, scans, ref):
+    for name in MAPS:
+        want = ref.cloud(name)
+        if want is None:
+            assert name not in out
+            continue
+        assert_clouds_equal(out[name], want, name)
+    for name, (pts, off) in scans.items():
+        w_pts, w_off = ref.scanset(name)
+        assert (np.asarray(off) == w_off).all(), name
+        assert_clouds_equal(pts, w_pts, name)
+
+
+@pytest.mark.parametrize("three_res", [False, True])
+def test_python_orchestration_matches_cpp_oracle_pipeline(orc, three_res):
+    from oracle_ops import OracleOps
+    C, Q = _tiny_pair()
+    kw = dict(gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5]) if three_res else {}
+    out, scans = _run(OracleOps(), C, Q, **kw)
+    ref = orc.pipeline_run(orc.make_params(use_self_removert=three_res, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,)), C, Q)
+    _check_against_oracle_pipeline(out, scans, ref)
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.dist import ShardedOps
+    from oracle_ops import OracleOps
+    C, Q = _tiny_pair()
+    out, scans = _run(ShardedOps(OracleOps(), dist, rank, world), C, Q)
+    q.put((rank, out, {k: (np.asarray(p), np.asarray(o)) for k, (p, o) in scans.items()}))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_keyframe_sharding_over_gloo_world2_matches_single_process(orc):
+    import torch.multiprocessing as mp
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=300) for _ in range(2)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    C, Q = _tiny_pair()
+    ref = orc.pipeline_run(orc.make_params(), C, Q)
+    for rank, out, scans in results:       # every rank must hold the full, identical result
+        _check_against_oracle_pipeline(out, scans, ref)
+
+
+def test_shard_ranges_cover_and_are_disjoint():
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.dist import shard_range
+    for n in (0, 1, 7, 500, 2000):
+        for world in (1, 2, 3, 8):
+            r = [shard_range(n, k, world) for k in range(world)]
+            assert r[0][0] == 0 and r[-1][1] == n
+            assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
+            assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
