@@ -1,0 +1,84 @@
+// Removerter.h -- mirror of ltremovert::Removerter (ltremovert/include/removert/Removerter.h:67-201) over the C ABI.
+// Same public method names and the same run() script (Removerter.cpp:1653-1678); the bodies are calls into
+// libltm_hip.so.  ROS publishers / image transport (Removerter.cpp:55-71, 580-585) are visualisation only and absent.
+#pragma once
+#include <memory>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "removert/RosParamServer.h"
+#include "removert/Session.h"
+
+namespace ltremovert
+{
+
+class Removerter : public RosParamServer
+{
+private:
+    std::shared_ptr<Device> dev_;
+    Session central_sess_;
+    Session query_sess_;
+
+    std::string updated_scans_save_dir_, updated_strong_scans_save_dir_, pd_scans_save_dir, strong_pd_scans_save_dir, strong_nd_scans_save_dir;
+    std::string central_map_static_save_dir_, central_map_dynamic_save_dir_;
+
+    float curr_res_alpha_ = 0.0f;
+    std::pair<int, int> curr_rimg_shape_{0, 0};
+    CloudPtr union_q_, union_c_;
+
+    void saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout = true);
+
+public:
+    Removerter();
+    ~Removerter();
+
+    void loadSessionInfo(void);
+    void parseKeyframes(void);
+    void loadKeyframes(void);
+    void precleaningKeyframes(float _radius);
+
+    void makeGlobalMap(Session& _sess);
+    void makeGlobalMap();
+
+    std::pair<CloudPtr, CloudPtr> partitionCurrentMap(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    std::pair<CloudPtr, CloudPtr> partitionCurrentMapForND(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    std::pair<CloudPtr, CloudPtr> partitionCurrentMapForPD(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
+
+    void removeOnce(Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void revertOnce(Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void resetCurrrentMapAsDynamic(Session& _sess, bool _as_dynamic);
+    void resetCurrrentMapAsDynamic(Session& _sess);
+    void resetCurrrentMapAsStatic(Session& _sess);
+    void selfRemovert(Session& _sess, int _repeat);
+    void removeHighDynamicPoints(void);
+
+    void filterStrongND(Session& _sess_src, Session& _sess_cleaner);
+    void iremoveOnceForND(Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void filterStrongPD(Session& _sess_src, Session& _sess_cleaner);
+    void removeOnceForPD(Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void detectLowDynamicPoints(void);
+
+    void updateCurrentMap(void);
+    void parseStaticScansViaProjection(Session& _sess);
+    void parseStaticScansViaProjection(void);
+    void parseUpdatedStaticScansViaProjection(void);
+    void parseUpdatedStaticScansViaProjection(Session& _sess);
+    void parseLDScansViaProjection();
+    void parseLDScansViaProjection(Session& _sess);
+    void updateScansScanwise(Session& _sess);
+    void updateScansScanwise();
+
+    void saveCurrentStaticAndDynamicPointCloudGlobal(const Session& _sess, std::string _postfix);
+    void saveAllTypeOfScans();
+    void saveUpdatedScans(Session& _sess);
+    void saveLDScans(Session& _sess);
+    void savePDScans(Session& _sess);
+    void saveStrongPDScans(Session& _sess);
+    void saveStrongNDScans(Session& _sess);
+    void saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout);
+
+    void run(void);
+};
+
+} // namespace ltremovert

@@ -1,0 +1,98 @@
+// Session.h -- mirror of ltremovert::Session (ltremovert/include/removert/Session.h:9-136) over the C ABI.
+// Member and method names follow the reference; clouds are device handles (ltm_cloud / ltm_scanset) instead of
+// pcl::PointCloud::Ptr, and the kd-tree / ICP members are gone (the kNN stage is one C-ABI call).
+#pragma once
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "removert/RosParamServer.h"
+#include "removert/utility.h"
+
+namespace ltremovert
+{
+
+// one context per process, shared by both sessions and the Removerter (the reference shares nothing but ROS)
+struct Device
+{
+    ltm_ctx* ctx = nullptr;
+    explicit Device(const RosParamServer& p);
+    ~Device();
+    Device(const Device&) = delete;
+    Device& operator=(const Device&) = delete;
+};
+
+// RAII handles ("boost::shared_ptr<cloud>" of the reference)
+struct CloudH { ltm_ctx* ctx = nullptr; ltm_cloud h = 0; CloudH() = default; CloudH(ltm_ctx* c, ltm_cloud v) : ctx(c), h(v) {} ~CloudH(); size_t size() const; Cloud download() const; };
+struct ScansH { ltm_ctx* ctx = nullptr; ltm_scanset h = 0; ScansH() = default; ScansH(ltm_ctx* c, ltm_scanset v) : ctx(c), h(v) {} ~ScansH(); size_t numKeyframes() const; std::vector<Cloud> download() const; };
+using CloudPtr = std::shared_ptr<CloudH>;
+using ScansPtr = std::shared_ptr<ScansH>;
+
+class Session : public RosParamServer
+{
+public:
+    const float kReprojectionAlpha = 3.0;   // Session.h:13
+
+    explicit Session(std::shared_ptr<Device> dev);
+
+    std::shared_ptr<Device> dev_;
+    std::string sess_type_;
+    float kDownsampleVoxelSize;
+    std::string scan_dir_, pose_path_;
+
+    std::vector<std::string> scan_names_, scan_paths_;
+    std::vector<Matrix4d> scan_poses_, scan_inverse_poses_;
+    int num_scans_ = 0;
+
+    int keyframe_gap_ = 1;
+    std::vector<std::string> keyframe_names_, keyframe_paths_;
+    std::vector<Matrix4d> keyframe_poses_, keyframe_inverse_poses_;
+
+    ltm_poses poses_h_ = 0;                 // keyframe_poses_ + keyframe_inverse_poses_ on the device
+    ScansPtr keyframe_scans_, keyframe_scans_static_projected_, keyframe_scans_dynamic_;
+    ScansPtr scans_knn_coexist_, scans_knn_diff_;
+    ScansPtr keyframe_scans_updated_, keyframe_scans_updated_strong_, keyframe_scans_pd_, keyframe_scans_strong_pd_,
+        keyframe_scans_strong_nd_, keyframe_scans_weak_nd_;
+
+    CloudPtr map_global_orig_, map_global_curr_, map_global_curr_static_, map_global_curr_dynamic_;
+    CloudPtr map_global_updated_, map_global_updated_strong_;
+    CloudPtr map_global_nd_, map_global_nd_strong_, map_global_nd_weak_;
+    CloudPtr map_global_pd_, map_global_pd_orig_, map_global_pd_strong_, map_global_pd_weak_;
+
+    void loadSessionInfo(std::string _sess_type, std::string _scan_dir, std::string _pose_path);   // Session.cpp:80-118
+    void setDownsampleSize(float _voxel_size);
+    void clearKeyframes(void);
+    void parseKeyframes(int _gap = 1);                                                             // :176-183
+    void parseKeyframes(std::pair<int, int> _range, int _gap = 1);                                 // :138-173
+    void parseKeyframesInROI(const std::vector<Matrix4d>& _roi_poses, int _gap = 1);               // :230-263
+    void loadKeyframes(void);                                                                      // :266-302
+    void precleaningKeyframes(float _radius);                                                      // :506-533
+    void mergeScansWithinGlobalCoord(void);                                                        // :186-202
+
+    void parseStaticScansViaProjection(void);
+    void parseUpdatedStaticScansViaProjection(void);
+    void parseUpdatedStrongStaticScansViaProjection(void);
+    void parsePDScansViaProjection(void);
+    void parseStrongPDScansViaProjection(void);
+    void parseWeakNDScansViaProjection(void);
+    void parseStrongNDScansViaProjection(void);
+    void parseScansViaProjection(const CloudPtr& _map, ScansPtr& _vec_to_store);                   // :348-360
+
+    void updateScansScanwise();                                                                    // :362-380
+    void extractLowDynPointsViaKnnDiff(const CloudPtr& _target_map);                               // :393-427
+    void extractHighDynPointsViaKnnDiff(const CloudPtr& _target_map);                              // :487-504
+    void constructGlobalNDMap();                                                                   // :430-435
+    void removeWeakNDMapPointsHavingStrongNDInNear();                                              // :452-484
+    void constructGlobalPDMap();                                                                   // :437-445
+    void revertStrongPDMapPointsHavingWeakPDInNear();                                              // :447-450 (empty in the reference)
+
+    // helpers shared with Removerter
+    CloudPtr wrap(ltm_cloud h) const { return std::make_shared<CloudH>(dev_->ctx, h); }
+    ScansPtr wrap_scans(ltm_scanset h) const { return std::make_shared<ScansH>(dev_->ctx, h); }
+    CloudPtr mergeScansToGlobal(const ScansPtr& scans) const;        // utility.cpp:170-192
+    CloudPtr octreeDownsampling(const CloudPtr& src, float leaf) const;   // utility.cpp:204-219
+    CloudPtr concat(const std::vector<CloudPtr>& parts) const;
+    void uploadPoses();
+};
+
+} // namespace ltremovert

@@ -1,0 +1,53 @@
+// utility.h -- host-side mirror of ltremovert/include/removert/utility.h for the MI355X build.
+//
+// Same role and names as the reference header, minus ROS/PCL/OpenCV: point type, PCD + pose-file I/O, and the
+// small helpers the Session/Removerter mirrors need.  All point arithmetic of the hot path lives behind the C ABI
+// (include/ltm.h); nothing in this directory projects, votes or searches neighbours on the CPU.
+#pragma once
+
+#include <cstddef>
+#include <cstdint>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "ltm.h"
+
+namespace ltremovert
+{
+
+// pcl::PointXYZI as stored on disk and on the device: 16 bytes (utility.h:90)
+struct PointType { float x, y, z, intensity; };
+using Cloud = std::vector<PointType>;
+
+const float kFlagNoPOINT = 10000.0f;       // utility.h:93
+const float kValidDiffUpperBound = 200.0f; // utility.h:94
+
+using Matrix4d = std::vector<double>;      // 16 doubles, row-major (pose text layout, Session.cpp:102-114)
+
+// utility.cpp:28-36
+std::vector<double> splitPoseLine(const std::string& _str_line, char _delimiter);
+// utility.cpp:222-236
+std::pair<int, int> resetRimgSize(const std::pair<float, float> _fov, const float _resize_ratio);
+
+// general 4x4 inverse in double (stands in for Eigen::Matrix4d::inverse(), Session.cpp:110, RosParamServer.cpp:30)
+bool inverse4x4(const double* m, double* inv);
+
+// ---- PCD v0.7 (pcl::io::loadPCDFile / savePCDFileBinary, Session.cpp:275, Removerter.cpp:232..1645)
+// reads ascii / binary / binary_compressed files with float x y z [intensity] fields (other fields are skipped)
+bool loadPCDFile(const std::string& path, Cloud& out, std::string* err = nullptr);
+// byte-compatible with pcl::io::savePCDFileBinary for PointXYZI.  `octree_layout`: the reference's clouds that come
+// out of octreeDownsampling carry width=1,height=n (utility.cpp:217-218); everything else is width=n,height=1.
+bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_layout, std::string* err = nullptr);
+
+// pcl::VoxelGrid as used by Session::loadKeyframes (Session.cpp:284-289), including the int32 overflow early-out
+// (output = input) that PCL takes for large extents.  Points inside a voxel are summed in input order.
+void voxelGridFilter(const Cloud& in, float leaf, Cloud& out);
+
+void fsmkdir(const std::string& _path);    // Removerter.cpp:6-10
+std::vector<std::string> listDirectorySorted(const std::string& dir, std::vector<std::string>* names);
+
+// throws std::runtime_error carrying ltm_last_error() when rc != LTM_OK
+void ltmCheck(ltm_ctx* ctx, int rc, const char* what);
+
+} // namespace ltremovert

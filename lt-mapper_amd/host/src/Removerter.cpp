@@ -1,0 +1,337 @@
+// Removerter.cpp -- mirror of ltremovert/src/Removerter.cpp over the C ABI (include/ltm.h).
+#include "removert/Removerter.h"
+
+#include <chrono>
+#include <iostream>
+#include <stdexcept>
+
+namespace ltremovert
+{
+
+#define LTM_INFO(msg) (std::cout << "\033[1;32m" << msg << "\033[0m" << std::endl)
+
+static std::shared_ptr<Device> make_device() { RosParamServer p; return std::make_shared<Device>(p); }
+
+Removerter::Removerter() : dev_(make_device()), central_sess_(dev_), query_sess_(dev_)
+{
+    // Removerter.cpp:26-50 : output directory protocol
+    if (save_pcd_directory_.substr(save_pcd_directory_.size() - 1, 1) != std::string("/")) save_pcd_directory_ = save_pcd_directory_ + "/";
+    fsmkdir(save_pcd_directory_);
+    updated_scans_save_dir_ = save_pcd_directory_ + "scans_updated";                fsmkdir(updated_scans_save_dir_);
+    updated_strong_scans_save_dir_ = save_pcd_directory_ + "scans_updated_strong";  fsmkdir(updated_strong_scans_save_dir_);
+    pd_scans_save_dir = save_pcd_directory_ + "scans_pd";                            fsmkdir(pd_scans_save_dir);
+    strong_pd_scans_save_dir = save_pcd_directory_ + "scans_pd_strong";              fsmkdir(strong_pd_scans_save_dir);
+    strong_nd_scans_save_dir = save_pcd_directory_ + "scans_nd_strong";              fsmkdir(strong_nd_scans_save_dir);
+    central_map_static_save_dir_ = save_pcd_directory_ + "map_static";               fsmkdir(central_map_static_save_dir_);
+    central_map_dynamic_save_dir_ = save_pcd_directory_ + "map_dynamic";             fsmkdir(central_map_dynamic_save_dir_);
+}
+
+Removerter::~Removerter() {}
+
+void Removerter::saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout)
+{
+    std::string err;
+    if (!savePCDFileBinary(file, cloud->download(), octree_layout, &err)) throw std::runtime_error(err);
+}
+
+void Removerter::loadSessionInfo(void)
+{
+    central_sess_.loadSessionInfo("Central", central_sess_scan_dir_, central_sess_pose_path_);
+    query_sess_.loadSessionInfo("Query", query_sess_scan_dir_, query_sess_pose_path_);
+    central_sess_.setDownsampleSize(kDownsampleVoxelSize);
+    query_sess_.setDownsampleSize(kDownsampleVoxelSize);
+}
+
+void Removerter::parseKeyframes(void)
+{
+    central_sess_.parseKeyframes({start_idx_, end_idx_}, keyframe_gap_);
+    query_sess_.parseKeyframesInROI(central_sess_.keyframe_poses_, keyframe_gap_);
+}
+
+void Removerter::loadKeyframes(void) { central_sess_.loadKeyframes(); query_sess_.loadKeyframes(); }
+
+void Removerter::precleaningKeyframes(float _radius)
+{
+    central_sess_.precleaningKeyframes(_radius);
+    query_sess_.precleaningKeyframes(_radius);
+}
+
+void Removerter::makeGlobalMap(Session& _sess)
+{
+    _sess.mergeScansWithinGlobalCoord();
+    LTM_INFO(" Map pointcloud (having redundant points) have: " << _sess.map_global_orig_->size() << " points.");
+    LTM_INFO(" Downsampling leaf size is " << kDownsampleVoxelSize << " m.");
+    _sess.map_global_curr_ = _sess.octreeDownsampling(_sess.map_global_orig_, kDownsampleVoxelSize);
+    _sess.map_global_orig_.reset();
+    if (kFlagSaveMapPointcloud) {
+        const std::string name = save_pcd_directory_ + "OriginalNoisy" + _sess.sess_type_ + "MapGlobal.pcd";
+        saveMap(name, _sess.map_global_curr_);
+        LTM_INFO(" The original pointcloud is saved (global coord): " << name);
+    }
+}
+void Removerter::makeGlobalMap(void) { makeGlobalMap(central_sess_); makeGlobalMap(query_sess_); }
+
+// Removerter.cpp:801-828 / :771-799 / :740-768 : one visibility vote + index-ascending split
+static std::pair<CloudPtr, CloudPtr> vote_partition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode)
+{
+    ltm_cloud kept = 0, flagged = 0;
+    ltmCheck(tgt.dev_->ctx, ltm_visibility_partition(tgt.dev_->ctx, map->h, scans->h, src.poses_h_, res, 0.1f, mode, &kept, &flagged, nullptr),
+             "ltm_visibility_partition");
+    return {tgt.wrap(kept), tgt.wrap(flagged)};
+}
+
+std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMap(const Session& _target_sess, const Session& _source_sess, float _res_alpha)
+{
+    curr_res_alpha_ = _res_alpha;
+    curr_rimg_shape_ = resetRimgSize(kFOV, _res_alpha);
+    LTM_INFO(" with resolution: x" << _res_alpha << " (" << 1.0 / _res_alpha << " deg/pixel)");
+    LTM_INFO(" -- The range image size is: [" << curr_rimg_shape_.first << ", " << curr_rimg_shape_.second << "].");
+    LTM_INFO(" -- The number of " << _target_sess.sess_type_ << " map points: " << _target_sess.map_global_curr_->size());
+    LTM_INFO(" -- ... starts cleaning ... ");
+    auto r = vote_partition(_target_sess, _target_sess.map_global_curr_, _source_sess.keyframe_scans_, _source_sess, _res_alpha, 0);
+    LTM_INFO(" -- The number of dynamic points: " << r.second->size());
+    LTM_INFO(" -- The number of static points: " << r.first->size());
+    return r;
+}
+std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMapForND(const Session& _target_sess, const Session& _source_sess, float _res_alpha)
+{
+    curr_res_alpha_ = _res_alpha;
+    curr_rimg_shape_ = resetRimgSize(kFOV, _res_alpha);
+    LTM_INFO(" -- The number of " << _target_sess.sess_type_ << " ND map points: " << _target_sess.map_global_nd_->size());
+    LTM_INFO(" -- ... starts to clean ambiguous ND ... ");
+    return vote_partition(_target_sess, _target_sess.map_global_nd_, _source_sess.keyframe_scans_static_projected_, _source_sess, _res_alpha, 1);
+}
+std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMapForPD(const Session& _target_sess, const Session& _source_sess, float _res_alpha)
+{
+    curr_res_alpha_ = _res_alpha;
+    curr_rimg_shape_ = resetRimgSize(kFOV, _res_alpha);
+    LTM_INFO(" -- The number of " << _target_sess.sess_type_ << " PD map points: " << _target_sess.map_global_pd_->size());
+    LTM_INFO(" -- ... starts to clean non-volume-extending PD ... ");
+    return vote_partition(_target_sess, _target_sess.map_global_pd_, _source_sess.keyframe_scans_static_projected_, _source_sess, _res_alpha, 0);
+}
+
+static CloudPtr append(const Session& s, const CloudPtr& a, const CloudPtr& b) { return a ? s.concat({a, b}) : s.concat({b}); }
+
+void Removerter::removeOnce(Session& t, const Session& src, float _res_alpha)      // Removerter.cpp:882-905
+{
+    LTM_INFO("\nSelf-removing starts ");
+    auto [static_tt, dynamic_tt] = partitionCurrentMap(t, src, _res_alpha);
+    t.map_global_curr_static_ = t.octreeDownsampling(static_tt, 0.05f);
+    LTM_INFO(" Current Static pointcloud have: " << t.map_global_curr_static_->size() << " points.");
+    t.map_global_curr_ = t.map_global_curr_static_;
+    t.map_global_curr_dynamic_ = t.octreeDownsampling(append(t, t.map_global_curr_dynamic_, dynamic_tt), 0.05f);
+    LTM_INFO(" Current Dynamic pointcloud have: " << t.map_global_curr_dynamic_->size() << " points.");
+}
+
+void Removerter::revertOnce(Session& t, const Session& src, float _res_alpha)      // Removerter.cpp:908-931
+{
+    LTM_INFO("\nSelf-reverting starts ");
+    auto [static_tt, dynamic_tt] = partitionCurrentMap(t, src, _res_alpha);
+    t.map_global_curr_dynamic_ = t.octreeDownsampling(dynamic_tt, 0.05f);
+    LTM_INFO(" Current Dynamic pointcloud have: " << t.map_global_curr_dynamic_->size() << " points.");
+    t.map_global_curr_ = t.map_global_curr_dynamic_;
+    t.map_global_curr_static_ = t.octreeDownsampling(append(t, t.map_global_curr_static_, static_tt), 0.05f);
+    LTM_INFO(" Current Static pointcloud have: " << t.map_global_curr_static_->size() << " points.");
+}
+
+void Removerter::resetCurrrentMapAsDynamic(Session& _sess, bool _as_dynamic)       // Removerter.cpp:714-737
+{
+    _sess.map_global_curr_ = _as_dynamic ? _sess.map_global_curr_dynamic_ : _sess.map_global_curr_static_;
+}
+void Removerter::resetCurrrentMapAsDynamic(Session& _sess) { resetCurrrentMapAsDynamic(_sess, true); }
+void Removerter::resetCurrrentMapAsStatic(Session& _sess) { resetCurrrentMapAsDynamic(_sess, false); }
+
+void Removerter::selfRemovert(Session& _sess, int _repeat = 1)                     // Removerter.cpp:1378-1393
+{
+    for (float _res : remove_resolution_list_) {
+        for (int i = 0; i < _repeat; i++) {
+            removeOnce(_sess, _sess, _res);
+            resetCurrrentMapAsDynamic(_sess);
+            revertOnce(_sess, _sess, 0.95 * _res);
+            resetCurrrentMapAsStatic(_sess);
+            removeOnce(_sess, _sess, _res);
+        }
+    }
+    saveCurrentStaticAndDynamicPointCloudGlobal(_sess, "_MVM");
+}
+
+void Removerter::saveCurrentStaticAndDynamicPointCloudGlobal(const Session& _sess, std::string _postfix)   // Removerter.cpp:318-338
+{
+    if (!kFlagSaveMapPointcloud) return;
+    const std::string r = std::to_string(curr_res_alpha_);
+    saveMap(central_map_dynamic_save_dir_ + "/" + _sess.sess_type_ + "DynamicMapMapsideGlobal" + _postfix + "ResX" + r + ".pcd", _sess.map_global_curr_dynamic_);
+    saveMap(central_map_static_save_dir_ + "/" + _sess.sess_type_ + "StaticMapMapsideGlobalResX" + _postfix + "ResX" + r + ".pcd", _sess.map_global_curr_static_);   // doubled "ResX": sic (:335)
+}
+
+void Removerter::removeHighDynamicPoints(void)                                     // Removerter.cpp:1580-1604
+{
+    if (gpu_use_self_removert_ && !remove_resolution_list_.empty()) {
+        selfRemovert(central_sess_, repeat_removert_iter_);
+        selfRemovert(query_sess_, repeat_removert_iter_);
+    } else {
+        removeOnce(central_sess_, central_sess_, 2.5);
+        removeOnce(query_sess_, query_sess_, 2.5);
+    }
+    if (gpu_skip_hd_knn_) return;
+    central_sess_.extractHighDynPointsViaKnnDiff(central_sess_.map_global_curr_static_);
+    query_sess_.extractHighDynPointsViaKnnDiff(query_sess_.map_global_curr_static_);
+    auto c = central_sess_.octreeDownsampling(central_sess_.mergeScansToGlobal(central_sess_.keyframe_scans_dynamic_), 0.05f);
+    auto q = query_sess_.octreeDownsampling(query_sess_.mergeScansToGlobal(query_sess_.keyframe_scans_dynamic_), 0.05f);
+    saveMap(save_pcd_directory_ + "central_sess_high_dyn.pcd", c);
+    saveMap(save_pcd_directory_ + "query_sess_high_dyn.pcd", q);
+    LTM_INFO(" high dynamic maps are saved. ");
+}
+
+void Removerter::iremoveOnceForND(Session& t, const Session& src, float _res_alpha)   // Removerter.cpp:831-854
+{
+    LTM_INFO("\nIdentifying Strong/Weak ND points starts ");
+    auto [static_tt, dynamic_tt] = partitionCurrentMapForND(t, src, _res_alpha);
+    t.map_global_nd_strong_ = t.octreeDownsampling(static_tt, 0.05f);
+    t.map_global_nd_ = t.map_global_nd_strong_;
+    t.map_global_nd_weak_ = t.octreeDownsampling(append(t, t.map_global_nd_weak_, dynamic_tt), 0.05f);
+}
+void Removerter::removeOnceForPD(Session& t, const Session& src, float _res_alpha)    // Removerter.cpp:856-880
+{
+    LTM_INFO("\nIdentifying Strong/Weak PD points starts ");
+    auto [static_tt, dynamic_tt] = partitionCurrentMapForPD(t, src, _res_alpha);
+    t.map_global_pd_strong_ = t.octreeDownsampling(static_tt, 0.05f);
+    t.map_global_pd_ = t.map_global_pd_strong_;
+    t.map_global_pd_weak_ = t.octreeDownsampling(append(t, t.map_global_pd_weak_, dynamic_tt), 0.05f);
+}
+void Removerter::filterStrongPD(Session& a, Session& b) { const float res = 2.5; for (int i = 0; i < 3; ++i) removeOnceForPD(a, b, res); }   // :1395-1401
+void Removerter::filterStrongND(Session& a, Session& b) { const float res = 2.5; for (int i = 0; i < 3; ++i) iremoveOnceForND(a, b, res); }  // :1403-1411
+
+void Removerter::detectLowDynamicPoints(void)                                      // Removerter.cpp:1413-1481
+{
+    LTM_INFO(" parse low dynamic diff via knn: " << central_sess_.sess_type_ << " to " << query_sess_.sess_type_);
+    central_sess_.extractLowDynPointsViaKnnDiff(query_sess_.map_global_curr_static_);
+    LTM_INFO(" parse low dynamic diff via knn: " << query_sess_.sess_type_ << " to " << central_sess_.sess_type_);
+    query_sess_.extractLowDynPointsViaKnnDiff(central_sess_.map_global_curr_static_);
+
+    central_sess_.constructGlobalNDMap();
+    filterStrongND(central_sess_, query_sess_);
+    central_sess_.removeWeakNDMapPointsHavingStrongNDInNear();
+
+    query_sess_.constructGlobalPDMap();
+    filterStrongPD(query_sess_, central_sess_);
+    query_sess_.revertStrongPDMapPointsHavingWeakPDInNear();
+
+    central_sess_.map_global_pd_ = query_sess_.map_global_pd_;
+    central_sess_.map_global_pd_orig_ = query_sess_.map_global_pd_orig_;
+    central_sess_.map_global_pd_strong_ = query_sess_.map_global_pd_strong_;
+
+    // :1443-1480 merged maps "for visual debug" (they also re-voxelise state that Step 3 reads)
+    Session& C = central_sess_; Session& Q = query_sess_;
+    union_q_ = Q.octreeDownsampling(Q.mergeScansToGlobal(Q.scans_knn_coexist_), 0.05f);
+    saveMap(save_pcd_directory_ + "union_map_queryside.pcd", union_q_);
+    union_c_ = C.octreeDownsampling(C.mergeScansToGlobal(C.scans_knn_coexist_), 0.05f);
+    saveMap(save_pcd_directory_ + "union_map_centralside.pcd", union_c_);
+    saveMap(save_pcd_directory_ + "pd_map.pcd", Q.octreeDownsampling(Q.mergeScansToGlobal(Q.scans_knn_diff_), 0.05f));
+    saveMap(save_pcd_directory_ + "nd_map.pcd", C.octreeDownsampling(C.mergeScansToGlobal(C.scans_knn_diff_), 0.05f));
+    LTM_INFO(" Union, PD, and ND map saved ");
+    if (C.map_global_nd_strong_->size() != 0) {
+        C.map_global_nd_strong_ = C.octreeDownsampling(C.map_global_nd_strong_, 0.05f);
+        saveMap(save_pcd_directory_ + "strong_nd_map.pcd", C.map_global_nd_strong_);
+    }
+    C.map_global_nd_weak_ = C.octreeDownsampling(C.map_global_nd_weak_, 0.05f);
+    saveMap(save_pcd_directory_ + "weak_nd_map.pcd", C.map_global_nd_weak_);
+    LTM_INFO(" Strong/Weak ND map saved ");
+    Q.map_global_pd_strong_ = Q.octreeDownsampling(Q.map_global_pd_strong_, 0.05f);
+    saveMap(save_pcd_directory_ + "strong_pd_map.pcd", Q.map_global_pd_strong_);
+    Q.map_global_pd_weak_ = Q.octreeDownsampling(Q.map_global_pd_weak_, 0.05f);
+    saveMap(save_pcd_directory_ + "weak_pd_map.pcd", Q.map_global_pd_weak_);
+    LTM_INFO(" Strong/Weak PD map saved ");
+}
+
+void Removerter::updateCurrentMap(void)                                            // Removerter.cpp:1483-1524
+{
+    Session& C = central_sess_;
+    // the union maps of :1489-1493 are recomputed from unchanged inputs in the reference: identical to :1445-1451
+    CloudPtr updated = C.concat({union_q_, union_c_, C.map_global_nd_weak_});
+    LTM_INFO(" -- The number of map points (updating ...): " << updated->size());
+    C.map_global_updated_strong_ = C.octreeDownsampling(C.concat({updated, C.map_global_pd_strong_}), 0.05f);
+    LTM_INFO(" -- The number of strong map points (updating ...): " << C.map_global_updated_strong_->size());
+    C.map_global_updated_ = C.octreeDownsampling(C.concat({updated, C.map_global_pd_orig_}), 0.05f);
+    LTM_INFO(" -- The number of map points (updating ...): " << C.map_global_updated_->size());
+    saveMap(save_pcd_directory_ + "updated_map.pcd", C.map_global_updated_);
+    saveMap(save_pcd_directory_ + "updated_map_strong.pcd", C.map_global_updated_strong_);
+    LTM_INFO(" -- The updated map is saved ");
+}
+
+void Removerter::parseStaticScansViaProjection(Session& _sess)
+{
+    LTM_INFO(" parse static scans via projection: " << _sess.sess_type_);
+    _sess.parseStaticScansViaProjection();
+}
+void Removerter::parseStaticScansViaProjection(void) { parseStaticScansViaProjection(central_sess_); parseStaticScansViaProjection(query_sess_); }
+void Removerter::updateScansScanwise() { updateScansScanwise(central_sess_); }
+void Removerter::updateScansScanwise(Session& _sess) { _sess.updateScansScanwise(); LTM_INFO(" final update scans: " << _sess.sess_type_); }
+void Removerter::parseUpdatedStaticScansViaProjection() { parseUpdatedStaticScansViaProjection(central_sess_); }
+void Removerter::parseUpdatedStaticScansViaProjection(Session& _sess)
+{
+    _sess.parseUpdatedStaticScansViaProjection();
+    _sess.parseUpdatedStrongStaticScansViaProjection();
+    LTM_INFO(" parse updated scans via projection: " << _sess.sess_type_);
+}
+void Removerter::parseLDScansViaProjection() { parseLDScansViaProjection(central_sess_); }
+void Removerter::parseLDScansViaProjection(Session& _sess)
+{
+    _sess.parsePDScansViaProjection();
+    _sess.parseStrongPDScansViaProjection();
+    _sess.parseWeakNDScansViaProjection();
+    if (!_sess.map_global_nd_strong_) { ltm_cloud h = 0; PointType none{}; ltmCheck(dev_->ctx, ltm_cloud_upload(dev_->ctx, &none, 0, 16, &h), "ltm_cloud_upload"); _sess.map_global_nd_strong_ = _sess.wrap(h); }
+    _sess.parseStrongNDScansViaProjection();
+    LTM_INFO(" parse LD scans via projection: " << _sess.sess_type_);
+}
+
+void Removerter::saveAllTypeOfScans() { saveUpdatedScans(central_sess_); saveLDScans(central_sess_); }
+void Removerter::saveLDScans(Session& _sess) { savePDScans(_sess); saveStrongPDScans(_sess); saveStrongNDScans(_sess); }
+void Removerter::saveUpdatedScans(Session& _sess)
+{
+    saveScans(_sess, _sess.keyframe_scans_updated_, updated_scans_save_dir_, true);           // went through octreeDownsampling (Session.cpp:375)
+    saveScans(_sess, _sess.keyframe_scans_updated_strong_, updated_strong_scans_save_dir_, false);
+}
+void Removerter::savePDScans(Session& _sess) { saveScans(_sess, _sess.keyframe_scans_pd_, pd_scans_save_dir, false); }
+void Removerter::saveStrongPDScans(Session& _sess) { saveScans(_sess, _sess.keyframe_scans_strong_pd_, strong_pd_scans_save_dir, false); }
+void Removerter::saveStrongNDScans(Session& _sess) { saveScans(_sess, _sess.keyframe_scans_strong_nd_, strong_nd_scans_save_dir, false); }
+
+void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout)   // Removerter.cpp:1637-1650
+{
+    const std::vector<Cloud> scans = _scans->download();
+    for (std::size_t idx_scan = 0; idx_scan < scans.size(); idx_scan++) {
+        const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(idx_scan);   // same file name as the input scan
+        std::string err;
+        if (!savePCDFileBinary(file_name, scans[idx_scan], octree_layout, &err)) throw std::runtime_error(err);
+    }
+    LTM_INFO(" " << scans.size() << " scans saved under " << _save_dir);
+}
+
+void Removerter::run(void)                                                         // Removerter.cpp:1653-1678
+{
+    using clk = std::chrono::steady_clock;
+    const auto t0 = clk::now();
+    // # Step 0: Preparations
+    loadSessionInfo();
+    parseKeyframes();
+    loadKeyframes();
+    precleaningKeyframes(2.5);
+    makeGlobalMap();
+    const auto t1 = clk::now();
+    // # Step 1: HD noise removal
+    removeHighDynamicPoints();
+    parseStaticScansViaProjection();
+    // # Step 2: LD change detection
+    detectLowDynamicPoints();
+    // # Step 3: LT-map
+    updateCurrentMap();
+    parseUpdatedStaticScansViaProjection();
+    parseLDScansViaProjection();
+    updateScansScanwise();
+    const auto t2 = clk::now();
+    saveAllTypeOfScans();
+    const auto t3 = clk::now();
+    auto s = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
+    LTM_INFO(" [timing] step0 (load+map) " << s(t0, t1) << " s, steps 1-3 " << s(t1, t2) << " s (includes map PCD writes), scan writes " << s(t2, t3) << " s");
+}
+
+} // namespace ltremovert

@@ -1,0 +1,270 @@
+// utility.cpp -- host-side helpers of the MI355X build of `removert` (mirror of ltremovert/src/utility.cpp without
+// ROS/PCL/OpenCV).  File formats only; no point arithmetic of the hot path happens here.
+#include "removert/utility.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <filesystem>
+#include <fstream>
+#include <limits>
+#include <sstream>
+#include <stdexcept>
+
+namespace fs = std::filesystem;
+
+namespace ltremovert
+{
+
+std::vector<double> splitPoseLine(const std::string& _str_line, char _delimiter)
+{
+    std::vector<double> parsed;
+    std::stringstream ss(_str_line);
+    std::string temp;
+    while (getline(ss, temp, _delimiter)) {
+        if (temp.empty()) continue;          // tolerate repeated blanks (std::stod would throw in the reference)
+        parsed.push_back(std::stod(temp));
+    }
+    return parsed;
+}
+
+std::pair<int, int> resetRimgSize(const std::pair<float, float> _fov, const float _resize_ratio)
+{
+    int rows = 0, cols = 0;
+    ltm_rimg_size(_fov.first, _fov.second, _resize_ratio, &rows, &cols);
+    return {rows, cols};
+}
+
+bool inverse4x4(const double* m, double* inv)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) { a[r][k] = m[4 * r + k]; a[r][4 + k] = (r == k) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) return false;
+        if (piv != col) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
+        const double d = a[col][col];
+        for (int k = 0; k < 8; ++k) a[col][k] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = a[r][4 + k];
+    return true;
+}
+
+void fsmkdir(const std::string& _path)
+{
+    if (!fs::is_directory(_path) || !fs::exists(_path)) fs::create_directories(_path);
+}
+
+std::vector<std::string> listDirectorySorted(const std::string& dir, std::vector<std::string>* names)
+{
+    std::vector<std::string> paths;
+    if (names) names->clear();
+    for (auto& e : fs::directory_iterator(dir)) {        // Session.cpp:87-92
+        paths.emplace_back(e.path().string());
+        if (names) names->emplace_back(e.path().filename().string());
+    }
+    std::sort(paths.begin(), paths.end());
+    if (names) std::sort(names->begin(), names->end());
+    return paths;
+}
+
+void ltmCheck(ltm_ctx* ctx, int rc, const char* what)
+{
+    if (rc == LTM_OK) return;
+    throw std::runtime_error(std::string(what) + " failed (" + std::to_string(rc) + "): " + (ctx ? ltm_last_error(ctx) : "no context"));
+}
+
+// ------------------------------------------------------------------------------------------ PCD
+namespace {
+
+struct Field { std::string name; int size = 4; char type = 'F'; int count = 1; int offset = 0; };
+
+// LZF decompression (the codec PCL's binary_compressed PCD files use)
+bool lzf_decompress(const unsigned char* in, size_t in_len, unsigned char* out, size_t out_len)
+{
+    const unsigned char* ip = in; const unsigned char* const in_end = in + in_len;
+    unsigned char* op = out; unsigned char* const out_end = out + out_len;
+    while (ip < in_end) {
+        unsigned ctrl = *ip++;
+        if (ctrl < 32) {                       // literal run of ctrl+1 bytes
+            ++ctrl;
+            if (op + ctrl > out_end || ip + ctrl > in_end) return false;
+            memcpy(op, ip, ctrl); op += ctrl; ip += ctrl;
+        } else {                               // back reference
+            unsigned len = ctrl >> 5;
+            if (ip >= in_end) return false;
+            if (len == 7) { len += *ip++; if (ip >= in_end) return false; }
+            const unsigned char* ref = op - ((ctrl & 0x1f) << 8) - 1 - *ip++;
+            len += 2;
+            if (ref < out || op + len > out_end) return false;
+            for (unsigned i = 0; i < len; ++i) op[i] = ref[i];   // may overlap
+            op += len;
+        }
+    }
+    return op == out_end;
+}
+
+float read_as_float(const unsigned char* p, const Field& f)
+{
+    switch (f.type) {
+    case 'F': if (f.size == 4) { float v; memcpy(&v, p, 4); return v; } else { double v; memcpy(&v, p, 8); return (float)v; }
+    case 'U': if (f.size == 1) return (float)*p; if (f.size == 2) { uint16_t v; memcpy(&v, p, 2); return (float)v; } { uint32_t v; memcpy(&v, p, 4); return (float)v; }
+    case 'I': if (f.size == 1) return (float)*(const int8_t*)p; if (f.size == 2) { int16_t v; memcpy(&v, p, 2); return (float)v; } { int32_t v; memcpy(&v, p, 4); return (float)v; }
+    }
+    return 0.0f;
+}
+
+} // namespace
+
+bool loadPCDFile(const std::string& path, Cloud& out, std::string* err)
+{
+    auto fail = [&](const std::string& m) { if (err) *err = path + ": " + m; return false; };
+    std::ifstream f(path, std::ios::binary);
+    if (!f) return fail("cannot open");
+    std::vector<Field> fields;
+    size_t n_points = 0, width = 0, height = 1;
+    std::string data_kind, line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        if (line.empty() || line[0] == '#') continue;
+        std::stringstream ss(line);
+        std::string key; ss >> key;
+        if (key == "FIELDS") { std::string n; while (ss >> n) { Field fd; fd.name = n; fields.push_back(fd); } }
+        else if (key == "SIZE") { for (auto& fd : fields) ss >> fd.size; }
+        else if (key == "TYPE") { for (auto& fd : fields) ss >> fd.type; }
+        else if (key == "COUNT") { for (auto& fd : fields) ss >> fd.count; }
+        else if (key == "WIDTH") ss >> width;
+        else if (key == "HEIGHT") ss >> height;
+        else if (key == "POINTS") ss >> n_points;
+        else if (key == "DATA") { ss >> data_kind; break; }
+    }
+    if (fields.empty() || data_kind.empty()) return fail("malformed header");
+    if (n_points == 0) n_points = width * height;
+    int stride = 0;
+    for (auto& fd : fields) { fd.offset = stride; stride += fd.size * fd.count; }
+    int ix = -1, iy = -1, iz = -1, ii = -1;
+    for (size_t k = 0; k < fields.size(); ++k) {
+        if (fields[k].name == "x") ix = (int)k; else if (fields[k].name == "y") iy = (int)k;
+        else if (fields[k].name == "z") iz = (int)k; else if (fields[k].name == "intensity") ii = (int)k;
+    }
+    if (ix < 0 || iy < 0 || iz < 0) return fail("no x/y/z fields");
+    out.assign(n_points, PointType{0, 0, 0, 0});
+    if (data_kind == "ascii") {
+        for (size_t p = 0; p < n_points; ++p) {
+            if (!std::getline(f, line)) return fail("truncated ascii data");
+            std::stringstream ss(line);
+            for (size_t k = 0; k < fields.size(); ++k)
+                for (int c = 0; c < fields[k].count; ++c) {
+                    double v; ss >> v;
+                    if (c) continue;
+                    if ((int)k == ix) out[p].x = (float)v; else if ((int)k == iy) out[p].y = (float)v;
+                    else if ((int)k == iz) out[p].z = (float)v; else if ((int)k == ii) out[p].intensity = (float)v;
+                }
+        }
+        return true;
+    }
+    std::vector<unsigned char> raw((size_t)stride * n_points);
+    if (data_kind == "binary") {
+        f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)raw.size());
+        if ((size_t)f.gcount() != raw.size()) return fail("truncated binary data");
+        for (size_t p = 0; p < n_points; ++p) {
+            const unsigned char* b = raw.data() + p * stride;
+            out[p].x = read_as_float(b + fields[ix].offset, fields[ix]);
+            out[p].y = read_as_float(b + fields[iy].offset, fields[iy]);
+            out[p].z = read_as_float(b + fields[iz].offset, fields[iz]);
+            if (ii >= 0) out[p].intensity = read_as_float(b + fields[ii].offset, fields[ii]);
+        }
+        return true;
+    }
+    if (data_kind == "binary_compressed") {
+        uint32_t csize = 0, usize = 0;
+        f.read(reinterpret_cast<char*>(&csize), 4); f.read(reinterpret_cast<char*>(&usize), 4);
+        if (!f || usize != raw.size()) return fail("bad compressed sizes");
+        std::vector<unsigned char> comp(csize);
+        f.read(reinterpret_cast<char*>(comp.data()), csize);
+        if ((size_t)f.gcount() != csize) return fail("truncated compressed data");
+        if (!lzf_decompress(comp.data(), csize, raw.data(), usize)) return fail("LZF decode failed");
+        // compressed payload is structure-of-arrays: all of field 0, then all of field 1, ...
+        size_t base = 0;
+        for (size_t k = 0; k < fields.size(); ++k) {
+            const size_t fsz = (size_t)fields[k].size * fields[k].count;
+            if ((int)k == ix || (int)k == iy || (int)k == iz || (int)k == ii)
+                for (size_t p = 0; p < n_points; ++p) {
+                    const float v = read_as_float(raw.data() + base + p * fsz, fields[k]);
+                    if ((int)k == ix) out[p].x = v; else if ((int)k == iy) out[p].y = v; else if ((int)k == iz) out[p].z = v; else out[p].intensity = v;
+                }
+            base += fsz * n_points;
+        }
+        return true;
+    }
+    return fail("unsupported DATA kind " + data_kind);
+}
+
+bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_layout, std::string* err)
+{
+    std::ofstream f(path, std::ios::binary | std::ios::trunc);
+    if (!f) { if (err) *err = path + ": cannot open for writing"; return false; }
+    const size_t n = cloud.size();
+    const size_t width = octree_layout ? 1 : n, height = octree_layout ? n : 1;
+    std::ostringstream h;   // the header pcl::PCDWriter::generateHeader emits for PointXYZI (padding fields stripped)
+    h << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+      << "WIDTH " << width << "\nHEIGHT " << height << "\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA binary\n";
+    const std::string hs = h.str();
+    f.write(hs.data(), (std::streamsize)hs.size());
+    if (n) f.write(reinterpret_cast<const char*>(cloud.data()), (std::streamsize)(n * sizeof(PointType)));
+    if (!f) { if (err) *err = path + ": write failed"; return false; }
+    return true;
+}
+
+// pcl::VoxelGrid::applyFilter (PCL 1.10, from its published behaviour): inverse leaf in float, bounding box from
+// getMinMax3D, dx*dy*dz > INT32_MAX => "Leaf size is too small" and output = input; else centroids ordered by linear
+// voxel index.  The reference sorts (voxel, point) pairs with an unstable std::sort, so the summation order inside a
+// voxel is unspecified there; here it is input order.  "parity unpinned" (DESIGN.md).
+void voxelGridFilter(const Cloud& in, float leaf, Cloud& out)
+{
+    if (in.empty()) { out.clear(); return; }
+    const float inv = 1.0f / leaf;
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float mx[3] = {-mn[0], -mn[1], -mn[2]};
+    for (const PointType& p : in) {
+        const float c[3] = {p.x, p.y, p.z};
+        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
+    }
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)std::numeric_limits<int32_t>::max()) { out = in; return; }
+    int minb[3], divb[3];
+    for (int d = 0; d < 3; ++d) {
+        minb[d] = (int)std::floor(mn[d] * inv);
+        divb[d] = (int)std::floor(mx[d] * inv) - minb[d] + 1;
+    }
+    std::vector<std::pair<uint32_t, uint32_t>> keyed(in.size());
+    for (size_t i = 0; i < in.size(); ++i) {
+        const int i0 = (int)std::floor(in[i].x * inv) - minb[0], i1 = (int)std::floor(in[i].y * inv) - minb[1], i2 = (int)std::floor(in[i].z * inv) - minb[2];
+        keyed[i] = {(uint32_t)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]), (uint32_t)i};
+    }
+    std::sort(keyed.begin(), keyed.end());
+    Cloud res;
+    size_t a = 0;
+    while (a < keyed.size()) {
+        size_t b = a;
+        float sx = 0, sy = 0, sz = 0, si = 0;
+        while (b < keyed.size() && keyed[b].first == keyed[a].first) {
+            const PointType& p = in[keyed[b].second];
+            sx += p.x; sy += p.y; sz += p.z; si += p.intensity;
+            ++b;
+        }
+        const float n = (float)(b - a);
+        res.push_back(PointType{sx / n, sy / n, sz / n, si / n});
+        a = b;
+    }
+    out.swap(res);
+}
+
+} // namespace ltremovert

@@ -1,0 +1,175 @@
+"""File-protocol drop-in test: the ROS-free `ltm_run` (C++ mirror of Removerter/Session over the C ABI) reads the reference's
+on-disk inputs (flat PCD scan directories, pose text files, params_ltmapper.yaml keys) and writes the reference's output
+tree.  Every output file is compared with the CPU oracle run on the same loaded data."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_clouds_equal
+
+pytestmark = pytest.mark.gpu
+
+HDR = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
+       "WIDTH {w}\nHEIGHT {h}\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
+
+
+def write_pcd(path, pts, ascii_=False):
+    n = len(pts)
+    with open(path, "wb") as f:
+        if ascii_:
+            f.write(HDR.format(w=n, h=1, n=n).replace("DATA binary", "DATA ascii").encode())
+            for p in pts:
+                f.write((" ".join(repr(float(v)) for v in p) + "\n").encode())
+        else:
+            f.write(HDR.format(w=n, h=1, n=n).encode())
+            f.write(np.ascontiguousarray(pts, dtype=np.float32).tobytes())
+
+
+def read_pcd(path):
+    raw = open(path, "rb").read()
+    i = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
+    hdr = raw[:i].decode()
+    n = int([l for l in hdr.splitlines() if l.startswith("POINTS")][0].split()[1])
+    return hdr, np.frombuffer(raw[i:], dtype=np.float32).reshape(n, 4)
+
+
+def voxel_grid(pts, leaf):
+    """pcl::VoxelGrid as restated in host/src/utility.cpp (float arithmetic, input-order sums, int32 overflow early-out)"""
+    pts = np.asarray(pts, np.float32)
+    inv = np.float32(1.0) / np.float32(leaf)
+    mn, mx = pts[:, :3].min(0), pts[:, :3].max(0)
+    d = ((mx - mn) * inv).astype(np.int64) + 1
+    if int(d[0]) * int(d[1]) * int(d[2]) > 2 ** 31 - 1:
+        return pts
+    minb = np.floor(mn * inv).astype(np.int64)
+    divb = np.floor(mx * inv).astype(np.int64) - minb + 1
+    ijk = np.floor(pts[:, :3] * inv).astype(np.int64) - minb
+    key = ijk[:, 0] + ijk[:, 1] * divb[0] + ijk[:, 2] * divb[0] * divb[1]
+    order = np.argsort(key, kind="stable")
+    out = []
+    a = 0
+    ks = key[order]
+    while a < len(order):
+        b = a
+        s = np.zeros(4, np.float32)
+        while b < len(order) and ks[b] == ks[a]:
+            s = (s + pts[order[b]]).astype(np.float32)
+            b += 1
+        out.append(s / np.float32(b - a))
+        a = b
+    return np.array(out, np.float32)
+
+
+def parse_keyframes(n, start, end):       # Session.cpp:138-173 incl. the double increment (quirk Q6), gap 1
+    out, i = [], 0
+    while i < n:
+        if i > end or i < start:
+            i += 2
+            continue
+        out.append(i)
+        i += 1
+    return out
+
+
+def test_ltm_run_file_protocol(tmp_path, orc):
+    from tools import synth
+    exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
+    assert os.path.exists(exe), "build the host mirror first (make host)"
+    n_kf = 40
+    sess = [synth.to_numpy(synth.make_session(s, n_kf, "tiny")) for s in (1, 2)]
+    dirs = []
+    for tag, S in zip(("01", "02"), sess):
+        d = tmp_path / tag / "Scans"
+        d.mkdir(parents=True)
+        for k in range(n_kf):
+            a, b = int(S["offsets"][k]), int(S["offsets"][k + 1])
+            write_pcd(str(d / S["names"][k]), S["scans"][a:b], ascii_=(k == 3))
+        with open(tmp_path / tag / "poses.txt", "w") as f:
+            for k in range(n_kf):
+                f.write(" ".join(repr(float(v)) for v in S["poses"][k][:12]) + "\n")
+        dirs.append(d)
+    outdir = tmp_path / "out"
+    start_idx, end_idx = 11, 39         # odd start: the first in-range scan is skipped in the reference (Q6)
+    yaml = tmp_path / "params.yaml"
+    yaml.write_text(f"""removert:
+  isScanFileKITTIFormat: false
+  saveMapPCD: true   # also writes OriginalNoisy*MapGlobal.pcd
+  save_pcd_directory: "{outdir}"   # no trailing slash on purpose
+  central_sess_scan_dir: "{dirs[0]}/"
+  central_sess_pose_path: "{tmp_path}/01/poses.txt"
+  query_sess_scan_dir: "{dirs[1]}/"
+  query_sess_pose_path: "{tmp_path}/02/poses.txt"
+  sequence_vfov: 50
+  sequence_hfov: 360
+  ExtrinsicLiDARtoPoseBase: [1.0, 0.0, 0.0, 0.0,
+                             0.0, 1.0, 0.0, 0.0,
+                             0.0, 0.0, 1.0, 0.0,
+                             0.0, 0.0, 0.0, 1.0]
+  use_keyframe_gap: true
+  keyframe_gap: 1
+  start_idx: {start_idx}
+  end_idx: {end_idx}
+  remove_resolution_list: [2.5]
+  downsample_voxel_size: 0.05
+  num_nn_points_within: 2
+  dist_nn_points_within: 0.01
+  num_omp_cores: 16
+""")
+    r = subprocess.run([exe, str(yaml)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+    # ---- the same Step 0 on the host side of the oracle
+    c_kf = parse_keyframes(n_kf, start_idx, end_idx)
+    assert c_kf[0] == 12, "quirk Q6: an odd start_idx skips the first in-range scan"
+    c_pos = sess[0]["poses"].reshape(-1, 4, 4)[c_kf][:, :3, 3]
+    q_pos = sess[1]["poses"].reshape(-1, 4, 4)[:, :3, 3]
+    q_kf = [k for k in range(n_kf) if np.sqrt(((c_pos - q_pos[k]) ** 2).sum(1)).min() <= 10.0]
+    assert len(q_kf) > 3
+
+    def load(S, kfs):
+        pts, off = [], [0]
+        for k in kfs:
+            a, b = int(S["offsets"][k]), int(S["offsets"][k + 1])
+            raw = S["scans"][a:b]
+            if k == 3:   # went through the ascii writer: repr() round-trips float32 exactly
+                raw = np.array([[np.float32(float(repr(float(v)))) for v in p] for p in raw], np.float32)
+            p = orc.preclean(voxel_grid(raw, 0.05), 2.5)
+            pts.append(p); off.append(off[-1] + len(p))
+        poses = S["poses"].reshape(-1, 16)[kfs].copy()
+        # the pose file holds 12 numbers per line; the inverse is whatever the host computes (Gauss-Jordan here, Eigen in the reference)
+        inv = np.array([np.linalg.inv(p.reshape(4, 4)).reshape(16) for p in poses])
+        return dict(scans=np.concatenate(pts), offsets=np.array(off, np.uint64), poses=poses, inv=inv)
+
+    C, Q = load(sess[0], c_kf), load(sess[1], q_kf)
+    ref = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C, Q)
+
+    def close(a, b, what):   # inverse poses differ in the last bits between numpy and the host => XYZ tolerance of the north star
+        assert_clouds_equal(a, b, what, xyz_tol=1e-4)
+
+    files = {"OriginalNoisyCentralMapGlobal": "OriginalNoisyCentralMapGlobal", "OriginalNoisyQueryMapGlobal": "OriginalNoisyQueryMapGlobal",
+             "central_sess_high_dyn": "central_sess_high_dyn", "query_sess_high_dyn": "query_sess_high_dyn",
+             "union_map_queryside": "union_map_queryside", "union_map_centralside": "union_map_centralside", "pd_map": "pd_map", "nd_map": "nd_map",
+             "strong_nd_map": "strong_nd_map", "weak_nd_map": "weak_nd_map", "strong_pd_map": "strong_pd_map", "weak_pd_map": "weak_pd_map",
+             "updated_map": "updated_map", "updated_map_strong": "updated_map_strong"}
+    for fname, key in files.items():
+        want = ref.cloud(key)
+        path = outdir / (fname + ".pcd")
+        if want is None:
+            assert not path.exists()
+            continue
+        hdr, got = read_pcd(str(path))
+        assert hdr == HDR.format(w=1, h=len(got), n=len(got)), f"{fname}: header is not what pcl::io::savePCDFileBinary writes"
+        close(got, want, fname)
+    for d, key, octree in (("scans_updated", "scans_updated", True), ("scans_updated_strong", "scans_updated_strong", False), ("scans_pd", "scans_pd", False),
+                           ("scans_pd_strong", "scans_pd_strong", False), ("scans_nd_strong", "scans_nd_strong", False)):
+        w_pts, w_off = ref.scanset(key)
+        names = sorted(os.listdir(outdir / d))
+        assert names == [sess[0]["names"][k] for k in c_kf], f"{d}: one file per central keyframe, named like the input scan"
+        for j, nm in enumerate(names):
+            hdr, got = read_pcd(str(outdir / d / nm))
+            n = len(got)
+            assert hdr == (HDR.format(w=1, h=n, n=n) if octree else HDR.format(w=n, h=1, n=n))
+            close(got, w_pts[int(w_off[j]):int(w_off[j + 1])], f"{d}/{nm}")
+    assert (outdir / "map_static").is_dir() and (outdir / "map_dynamic").is_dir()

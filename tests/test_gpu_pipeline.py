@@ -76,3 +76,28 @@ def test_pipeline_other_knn_params_and_extrinsic(ltm, orc, small_pair):
     rmv.run()
     _compare(rmv, ref)
     ctx.close()
+
+
+def test_sharded_ops_world1_rccl_plumbing(ltm, orc, small_pair):
+    """dist.ShardedOps with a real RCCL process group of size 1: exercises the uint8 label all-reduce, the device-array views
+    and the all-gather reassembly on the GPU; result must equal the plain single-GPU pipeline (= the oracle)."""
+    import os
+    import socket
+    import torch
+    import torch.distributed as dist
+    from ltmapper_amd.dist import ShardedOps
+    from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        C, Q = small_pair
+        ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+        sessions = [Session(n, ctx.upload_scans(S["scans"], S["offsets"]), ctx.poses(S["poses"], S["inv"])) for n, S in (("Central", C), ("Query", Q))]
+        rmv = Removerter(ShardedOps(HipOps(ctx), dist, 0, 1), Params(), *sessions)
+        rmv.run()
+        _compare(rmv, orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C, Q))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
