@@ -123,6 +123,7 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_read()
+    cull_surv, cull_pts = ctx.cull_stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -163,6 +164,7 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+            "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
             "synth_generation_s": round(t_gen, 2),
         }
         print(json.dumps(out))

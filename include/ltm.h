@@ -146,6 +146,12 @@ void ltm_rimg_size(float vfov, float hfov, float res_alpha, int* rows, int* cols
  * division by the FOV constants) against plain IEEE division over all 2^32 binary32 inputs:
  * mismatches3 = {rad2deg, /vfov, /hfov}; the fast forms are used only when all three are zero. */
 int ltm_debug_selfcheck(ltm_ctx*, uint64_t* mismatches3, int* fast_math_enabled);
+/* checks the bounded-error projection that the range-culled vote kernel uses to decide which points need the exact
+ * arithmetic: counts points (host xyz, n*3 floats; global frame if inv_pose16 is given, else local) whose exact pixel /
+ * range fall outside its candidate set / bounds.  Must be 0. */
+int ltm_debug_cull_check(ltm_ctx*, const float* xyz, size_t n, const double* inv_pose16_or_null, float res_alpha, uint64_t* violations);
+/* diagnostic counters of the range-culled vote kernel since the last reset: points tested / points that needed the exact path */
+int ltm_debug_cull_stats(ltm_ctx*, uint64_t* survivors, uint64_t* points, int reset);
 
 /* ----------------------------------------------------------- measurement ---- */
 /* Per-kernel-class HIP-event timing on the context's stream.  Classes: "vote_map", "vote_scan",

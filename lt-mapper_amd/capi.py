@@ -72,6 +72,8 @@ SIGNATURES = {
     "ltm_debug_range_image": (_i, [_vp, _u64, _vp, _vp, _f, _vp, _vp]),
     "ltm_debug_project": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
     "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
+    "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),
+    "ltm_debug_cull_stats": (_i, [_vp, _pu64, _pu64, _i]),
     "ltm_rimg_size": (None, [_f, _f, _f, C.POINTER(_i), C.POINTER(_i)]),
     "ltm_profile_enable": (_i, [_vp, _i]),
     "ltm_profile_reset": (_i, [_vp]),
@@ -271,6 +273,18 @@ class Context:
         rc = np.empty((a.shape[0], 2), dtype=np.int32)
         self._ck(self.lib.ltm_debug_project(self.h, a.ctypes.data, a.shape[0], alpha, sph.ctypes.data, rc.ctypes.data))
         return sph, rc
+
+    def cull_check(self, xyz, alpha, inv_pose=None):
+        a = np.ascontiguousarray(xyz, dtype=np.float32).reshape(-1, 3)
+        t = None if inv_pose is None else _mat16(inv_pose)
+        v = _u64()
+        self._ck(self.lib.ltm_debug_cull_check(self.h, a.ctypes.data, a.shape[0], None if t is None else t.ctypes.data, alpha, C.byref(v)))
+        return int(v.value)
+
+    def cull_stats(self, reset=True):
+        a, b = _u64(), _u64()
+        self._ck(self.lib.ltm_debug_cull_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
 
     def selfcheck(self):
         m = (C.c_uint64 * 3)()

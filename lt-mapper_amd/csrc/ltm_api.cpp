@@ -94,7 +94,7 @@ struct Pool {
 
 struct Cloud { float4* d = nullptr; size_t n = 0; };
 struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> off; uint64_t* off_dev = nullptr; size_t nkf() const { return off.size() - 1; } };
-struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; };
+struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; float* approx_dev = nullptr; };
 
 struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0; };
 struct Pending { int cls; hipEvent_t a, b; };
@@ -266,6 +266,34 @@ bool inverse4x4(const double* m, double* inv)
     return true;
 }
 
+// Bounded-error form of "base2lidar * inverse pose" for the cull test: p_local ~= A (p - c), c = sensor position in
+// the map frame as a float-float pair.  out[16] = {A row-major, c_hi, c_lo, ok}.
+void approx_pose(const double* b2l16, const double* inv16, float* out)
+{
+    double T[12];
+    for (int r = 0; r < 3; ++r)
+        for (int k = 0; k < 4; ++k) {
+            double v = (k == 3) ? b2l16[4 * r + 3] : 0.0;
+            for (int j = 0; j < 3; ++j) v += b2l16[4 * r + j] * inv16[4 * j + k];
+            T[4 * r + k] = v;
+        }
+    const double a = T[0], b = T[1], c3 = T[2], d = T[4], e = T[5], f = T[6], g = T[8], h = T[9], i = T[10];
+    const double det = a * (e * i - f * h) - b * (d * i - f * g) + c3 * (d * h - e * g);
+    for (int k = 0; k < 16; ++k) out[k] = 0.0f;
+    if (!(std::fabs(det) > 1e-12) || !std::isfinite(det)) return;          // ok stays 0: every point takes the exact path
+    const double inv[9] = {(e * i - f * h) / det, (c3 * h - b * i) / det, (b * f - c3 * e) / det,
+                           (f * g - d * i) / det, (a * i - c3 * g) / det, (c3 * d - a * f) / det,
+                           (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
+    const double t[3] = {T[3], T[7], T[11]};
+    for (int r = 0; r < 3; ++r) {
+        const double cr = -(inv[3 * r] * t[0] + inv[3 * r + 1] * t[1] + inv[3 * r + 2] * t[2]);
+        out[9 + r] = (float)cr;
+        out[12 + r] = (float)(cr - (double)out[9 + r]);
+        for (int k = 0; k < 3; ++k) out[3 * r + k] = (float)T[4 * r + k];
+    }
+    out[15] = 1.0f;
+}
+
 // utility.cpp:222-236 resetRimgSize
 Geom geom_for(const ltm_ctx* c, float alpha)
 {
@@ -341,7 +369,8 @@ void do_vote(ltm_ctx* c, const Cloud& map, const ScanSet& ss, const Poses& ps, s
         }
         {
             ProfScope p(c, "vote_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
-            LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, kb, nb, c->B2L, c->b2l_identity, g, map_img.as<uint64_t>(), c->stream));
+            LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img.as<uint32_t>(),
+                                          thr, mode, map_img.as<uint64_t>(), c->stream));
         }
         {
             ProfScope p(c, "vote_compare", (double)(nb * npx), (double)(nb * npx) * 12 + (double)nb * map.n / 8.0);
@@ -579,6 +608,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         return LTM_E_DEVICE;
     }
     if (const char* v = getenv("LTM_MAP_KERNEL")) set_map_kernel_variant(atoi(v));   // A/B switch for profiling
+    if (const char* v = getenv("LTM_VOTE_CULL")) set_vote_cull(atoi(v));
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's
     // constants; they are enabled only if they reproduce the exact IEEE results for every input.
     {
@@ -829,6 +859,12 @@ int ltm_poses_create(ltm_ctx* c, size_t n, const double* poses, const double* in
         p.inv_dev = reinterpret_cast<double*>(c->pool.alloc(b.size() * 8));
         h2d(c, p.pose_dev, a.data(), a.size() * 8);
         h2d(c, p.inv_dev, b.data(), b.size() * 8);
+        std::vector<float> ap(16 * std::max<size_t>(n, 1), 0.0f);
+        double b2l16[16] = {0};
+        memcpy(b2l16, c->B2L.m, 12 * sizeof(double)); b2l16[15] = 1.0;
+        for (size_t i = 0; i < n; ++i) approx_pose(b2l16, &p.inv[16 * i], &ap[16 * i]);
+        p.approx_dev = reinterpret_cast<float*>(c->pool.alloc(ap.size() * 4));
+        h2d(c, p.approx_dev, ap.data(), ap.size() * 4);
         const uint64_t h = c->next_handle++;
         c->poses[h] = std::move(p);
         *out = h;
@@ -836,7 +872,7 @@ int ltm_poses_create(ltm_ctx* c, size_t n, const double* poses, const double* in
 }
 int ltm_poses_free(ltm_ctx* c, ltm_poses h)
 {
-    return guarded(c, [&] { Poses& p = get_poses(c, h); c->pool.free(p.pose_dev); c->pool.free(p.inv_dev); c->poses.erase(h); });
+    return guarded(c, [&] { Poses& p = get_poses(c, h); c->pool.free(p.pose_dev); c->pool.free(p.inv_dev); c->pool.free(p.approx_dev); c->poses.erase(h); });
 }
 
 // ------------------------------------------------------------------------------- stages
@@ -1117,6 +1153,43 @@ int ltm_debug_project(ltm_ctx* c, const float* xyz, size_t n, float alpha, float
         LTM_HIP(debug_project(in.as<float>(), n, g, o1.as<float>(), o2.as<int32_t>(), c->stream));
         d2h(c, sph, o1.p, n * 12);
         d2h(c, rc, o2.p, n * 8);
+    });
+}
+
+int ltm_debug_cull_check(ltm_ctx* c, const float* xyz, size_t n, const double* inv_pose16, float alpha, uint64_t* violations)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE((xyz && violations) || n == 0, "null argument");
+        if (violations) *violations = 0;
+        if (!n) return;
+        const Geom g = geom_for(c, alpha);
+        DevBuf in(c, n * 12), bad(c, 8), apd(c, 64);
+        h2d(c, in.p, xyz, n * 12);
+        LTM_HIP(hipMemsetAsync(bad.p, 0, 8, c->stream));
+        HostMat34 T{};
+        if (inv_pose16) {
+            LTM_REQUIRE(c->b2l_identity, "cull check with a pose needs an identity extrinsic");
+            float ap[16];
+            double b2l16[16] = {0};
+            memcpy(b2l16, c->B2L.m, 12 * sizeof(double)); b2l16[15] = 1.0;
+            approx_pose(b2l16, inv_pose16, ap);
+            h2d(c, apd.p, ap, 64);
+            T = to34(inv_pose16);
+        }
+        LTM_HIP(cull_check(in.as<float>(), n, inv_pose16 ? &T : nullptr, apd.as<float>(), g, bad.as<unsigned long long>(), c->stream));
+        unsigned long long v = 0;
+        d2h(c, &v, bad.p, 8);
+        *violations = v;
+    });
+}
+
+int ltm_debug_cull_stats(ltm_ctx* c, uint64_t* survivors, uint64_t* points, int reset)
+{
+    return guarded(c, [&] {
+        unsigned long long v[2] = {0, 0};
+        LTM_HIP(cull_stats(v, reset, c->stream));
+        if (survivors) *survivors = v[0];
+        if (points) *points = v[1];
     });
 }
 

@@ -182,6 +182,31 @@ __device__ __forceinline__ int pixel_index(const RimgGeom& g, float az, float el
     return row * g.cols + col;
 }
 
+// ---- bounded-error fast forms, used ONLY to decide which points need the exact arithmetic (never for a result) ----
+// atan(a), 0 <= a <= 1: a*P(a^2), degree-5 minimax fit; |error| <= 1.8e-6 rad including binary32 evaluation
+// (fit + bound: DESIGN.md 4.4; checked on the device by ltm_debug_cull_check).
+__device__ __forceinline__ float atan_unit_approx(float a)
+{
+    const float t = a * a;
+    float p = -1.171913743e-02f;
+    p = __builtin_fmaf(p, t, 5.264735594e-02f);
+    p = __builtin_fmaf(p, t, -1.164264902e-01f);
+    p = __builtin_fmaf(p, t, 1.935403794e-01f);
+    p = __builtin_fmaf(p, t, -3.326228261e-01f);
+    p = __builtin_fmaf(p, t, 9.999772310e-01f);
+    return a * p;
+}
+// atan2 for finite, non-zero y and x; |error| <= 3e-6 rad
+__device__ __forceinline__ float atan2_approx(float y, float x)
+{
+    const float ax = fabsf(x), ay = fabsf(y);
+    const float mx = fmaxf(ax, ay), mn = fminf(ax, ay);
+    float r = atan_unit_approx(mn * __builtin_amdgcn_rcpf(mx));
+    r = (ay > ax) ? (1.57079632679f - r) : r;
+    r = (x < 0.0f) ? (3.14159265359f - r) : r;
+    return (y < 0.0f) ? -r : r;
+}
+
 // PCL transformPointCloud<PointXYZI,double>: (float)(((m0*x + m1*y) + m2*z) + m3) per row, double math.
 struct Mat34 { double m[12]; };
 

@@ -33,6 +33,14 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
 hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
                             uint8_t* labels, hipStream_t s);
+// vote form of the above: mode 0 may cull points that provably cannot be flagged (needs the finished scan images)
+// approx_poses_dev: 16 floats per keyframe {A[9], c_hi[3], c_lo[3], ok} with p_local ~= A (p - c) (see xform_approx)
+hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
+                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, float thr, int mode, uint64_t* map_img,
+                                 hipStream_t s);
+void set_vote_cull(int v);
+hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s);   // {survivors, points} since the last reset
+hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const float* approx_pose_dev, Geom g, unsigned long long* bad_dev, hipStream_t s);
 void set_map_kernel_variant(int v);   // 0 = per-point global atomics, 1 = LDS pre-reduction (default)
 // generic single image with up to two explicit transforms (debug / parity)
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,

@@ -207,6 +207,239 @@ k_map_rimg_lds(const float4* __restrict__ map, size_t M, const double* __restric
     }
 }
 
+hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb, HostMat34 b2l,
+                            int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
+
+// ---------------------------------------------------------------------------------------------------------------
+// Range-culled vote kernel (mode 0: diff = scan - map).  A map point P can influence the labels only if it could be
+// flagged in its own pixel, i.e. fl(scan[px(P)] - r_P) > thr: if it cannot, then (a) it is not flagged itself, and
+// (b) removing it from the arg-min competition changes nothing -- whoever wins instead is at least as far, so that
+// pixel stays unflagged; and any flagged winner is nearer than P, so P never displaces it.  The scan images are
+// complete before this kernel runs, so the test needs no inter-workgroup ordering.
+// Phase 1 (every point): exact fp64 transform, then a bounded-error projection (atan2 within 3e-6 rad, native
+// sqrt) gives the pixel up to +-kCullEpsPx; the point survives if for ANY candidate pixel the scan range exceeds a
+// lower bound of its range by more than thr minus a margin (or if it is in a domain the fast forms do not cover).
+// Survivors (typically 10-20 %) are queued in LDS.  Phase 2: survivors get the exact arithmetic and the same LDS
+// pre-reduction as k_map_rimg_lds.  Labels are identical to the un-culled path (parity tests); the map image is
+// not (culled points are absent), which is why ltm_debug_range_image / reprojection / mode 1 use k_map_rimg_lds.
+static constexpr float kCullEpsPx = 3.0e-3f;
+
+struct CullCand { int r0, r1, c0, c1; float r_lo; bool unusual; };
+
+// p' = A (p - c): the inverse pose (composed with base->lidar) rewritten around the sensor position c so that the
+// subtraction happens between nearby numbers; c is carried as a float-float pair.  Relative error of p' <= 5e-7
+// (binary32 roundings only), i.e. <= 5e-7 rad of direction error at any range.  16 floats per keyframe.
+__device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, float4 p4, bool& ok)
+{
+    const float dx = (p4.x - ap[9]) - ap[12], dy = (p4.y - ap[10]) - ap[13], dz = (p4.z - ap[11]) - ap[14];
+    ok = ap[15] != 0.0f;
+    float3 o;
+    o.x = __builtin_fmaf(ap[2], dz, __builtin_fmaf(ap[1], dy, ap[0] * dx));
+    o.y = __builtin_fmaf(ap[5], dz, __builtin_fmaf(ap[4], dy, ap[3] * dx));
+    o.z = __builtin_fmaf(ap[8], dz, __builtin_fmaf(ap[7], dy, ap[6] * dx));
+    return o;
+}
+
+__device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale)
+{
+    CullCand cc;
+    const uint32_t ix = f2u(p.x) & 0x7fffffffu, iy = f2u(p.y) & 0x7fffffffu, iz = f2u(p.z) & 0x7fffffffu;
+    const float xy2 = __builtin_fmaf(p.x, p.x, p.y * p.y);
+    const float rxy = __builtin_amdgcn_sqrtf(xy2);
+    const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(p.z, p.z, xy2));
+    // fast forms cover: x, y, z finite and non-zero, moderate magnitudes (no under/overflow in the squares)
+    const bool usual = (ix - 0x20000000u < 0x3e000000u) & (iy - 0x20000000u < 0x3e000000u) & (iz - 0x20000000u < 0x3e000000u);
+    cc.unusual = !usual | !(r < 9000.0f);
+    const float az = atan2_approx(p.y, p.x);
+    const float el = atan2_approx(p.z, rxy);
+    // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
+    const float rowh = __builtin_fmaf(-el, row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5
+    const float colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
+    const float rfl = floorf(rowh), cfl = floorf(colh);
+    const float rfr = rowh - rfl, cfr = colh - cfl;                             // in [0,1): distance above the rounding boundary
+    const int rc = (int)rfl, ccn = (int)cfl;
+    const int rmax = g.rows - 1, cmax = g.cols - 1;
+    cc.r0 = min(max(rc - (rfr < kCullEpsPx ? 1 : 0), 0), rmax);
+    cc.r1 = min(max(rc + (rfr > 1.0f - kCullEpsPx ? 1 : 0), 0), rmax);
+    cc.c0 = min(max(ccn - (cfr < kCullEpsPx ? 1 : 0), 0), cmax);
+    cc.c1 = min(max(ccn + (cfr > 1.0f - kCullEpsPx ? 1 : 0), 0), cmax);
+    cc.r_lo = r * (1.0f - 1.5e-6f);
+    return cc;
+}
+
+__device__ __forceinline__ bool cull_matters(const CullCand& cc, const uint32_t* __restrict__ scan, int cols, float thr)
+{
+    if (cc.unusual) return true;
+    const float thr_lo = thr - (1.0e-3f + cc.r_lo * 3.0e-6f);
+    auto t = [&](int r, int c) {
+        const float s = u2f(scan[r * cols + c]);
+        return (s < 9000.0f) & ((s - cc.r_lo) > thr_lo);     // empty scan pixels (10000) can never be flagged: diff > 200
+    };
+    bool m = t(cc.r0, cc.c0);
+    if (cc.c1 != cc.c0) m |= t(cc.r0, cc.c1);
+    if (cc.r1 != cc.r0) { m |= t(cc.r1, cc.c0); if (cc.c1 != cc.c0) m |= t(cc.r1, cc.c1); }
+    return m;
+}
+
+__device__ unsigned long long g_cull_stats[2];   // {survivors, points}: diagnostic, read by cull_stats()
+
+static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
+
+template <bool B2L_IDENTITY, int ABL = 0>
+__global__ void __launch_bounds__(kBlock)
+k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
+                uint32_t kb, HostMat34 b2l_h, Geom gg, const uint32_t* __restrict__ scan_img, float thr, uint64_t* __restrict__ img)
+{
+    __shared__ uint64_t vals[kCullSlots];
+    __shared__ uint32_t tags[kCullSlots];
+    __shared__ uint16_t queue[kBlock * kPtsPerThread];
+    __shared__ uint32_t qcount;
+    for (int s = threadIdx.x; s < kCullSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
+    if (threadIdx.x == 0) qcount = 0;
+    __syncthreads();
+    const uint32_t kf = kb + blockIdx.y;
+    const RimgGeom g = make_geom(gg);
+    const uint32_t npx = (uint32_t)(g.rows * g.cols);
+    uint64_t* __restrict__ imgk = img + (size_t)blockIdx.y * npx;
+    const uint32_t* __restrict__ scank = scan_img + (size_t)blockIdx.y * npx;
+    const uint32_t block_base = blockIdx.x * (uint32_t)(kBlock * kPtsPerThread);
+    const float4* __restrict__ mapb = map + block_base;
+    const uint32_t nloc = min((uint32_t)(kBlock * kPtsPerThread), M - block_base);
+    // ---- phase 1: who can matter?  (bounded-error arithmetic only).  Four points per lane are in flight at once so the
+    // dependent scan-image load of one overlaps the arithmetic of the others.
+    {
+        const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
+        const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
+        constexpr int kInFlight = 4;
+        for (uint32_t j0 = 0; j0 < (uint32_t)kPtsPerThread; j0 += kInFlight) {
+            float4 pt[kInFlight];
+            CullCand cc[kInFlight];
+            uint32_t s0[kInFlight];
+            bool live[kInFlight];
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const uint32_t li = (j0 + u) * kBlock + threadIdx.x;
+                live[u] = li < nloc;
+                pt[u] = live[u] ? mapb[li] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            }
+            if (ABL == 1) {   // ablation: stream the map only
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u) if (pt[u].x == 1.2345e-30f) queue[atomicAdd(&qcount, 1u)] = (uint16_t)u;
+                continue;
+            }
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                bool ok;
+                const float3 p = xform_approx(ap, pt[u], ok);
+                cc[u] = cull_candidates(g, p, row_scale, col_scale);
+                cc[u].unusual |= !ok;
+                s0[u] = (ABL == 2) ? f2u(cc[u].r_lo * 0.5f) : scank[cc[u].r0 * g.cols + cc[u].c0];   // ablation 2: no scan-image load
+            }
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) {
+                const float thr_lo = thr - (1.0e-3f + cc[u].r_lo * 3.0e-6f);
+                const float s = u2f(s0[u]);
+                bool m = cc[u].unusual | ((s < 9000.0f) & ((s - cc[u].r_lo) > thr_lo));
+                if (__builtin_expect((cc[u].r1 != cc[u].r0) | (cc[u].c1 != cc[u].c0), 0)) m |= cull_matters(cc[u], scank, g.cols, thr);
+                if (m & live[u]) queue[atomicAdd(&qcount, 1u)] = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
+            }
+        }
+    }
+    __syncthreads();
+    // ---- phase 2: exact arithmetic for the survivors, LDS pre-reduction as in k_map_rimg_lds
+    const uint32_t nq = qcount;
+    if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled 1/64: same-address atomics from every workgroup would serialise the grid
+        atomicAdd(&g_cull_stats[0], (unsigned long long)nq);
+        atomicAdd(&g_cull_stats[1], (unsigned long long)nloc);
+    }
+    if (nq) {
+        const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
+        for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
+            const uint32_t i = block_base + queue[q];
+            const float4 p4 = map[i];
+            float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+            if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+            const Sph s = cart2sph(p.x, p.y, p.z);
+            int row, col;
+            pixel_row_col(g, s.az, s.el, row, col);
+            const uint32_t px = (uint32_t)(row * g.cols + col);
+            const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
+            const int slot = ((row & 7) << 6) | (col & 63);
+            uint32_t t = tags[slot];
+            if (t == kEmptyTag) {
+                const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+                t = (old == kEmptyTag) ? px : old;
+            }
+            if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+            else img_min_u64(imgk + px, v);
+        }
+    }
+    __syncthreads();
+    if (nq)
+        for (int s = threadIdx.x; s < kCullSlots; s += kBlock) {
+            const uint32_t t = tags[s];
+            if (t != kEmptyTag) img_min_u64(imgk + t, vals[s]);
+        }
+}
+
+hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s)
+{
+    hipError_t e = hipMemcpyFromSymbolAsync(out2, HIP_SYMBOL(g_cull_stats), 16, 0, hipMemcpyDeviceToHost, s);
+    if (e != hipSuccess) return e;
+    e = hipStreamSynchronize(s);
+    if (e != hipSuccess || !reset) return e;
+    const unsigned long long z[2] = {0, 0};
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cull_stats), z, 16, 0, hipMemcpyHostToDevice, s);
+    return e == hipSuccess ? hipStreamSynchronize(s) : e;
+}
+
+static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
+void set_vote_cull(int v) { g_vote_cull = v; }
+
+hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
+                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, float thr, int mode, uint64_t* map_img,
+                                 hipStream_t s)
+{
+    if (!M || !nb) return hipSuccess;
+    if (mode != 0 || !g_vote_cull || !approx_poses_dev) return map_range_images(map, M, inv_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
+    const size_t per_block = (size_t)kBlock * kPtsPerThread;
+    dim3 grid((unsigned)((M + per_block - 1) / per_block), (unsigned)nb);
+    if (g_vote_cull == 2) k_vote_map_cull<true, 1><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
+    else if (g_vote_cull == 3) k_vote_map_cull<true, 2><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
+    else if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
+    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
+    return hipGetLastError();
+}
+
+// debug: number of points whose exact pixel is NOT inside the candidate set of the bounded-error projection.
+// T (3x4 double) / ap (16 floats) are the exact and the approximate form of the same keyframe transform, or null.
+__global__ void __launch_bounds__(kBlock)
+k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, const float* __restrict__ ap, Geom gg, unsigned long long* __restrict__ bad)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const RimgGeom g = make_geom(gg);
+    const float4 p4 = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
+    float3 pe = make_float3(p4.x, p4.y, p4.z), pa = pe;
+    bool ok = true;
+    if (ap) { pe = xform(to_dev(T), pe); pa = xform_approx(ap, p4, ok); }
+    const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
+    const CullCand cc = cull_candidates(g, pa, row_scale, col_scale);
+    if (cc.unusual || !ok) return;
+    const Sph s = cart2sph(pe.x, pe.y, pe.z);
+    int row, col;
+    pixel_row_col(g, s.az, s.el, row, col);
+    const bool good = (row == cc.r0 || row == cc.r1) && (col == cc.c0 || col == cc.c1) && (cc.r_lo <= s.r) && (s.r <= cc.r_lo * (1.0f + 3.0e-6f));
+    if (!good) atomicAdd(bad, 1ull);
+}
+hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const float* approx_pose_dev, Geom g, unsigned long long* bad_dev, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    HostMat34 z{};
+    k_cull_check<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(xyz_dev, n, T ? *T : z, T ? approx_pose_dev : nullptr, g, bad_dev);
+    return hipGetLastError();
+}
+
 static int g_map_kernel_variant = 1;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction
 void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
 

@@ -246,3 +246,30 @@ def test_voxel_centroid_scanset_matches_per_keyframe_oracle(gpu_ctx, orc, small_
         assert int(g_off[k]) == at and int(g_off[k + 1]) == at + len(want)
         assert_clouds_equal(g_pts[at:at + len(want)], want, f"scanwise voxel kf {k}")
         at += len(want)
+
+
+def test_cull_projection_bounds_hold(gpu_ctx):
+    """the bounded-error projection that decides which points get the exact arithmetic must contain the exact pixel and
+    bracket the exact range for every point (lidar-like, tiny, huge, and points sitting on pixel boundaries)"""
+    rng = np.random.default_rng(31)
+    n = 4_000_000
+    sets = [rng.normal(0, 30, (n, 3)), rng.normal(0, 0.5, (n, 3)), rng.normal(0, 3000, (n, 3)),
+            rng.normal(0, 30, (n, 3)) * np.array([1.0, 1.0, 0.02])]
+    # points placed on azimuth/elevation pixel boundaries (+- a few ulp)
+    k = np.arange(n) % 900
+    az = np.deg2rad((k + 0.5) / 2.5 - 180.0 + rng.normal(0, 2e-5, n))
+    el = np.deg2rad(25.0 - (np.arange(n) % 125 + 0.5) / 2.5 + rng.normal(0, 2e-5, n))
+    r = rng.uniform(0.5, 120, n)
+    sets.append(np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1))
+    for alpha in (2.5, 2.375, 1.5):
+        for pts in sets:
+            assert gpu_ctx.cull_check(pts.astype(np.float32), alpha) == 0
+    # with the keyframe transform: exact fp64 PCL form vs the sensor-centred float-float form used by the cull test
+    prng = np.random.default_rng(32)
+    for trial in range(6):
+        T = _random_pose(prng)
+        T[:3, 3] *= (1, 1, 0.05) if trial % 2 else (30, 30, 1)        # sensors up to ~1 km from the origin
+        Tinv = np.linalg.inv(T)
+        for pts in (sets[0], sets[3], sets[4]):
+            glob = (T[:3, :3] @ pts[:1_000_000].T).T + T[:3, 3]
+            assert gpu_ctx.cull_check(glob.astype(np.float32), 2.5, Tinv) == 0
