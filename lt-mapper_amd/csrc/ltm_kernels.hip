@@ -156,42 +156,59 @@ static constexpr int kLdsSlots = 2048;
 static constexpr int kPtsPerThread = 16;
 static constexpr uint32_t kEmptyTag = 0xffffffffu;
 
-template <bool B2L_IDENTITY, int ABL = 0>
+// XCD-aware workgroup -> (map tile, keyframe) mapping.  Workgroup b runs on XCD b % 8 (observed dispatch rule; used for speed
+// only, any other placement is still correct).  Consecutive workgroups of one XCD take the SAME map tile for `kfg`
+// consecutive keyframes, so the tile (64 KB) is fetched from HBM / Infinity Cache once and served from that XCD's L2
+// for the other kfg-1 keyframes: with ~224 resident workgroups per XCD the live tile set is ~28 x 64 KB << 4 MiB of L2.
+struct TileKf { uint32_t tile, kfb; bool valid; };
+__device__ __forceinline__ TileKf tile_kf_of_block(uint32_t b, uint32_t n_tiles, uint32_t nb, uint32_t kfg)
+{
+    const uint32_t x = b & 7u, r = b >> 3;
+    const uint32_t n_tg = (n_tiles + 7u) >> 3;
+    const uint32_t kfl = r % kfg, q = r / kfg;
+    const uint32_t tg = q % n_tg, kg = q / n_tg;
+    TileKf t;
+    t.tile = tg * 8u + x;
+    t.kfb = kg * kfg + kfl;
+    t.valid = (t.tile < n_tiles) & (t.kfb < nb);
+    return t;
+}
+static inline unsigned tile_kf_grid(size_t n_tiles, size_t nb, unsigned kfg)
+{
+    const size_t n_tg = (n_tiles + 7) / 8, n_kg = (nb + kfg - 1) / kfg;
+    return (unsigned)(n_tg * 8 * kfg * n_kg);
+}
+
+template <bool B2L_IDENTITY>
 __global__ void __launch_bounds__(kBlock)
-k_map_rimg_lds(const float4* __restrict__ map, size_t M, const double* __restrict__ inv_poses, size_t kb,
+k_map_rimg_lds(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, uint32_t kb, uint32_t nb, uint32_t kfg,
                HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img)
 {
     __shared__ uint64_t vals[kLdsSlots];
     __shared__ uint32_t tags[kLdsSlots];
+    const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
+    const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
+    if (!tk.valid) return;
     for (int s = threadIdx.x; s < kLdsSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
     __syncthreads();
-    const size_t kf = kb + blockIdx.y;
-    const Mat34 Tinv = load_mat(inv_poses + 12 * kf);
     const RimgGeom g = make_geom(gg);
-    uint64_t* __restrict__ imgk = img + (size_t)blockIdx.y * (size_t)(g.rows * g.cols);
-    const size_t base = (size_t)blockIdx.x * (size_t)(kBlock * kPtsPerThread) + threadIdx.x;
+    const uint32_t npx = (uint32_t)(g.rows * g.cols);
+    const uint32_t block_base = tk.tile * per_block;
+    const float4* __restrict__ mapb = map + block_base;
+    const uint32_t nloc = min(per_block, M - block_base);
+    const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)(kb + tk.kfb));
+    uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
 #pragma unroll 2
-    for (int j = 0; j < kPtsPerThread; ++j) {
-        const size_t i = base + (size_t)j * kBlock;
-        if (i >= M) break;
-        const float4 p4 = map[i];
+    for (uint32_t li = threadIdx.x; li < nloc; li += kBlock) {
+        const float4 p4 = mapb[li];
+        float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+        const Sph s = cart2sph(p.x, p.y, p.z);
         int row, col;
-        Sph s;
-        if (ABL == 2) {   // fake, cheap projection with similar locality
-            const float fx = p4.x - (float)Tinv.m[3], fy = p4.y - (float)Tinv.m[7];
-            s.r = fabsf(fx) + fabsf(fy) + fabsf(p4.z);
-            row = min(max((int)(p4.z * 8.0f) + 40, 0), g.rows - 1);
-            col = min(max((int)((fx + fy) * 3.0f) + g.cols / 2, 0), g.cols - 1);
-        } else {
-            float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
-            if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
-            s = cart2sph(p.x, p.y, p.z);
-            pixel_row_col(g, s.az, s.el, row, col);
-        }
+        pixel_row_col(g, s.az, s.el, row, col);
         const uint32_t px = (uint32_t)(row * g.cols + col);
-        const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)(uint32_t)i;
+        const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)(block_base + li);
         const int slot = ((row & 15) << 7) | (col & 127);
-        if (ABL == 1) { if (v == 0x123456789ull) imgk[px] = v; continue; }
         uint32_t t = tags[slot];
         if (t == kEmptyTag) {
             const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
@@ -285,26 +302,30 @@ __device__ unsigned long long g_cull_stats[2];   // {survivors, points}: diagnos
 
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
-template <bool B2L_IDENTITY, int ABL = 0>
+template <bool B2L_IDENTITY>
 __global__ void __launch_bounds__(kBlock)
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                uint32_t kb, HostMat34 b2l_h, Geom gg, const uint32_t* __restrict__ scan_img, float thr, uint64_t* __restrict__ img)
+                uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const uint32_t* __restrict__ scan_img, float thr,
+                uint64_t* __restrict__ img)
 {
     __shared__ uint64_t vals[kCullSlots];
     __shared__ uint32_t tags[kCullSlots];
     __shared__ uint16_t queue[kBlock * kPtsPerThread];
     __shared__ uint32_t qcount;
+    const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
+    const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
+    if (!tk.valid) return;
     for (int s = threadIdx.x; s < kCullSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
     if (threadIdx.x == 0) qcount = 0;
     __syncthreads();
-    const uint32_t kf = kb + blockIdx.y;
     const RimgGeom g = make_geom(gg);
     const uint32_t npx = (uint32_t)(g.rows * g.cols);
-    uint64_t* __restrict__ imgk = img + (size_t)blockIdx.y * npx;
-    const uint32_t* __restrict__ scank = scan_img + (size_t)blockIdx.y * npx;
-    const uint32_t block_base = blockIdx.x * (uint32_t)(kBlock * kPtsPerThread);
+    const uint32_t block_base = tk.tile * per_block;
     const float4* __restrict__ mapb = map + block_base;
-    const uint32_t nloc = min((uint32_t)(kBlock * kPtsPerThread), M - block_base);
+    const uint32_t nloc = min(per_block, M - block_base);
+    const uint32_t kf = kb + tk.kfb;
+    uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
+    const uint32_t* __restrict__ scank = scan_img + (size_t)tk.kfb * npx;
     // ---- phase 1: who can matter?  (bounded-error arithmetic only).  Four points per lane are in flight at once so the
     // dependent scan-image load of one overlaps the arithmetic of the others.
     {
@@ -322,18 +343,13 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 live[u] = li < nloc;
                 pt[u] = live[u] ? mapb[li] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
             }
-            if (ABL == 1) {   // ablation: stream the map only
-#pragma unroll
-                for (int u = 0; u < kInFlight; ++u) if (pt[u].x == 1.2345e-30f) queue[atomicAdd(&qcount, 1u)] = (uint16_t)u;
-                continue;
-            }
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 bool ok;
                 const float3 p = xform_approx(ap, pt[u], ok);
                 cc[u] = cull_candidates(g, p, row_scale, col_scale);
                 cc[u].unusual |= !ok;
-                s0[u] = (ABL == 2) ? f2u(cc[u].r_lo * 0.5f) : scank[cc[u].r0 * g.cols + cc[u].c0];   // ablation 2: no scan-image load
+                s0[u] = scank[cc[u].r0 * g.cols + cc[u].c0];
             }
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
@@ -393,6 +409,8 @@ hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s)
     return e == hipSuccess ? hipStreamSynchronize(s) : e;
 }
 
+static int g_kf_per_block = 8;         // keyframes that reuse one map tile on an XCD (tile_kf_of_block); env LTM_KF_PER_BLOCK
+void set_kf_per_block(int v) { g_kf_per_block = v < 1 ? 1 : (v > 64 ? 64 : v); }
 static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
 void set_vote_cull(int v) { g_vote_cull = v; }
 
@@ -403,11 +421,10 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
     if (!M || !nb) return hipSuccess;
     if (mode != 0 || !g_vote_cull || !approx_poses_dev) return map_range_images(map, M, inv_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
-    dim3 grid((unsigned)((M + per_block - 1) / per_block), (unsigned)nb);
-    if (g_vote_cull == 2) k_vote_map_cull<true, 1><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
-    else if (g_vote_cull == 3) k_vote_map_cull<true, 2><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
-    else if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
-    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, b2l, g, scan_img, thr, map_img);
+    const unsigned kfg = (unsigned)g_kf_per_block;
+    dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
+    if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, thr, map_img);
+    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, thr, map_img);
     return hipGetLastError();
 }
 
@@ -440,7 +457,7 @@ hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const 
     return hipGetLastError();
 }
 
-static int g_map_kernel_variant = 1;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction
+static int g_map_kernel_variant = 1;   // 0: one global atomic per point (baseline, kept for A/B), 1: LDS pre-reduction
 void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
 
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb, HostMat34 b2l,
@@ -449,16 +466,10 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
     if (!M || !nb) return hipSuccess;
     if (g_map_kernel_variant == 1) {
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
-        dim3 grid((unsigned)((M + per_block - 1) / per_block), (unsigned)nb);
-        if (b2l_identity) k_map_rimg_lds<true><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
-        else k_map_rimg_lds<false><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
-        return hipGetLastError();
-    }
-    if (g_map_kernel_variant == 2 || g_map_kernel_variant == 3) {
-        const size_t per_block = (size_t)kBlock * kPtsPerThread;
-        dim3 grid((unsigned)((M + per_block - 1) / per_block), (unsigned)nb);
-        if (g_map_kernel_variant == 2) k_map_rimg_lds<true, 1><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
-        else k_map_rimg_lds<true, 2><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+        const unsigned kfg = (unsigned)g_kf_per_block;
+        dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
+        if (b2l_identity) k_map_rimg_lds<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
+        else k_map_rimg_lds<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
         return hipGetLastError();
     }
     dim3 grid(grid_for(M), (unsigned)nb);
