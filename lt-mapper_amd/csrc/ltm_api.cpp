@@ -817,23 +817,22 @@ int ltm_scanset_zip_concat(ltm_ctx* c, ltm_scanset ha, ltm_scanset hb, ltm_scans
 {
     return guarded(c, [&] {
         LTM_REQUIRE(out, "null argument");
-        const ScanSet* parts[3] = {&get_ss(c, ha), &get_ss(c, hb), hc ? &get_ss(c, hc) : nullptr};
-        const size_t nk = parts[0]->nkf();
-        size_t tot = 0;
-        for (const ScanSet* s : parts) if (s) { LTM_REQUIRE(s->nkf() == nk, "scan sets have different keyframe counts"); tot += s->n_pts; }
-        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(tot, 1) * 16));
+        const ScanSet& A = get_ss(c, ha);
+        const ScanSet& B = get_ss(c, hb);
+        const ScanSet* C = hc ? &get_ss(c, hc) : nullptr;
+        const size_t nk = A.nkf();
+        LTM_REQUIRE(B.nkf() == nk && (!C || C->nkf() == nk), "scan sets have different keyframe counts");
         std::vector<uint64_t> off(nk + 1, 0);
-        size_t at = 0;
-        for (size_t k = 0; k < nk; ++k) {
-            for (const ScanSet* s : parts) {
-                if (!s) continue;
-                const size_t cnt = s->off[k + 1] - s->off[k];
-                d2d(c, d + at, s->d + s->off[k], cnt * 16);
-                at += cnt;
-            }
-            off[k + 1] = at;
-        }
-        *out = new_scanset(c, d, std::move(off));
+        for (size_t k = 0; k < nk; ++k)
+            off[k + 1] = off[k] + (A.off[k + 1] - A.off[k]) + (B.off[k + 1] - B.off[k]) + (C ? C->off[k + 1] - C->off[k] : 0);
+        const size_t tot = off[nk];
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(tot, 1) * 16));
+        const ltm_scanset h = new_scanset(c, d, std::move(off));      // uploads the result offsets
+        const ScanSet& O = get_ss(c, h);
+        // a missing third operand is given zero-length segments by pointing it at B with B's own start offsets twice:
+        // (oc[k+1]-oc[k]) is never read for it because j < na + nb always holds; pass B's arrays to keep pointers valid
+        LTM_HIP(zip_concat(A.d, A.off_dev, B.d, B.off_dev, C ? C->d : B.d, C ? C->off_dev : B.off_dev, O.off_dev, nk, tot, d, c->stream));
+        *out = h;
     });
 }
 int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
@@ -1042,7 +1041,7 @@ int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, siz
                 LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
                 {
                     ProfScope ps(c, "reproject_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
-                    LTM_HIP(map_range_images(map.d, map.n, p.inv_dev, kb, nb, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream));
+                    LTM_HIP(map_range_images(map.d, map.n, p.inv_dev, p.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream));
                 }
                 ProfScope ps(c, "reproject_gather", (double)(nb * npx), (double)(nb * npx) * 12);
                 LTM_HIP(exclusive_scan_img_valid(img.as<uint64_t>(), pos.as<uint32_t>(), nb * npx, temp.p, tb, c->stream));

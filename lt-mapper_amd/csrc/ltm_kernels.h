@@ -28,7 +28,7 @@ hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, s
                              uint64_t first_pt, uint64_t n_pts, Geom g, uint32_t* scan_img, hipStream_t s);
 // transformGlobalMapToLocal + map2RangeImg: map_img[(kf-kb)*npx+px] = min (range_bits<<32 | idx)
 // inv_poses_dev: 12 doubles per keyframe (3x4 row-major).  b2l: 12 doubles, b2l_identity skips the arithmetic.
-hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb,
+hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                             HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
 hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
@@ -74,6 +74,9 @@ hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, siz
 // out[i] = xform(second, xform(first, in[i])) with per-keyframe `second` (merge: first=L2B, second=pose[kf])
 hipError_t transform_scans(const float4* in, const uint64_t* offsets_dev, size_t n_kf, uint64_t n_pts,
                            HostMat34 first, int first_identity, const double* per_kf_dev, float4* out, hipStream_t s);
+// out[k] = a[k] ++ b[k] ++ c[k] per keyframe; c (and oc) may alias b with an all-zero-length offsets array
+hipError_t zip_concat(const float4* a, const uint64_t* oa, const float4* b, const uint64_t* ob, const float4* c, const uint64_t* oc,
+                      const uint64_t* out_off_dev, size_t n_kf, uint64_t n, float4* out, hipStream_t s);
 hipError_t preclean_flags(const float4* in, uint64_t n, float radius, uint8_t* keep, hipStream_t s);
 
 // ---- voxel centroid ----

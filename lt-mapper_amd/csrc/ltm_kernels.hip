@@ -224,8 +224,8 @@ k_map_rimg_lds(const float4* __restrict__ map, uint32_t M, const double* __restr
     }
 }
 
-hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb, HostMat34 b2l,
-                            int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
+hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
+                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Range-culled vote kernel (mode 0: diff = scan - map).  A map point P can influence the labels only if it could be
@@ -419,7 +419,7 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
                                  hipStream_t s)
 {
     if (!M || !nb) return hipSuccess;
-    if (mode != 0 || !g_vote_cull || !approx_poses_dev) return map_range_images(map, M, inv_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
+    if (mode != 0 || !g_vote_cull || !approx_poses_dev) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
     const unsigned kfg = (unsigned)g_kf_per_block;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
@@ -457,14 +457,124 @@ hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const 
     return hipGetLastError();
 }
 
-static int g_map_kernel_variant = 1;   // 0: one global atomic per point (baseline, kept for A/B), 1: LDS pre-reduction
+// ---------------------------------------------------------------------------------------------------------------
+// Exact arg-min range image with a workgroup-local pre-filter (reprojection, ND votes, and any caller that needs the
+// true image).  Only a point that could be the nearest of its pixel AMONG THE 4096 POINTS OF ITS OWN TILE can be the
+// global arg-min, so:
+//   phase 1a  bounded-error projection of every point; points whose pixel is certain (one candidate) publish an UPPER
+//             bound of their range into a per-pixel LDS min table;
+//   phase 1b  a point survives unless its pixel is certain, owns a table slot, and its range LOWER bound exceeds the
+//             table's minimum upper bound (then some other point of the tile is strictly nearer in the same exact pixel);
+//   phase 2   survivors (a few per pixel) get the exact arithmetic and the usual 64-bit LDS/global min.
+// The result is bit-identical to k_map_rimg_lds / the serial reference: discarded points are provably not arg-mins.
+static constexpr int kBmSlots = 1024;
+
+template <bool B2L_IDENTITY>
+__global__ void __launch_bounds__(kBlock)
+k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
+                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img)
+{
+    __shared__ uint64_t vals[kBmSlots];
+    __shared__ uint32_t tags[kBmSlots];
+    __shared__ uint32_t amin[kBmSlots];
+    __shared__ uint16_t queue[kBlock * kPtsPerThread];
+    __shared__ uint32_t qcount;
+    const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
+    const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
+    if (!tk.valid) return;
+    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; amin[s] = 0x7f800000u; }
+    if (threadIdx.x == 0) qcount = 0;
+    __syncthreads();
+    const RimgGeom g = make_geom(gg);
+    const uint32_t npx = (uint32_t)(g.rows * g.cols);
+    const uint32_t block_base = tk.tile * per_block;
+    const float4* __restrict__ mapb = map + block_base;
+    const uint32_t nloc = min(per_block, M - block_base);
+    const uint32_t kf = kb + tk.kfb;
+    uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
+    const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
+    const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
+    // per-lane record of the 16 points: slot (0xffff = survive unconditionally) and range lower bound
+    float rlo[kPtsPerThread];
+    uint16_t slot_of[kPtsPerThread];
+    // ---- phase 1a
+#pragma unroll
+    for (int j = 0; j < kPtsPerThread; ++j) {
+        const uint32_t li = (uint32_t)j * kBlock + threadIdx.x;
+        rlo[j] = 0.0f; slot_of[j] = 0xfffe;                       // 0xfffe = not a point
+        if (li >= nloc) continue;
+        bool ok;
+        const float3 p = xform_approx(ap, mapb[li], ok);
+        const CullCand cc = cull_candidates(g, p, row_scale, col_scale);
+        rlo[j] = cc.r_lo;
+        slot_of[j] = 0xffff;
+        if (cc.unusual | !ok | (cc.r0 != cc.r1) | (cc.c0 != cc.c1)) continue;
+        const uint32_t px = (uint32_t)(cc.r0 * g.cols + cc.c0);
+        const int slot = ((cc.r0 & 15) << 6) | (cc.c0 & 63);
+        uint32_t t = tags[slot];
+        if (t == kEmptyTag) {
+            const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+            t = (old == kEmptyTag) ? px : old;
+        }
+        if (t != px) continue;                                     // slot owned by another pixel: survive unconditionally
+        slot_of[j] = (uint16_t)slot;
+        atomicMin(&amin[slot], f2u(cc.r_lo * (1.0f + 3.5e-6f)));   // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6))
+    }
+    __syncthreads();
+    // ---- phase 1b
+#pragma unroll
+    for (int j = 0; j < kPtsPerThread; ++j) {
+        const uint16_t sl = slot_of[j];
+        if (sl == 0xfffe) continue;
+        const bool survive = (sl == 0xffff) || !(rlo[j] > u2f(amin[sl]));
+        if (survive) queue[atomicAdd(&qcount, 1u)] = (uint16_t)((uint32_t)j * kBlock + threadIdx.x);
+    }
+    __syncthreads();
+    // ---- phase 2: exact arithmetic for the survivors
+    const uint32_t nq = qcount;
+    const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
+    for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
+        const uint32_t i = block_base + queue[q];
+        const float4 p4 = map[i];
+        float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+        const Sph s = cart2sph(p.x, p.y, p.z);
+        int row, col;
+        pixel_row_col(g, s.az, s.el, row, col);
+        const uint32_t px = (uint32_t)(row * g.cols + col);
+        const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
+        const int slot = ((row & 15) << 6) | (col & 63);
+        uint32_t t = tags[slot];
+        if (t == kEmptyTag) {
+            const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+            t = (old == kEmptyTag) ? px : old;
+        }
+        if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+        else img_min_u64(imgk + px, v);
+    }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) {
+        const uint32_t t = tags[s];
+        if (t != kEmptyTag && vals[s] != ~0ull) img_min_u64(imgk + t, vals[s]);
+    }
+}
+
+static int g_map_kernel_variant = 2;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction, 2: + workgroup-local arg-min pre-filter
 void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
 
-hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, size_t kb, size_t nb, HostMat34 b2l,
-                            int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s)
+hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
+                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s)
 {
     if (!M || !nb) return hipSuccess;
-    if (g_map_kernel_variant == 1) {
+    if (g_map_kernel_variant == 2 && approx_poses_dev) {
+        const size_t per_block = (size_t)kBlock * kPtsPerThread;
+        const unsigned kfg = (unsigned)g_kf_per_block;
+        dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
+        if (b2l_identity) k_map_rimg_blockmin<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
+        else k_map_rimg_blockmin<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
+        return hipGetLastError();
+    }
+    if (g_map_kernel_variant >= 1) {
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
         const unsigned kfg = (unsigned)g_kf_per_block;
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
@@ -701,6 +811,31 @@ hipError_t transform_scans(const float4* in, const uint64_t* offsets_dev, size_t
     if (!n_pts) return hipSuccess;
     if (first_identity) k_transform_scans<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(in, offsets_dev, n_kf, n_pts, first, per_kf_dev, out);
     else k_transform_scans<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(in, offsets_dev, n_kf, n_pts, first, per_kf_dev, out);
+    return hipGetLastError();
+}
+
+// per-keyframe concatenation a[k] ++ b[k] ++ c[k] (Session.cpp:365-371) as one gather: out_off = offsets of the result
+__global__ void __launch_bounds__(kBlock)
+k_zip_concat(const float4* __restrict__ a, const uint64_t* __restrict__ oa, const float4* __restrict__ b, const uint64_t* __restrict__ ob,
+             const float4* __restrict__ c, const uint64_t* __restrict__ oc, const uint64_t* __restrict__ out_off, size_t n_kf, uint64_t n,
+             float4* __restrict__ out)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const size_t k = find_kf(out_off, 0, n_kf, i);
+    uint64_t j = i - out_off[k];
+    const uint64_t na = oa[k + 1] - oa[k], nb = ob[k + 1] - ob[k];
+    if (j < na) { out[i] = a[oa[k] + j]; return; }
+    j -= na;
+    if (j < nb) { out[i] = b[ob[k] + j]; return; }
+    j -= nb;
+    out[i] = c[oc[k] + j];
+}
+hipError_t zip_concat(const float4* a, const uint64_t* oa, const float4* b, const uint64_t* ob, const float4* c, const uint64_t* oc,
+                      const uint64_t* out_off_dev, size_t n_kf, uint64_t n, float4* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_zip_concat<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(a, oa, b, ob, c, oc, out_off_dev, n_kf, n, out);
     return hipGetLastError();
 }
 
