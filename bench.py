@@ -133,14 +133,18 @@ def main():
     value = pairs_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
 
-    vm = prof.get("vote_map", dict(ms=0.0, launches=0, units=0.0, bytes=0.0))
+    # dominant kernel: k_vote_map_cull (profile class "vote_map_cull"; falls back to the exact kernel if culling is disabled)
+    cls = "vote_map_cull" if prof.get("vote_map_cull", {}).get("launches") else "vote_map_exact"
+    vm = prof.get(cls, dict(ms=0.0, launches=0, units=0.0, bytes=0.0))
     roofline = None
     if vm["launches"]:
         achieved = vm["bytes"] / (vm["ms"] * 1e-3) / 1e9
-        roofline = {"bound": "hbm", "kernel": "k_map_rimg (class vote_map)", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
-                    "launches": vm["launches"], "avg_launch_ms": round(vm["ms"] / vm["launches"], 4),
+        roofline = {"bound": "hbm", "kernel": "k_vote_map_cull" if cls == "vote_map_cull" else "k_map_rimg_blockmin",
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
+                    "traffic": measured_traffic(cls), "launches_per_step": vm["launches"] // max(args.steps, 1),
+                    "avg_launch_ms": round(vm["ms"] / vm["launches"], 4),
                     "algorithmic_bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
+                    "algorithmic_definition": "nb*(16*M + 8*R*C) per launch over nb keyframes (SURVEY 8d: map read + range|index image)",
                     "point_projections_per_s": round(vm["units"] / (vm["ms"] * 1e-3), 1)}
 
     cpu_baseline = None
@@ -170,6 +174,18 @@ def main():
         print(json.dumps(out))
     if dist is not None:
         dist.destroy_process_group()
+
+
+def measured_traffic(cls):
+    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
+    inside this process; the file records the command).  None if no measurement exists for this kernel."""
+    path = os.path.join(ROOT, "profiles", "r1_final_pmc_hbm_traffic.json")
+    if cls != "vote_map_cull" or not os.path.exists(path):
+        return None
+    try:
+        return round(json.load(open(path))["hbm_bytes_per_launch"], 1)
+    except Exception:
+        return None
 
 
 def run_cpu_baseline(sess_t, three_res, n_kf, stride, verbose):

@@ -368,7 +368,9 @@ void do_vote(ltm_ctx* c, const Cloud& map, const ScanSet& ss, const Poses& ps, s
             LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, scan_img.as<uint32_t>(), c->stream));
         }
         {
-            ProfScope p(c, "vote_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
+            // class name = kernel: k_vote_map_cull for mode 0 (when enabled), k_map_rimg_blockmin otherwise
+            const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
+            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
             LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img.as<uint32_t>(),
                                           thr, mode, map_img.as<uint64_t>(), c->stream));
         }

@@ -39,6 +39,7 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
                                  HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, float thr, int mode, uint64_t* map_img,
                                  hipStream_t s);
 void set_vote_cull(int v);
+int vote_cull_enabled();
 void set_kf_per_block(int v);    // keyframes that share one map-tile read inside a workgroup (1, 2, 4, 8)
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s);   // {survivors, points} since the last reset
 hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const float* approx_pose_dev, Geom g, unsigned long long* bad_dev, hipStream_t s);

@@ -413,6 +413,7 @@ static int g_kf_per_block = 8;         // keyframes that reuse one map tile on a
 void set_kf_per_block(int v) { g_kf_per_block = v < 1 ? 1 : (v > 64 ? 64 : v); }
 static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
 void set_vote_cull(int v) { g_vote_cull = v; }
+int vote_cull_enabled() { return g_vote_cull != 0; }
 
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                  HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, float thr, int mode, uint64_t* map_img,
