@@ -99,6 +99,7 @@ def main():
     sessions = fresh_sessions()   # loading + pre-clean are Step 0 plumbing, outside the timed region
 
     def one_step():
+        ctx.clear_caches()   # no derived data (scan range images) survives from a previous step: every step is a fresh run
         C, Q = sessions
         rm = Removerter(ops, P, Session("Central", C.keyframe_scans_, C.keyframe_poses), Session("Query", Q.keyframe_scans_, Q.keyframe_poses))
         rm.run()

@@ -60,6 +60,9 @@ int         ltm_create(const ltm_config* cfg, ltm_ctx** out);
 void        ltm_destroy(ltm_ctx* ctx);
 const char* ltm_last_error(const ltm_ctx* ctx);
 int         ltm_synchronize(ltm_ctx* ctx);
+/* drops derived data the context keeps between calls (finished scan range images, keyed by scan set + image shape).
+ * Results never depend on it; benchmarks call it so that every timed run does the work of a fresh run. */
+int         ltm_clear_caches(ltm_ctx* ctx);
 /* the hipStream_t every kernel of this context is launched on (for events / interop) */
 void*       ltm_stream(ltm_ctx* ctx);
 

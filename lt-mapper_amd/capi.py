@@ -38,6 +38,7 @@ SIGNATURES = {
     "ltm_destroy": (None, [_vp]),
     "ltm_last_error": (C.c_char_p, [_vp]),
     "ltm_synchronize": (_i, [_vp]),
+    "ltm_clear_caches": (_i, [_vp]),
     "ltm_stream": (_vp, [_vp]),
     "ltm_cloud_upload": (_i, [_vp, _vp, _sz, _sz, _pu64]),
     "ltm_cloud_from_device": (_i, [_vp, _vp, _sz, _pu64]),
@@ -295,6 +296,9 @@ class Context:
     # ---- measurement
     def synchronize(self):
         self._ck(self.lib.ltm_synchronize(self.h))
+
+    def clear_caches(self):
+        self._ck(self.lib.ltm_clear_caches(self.h))
 
     def stream(self):
         return self.lib.ltm_stream(self.h)

@@ -97,6 +97,9 @@ struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> of
 struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; float* approx_dev = nullptr; };
 
 struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0; };
+// scan2RangeImg depends only on (scan set, image shape, keyframe range): the remove / revert / remove passes of one
+// resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
+struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; size_t bytes; uint64_t stamp; };
 struct Pending { int cls; hipEvent_t a, b; };
 
 } // namespace
@@ -122,6 +125,9 @@ struct ltm_ctx {
     std::vector<ProfClass> prof;
     std::vector<Pending> pending;
     std::vector<hipEvent_t> event_pool;
+    std::vector<ScanImgEntry> scan_cache;
+    uint64_t scan_cache_stamp = 0;
+    size_t scan_cache_cap = (size_t)3 << 30;   // bytes
 };
 
 namespace {
@@ -342,7 +348,42 @@ size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, siz
 }
 
 // --------------------------------------------------------------------------------- vote
-void do_vote(ltm_ctx* c, const Cloud& map, const ScanSet& ss, const Poses& ps, size_t kf_begin, size_t kf_end, float alpha, float thr,
+void scan_cache_drop(ltm_ctx* c, uint64_t ss_handle)
+{
+    for (size_t i = 0; i < c->scan_cache.size();) {
+        if (ss_handle == 0 || c->scan_cache[i].ss == ss_handle) { c->pool.free(c->scan_cache[i].buf); c->scan_cache.erase(c->scan_cache.begin() + i); }
+        else ++i;
+    }
+}
+
+// returns the finished scan range images of keyframes [kb, kb+nb) (cached or freshly computed and then cached)
+const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size_t kb, size_t nb, const Geom& g)
+{
+    const size_t npx = (size_t)g.rows * g.cols;
+    for (ScanImgEntry& e : c->scan_cache)
+        if (e.ss == ss_handle && e.rows == g.rows && e.cols == g.cols && e.kb == kb && e.nb == nb) { e.stamp = ++c->scan_cache_stamp; return e.buf; }
+    const size_t bytes = nb * npx * sizeof(uint32_t);
+    size_t held = 0;
+    for (const ScanImgEntry& e : c->scan_cache) held += e.bytes;
+    while (!c->scan_cache.empty() && held + bytes > c->scan_cache_cap) {      // evict least recently used
+        size_t lru = 0;
+        for (size_t i = 1; i < c->scan_cache.size(); ++i) if (c->scan_cache[i].stamp < c->scan_cache[lru].stamp) lru = i;
+        held -= c->scan_cache[lru].bytes;
+        c->pool.free(c->scan_cache[lru].buf);
+        c->scan_cache.erase(c->scan_cache.begin() + lru);
+    }
+    uint32_t* buf = reinterpret_cast<uint32_t*>(c->pool.alloc(bytes));
+    const uint64_t first = ss.off[kb], npts = ss.off[kb + nb] - first;
+    {
+        ProfScope p(c, "vote_scan", (double)npts, (double)npts * 16 + (double)(nb * npx) * 4);
+        LTM_HIP(fill_u32(buf, kNoPointBits, nb * npx, c->stream));
+        LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, buf, c->stream));
+    }
+    c->scan_cache.push_back(ScanImgEntry{ss_handle, g.rows, g.cols, kb, nb, buf, bytes, ++c->scan_cache_stamp});
+    return buf;
+}
+
+void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss, const Poses& ps, size_t kf_begin, size_t kf_end, float alpha, float thr,
              int mode, uint8_t* labels_dev)
 {
     LTM_REQUIRE(ss.nkf() == ps.n, "scan set and poses have different keyframe counts");
@@ -354,29 +395,24 @@ void do_vote(ltm_ctx* c, const Cloud& map, const ScanSet& ss, const Poses& ps, s
     LTM_REQUIRE(g.rows > 0 && g.cols > 0, "empty range image");
     const size_t npx = (size_t)g.rows * g.cols;
     const size_t KB = std::min(c->kf_batch, kf_end - kf_begin);
-    DevBuf scan_img(c, KB * npx * sizeof(uint32_t)), map_img(c, KB * npx * sizeof(uint64_t));
+    DevBuf map_img(c, KB * npx * sizeof(uint64_t));
     for (size_t kb = kf_begin; kb < kf_end; kb += KB) {
         const size_t nb = std::min(KB, kf_end - kb);
-        const uint64_t first = ss.off[kb], npts = ss.off[kb + nb] - first;
+        const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g);
         {
-            ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 12));
-            LTM_HIP(fill_u32(scan_img.as<uint32_t>(), kNoPointBits, nb * npx, c->stream));
+            ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 8));
             LTM_HIP(fill_u64(map_img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
-        }
-        {
-            ProfScope p(c, "vote_scan", (double)npts, (double)npts * 16 + (double)(nb * npx) * 4);
-            LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, scan_img.as<uint32_t>(), c->stream));
         }
         {
             // class name = kernel: k_vote_map_cull for mode 0 (when enabled), k_map_rimg_blockmin otherwise
             const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
             ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
-            LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img.as<uint32_t>(),
+            LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img,
                                           thr, mode, map_img.as<uint64_t>(), c->stream));
         }
         {
             ProfScope p(c, "vote_compare", (double)(nb * npx), (double)(nb * npx) * 12 + (double)nb * map.n / 8.0);
-            LTM_HIP(compare_and_flag(scan_img.as<uint32_t>(), map_img.as<uint64_t>(), nb * npx, thr, mode, labels_dev, c->stream));
+            LTM_HIP(compare_and_flag(scan_img, map_img.as<uint64_t>(), nb * npx, thr, mode, labels_dev, c->stream));
         }
     }
 }
@@ -643,6 +679,7 @@ void ltm_destroy(ltm_ctx* c)
 
 const char* ltm_last_error(const ltm_ctx* c) { return c ? c->err.c_str() : "null context"; }
 int ltm_synchronize(ltm_ctx* c) { return guarded(c, [&] { sync(c); }); }
+int ltm_clear_caches(ltm_ctx* c) { return guarded(c, [&] { sync(c); scan_cache_drop(c, 0); }); }
 void* ltm_stream(ltm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
 void ltm_rimg_size(float vfov, float hfov, float alpha, int* rows, int* cols)
@@ -839,7 +876,7 @@ int ltm_scanset_zip_concat(ltm_ctx* c, ltm_scanset ha, ltm_scanset hb, ltm_scans
 }
 int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
 {
-    return guarded(c, [&] { ScanSet& s = get_ss(c, h); c->pool.free(s.d); c->pool.free(s.off_dev); c->scansets.erase(h); });
+    return guarded(c, [&] { ScanSet& s = get_ss(c, h); scan_cache_drop(c, h); c->pool.free(s.d); c->pool.free(s.off_dev); c->scansets.erase(h); });
 }
 
 // -------------------------------------------------------------------------------- poses
@@ -990,7 +1027,7 @@ int ltm_visibility_vote(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_poses hp
 {
     return guarded(c, [&] {
         LTM_REQUIRE(labels_dev, "null labels buffer");
-        do_vote(c, get_cloud(c, hmap), get_ss(c, hs), get_poses(c, hp), kf_begin, kf_end, alpha, thr, mode, labels_dev);
+        do_vote(c, get_cloud(c, hmap), hs, get_ss(c, hs), get_poses(c, hp), kf_begin, kf_end, alpha, thr, mode, labels_dev);
         sync(c);   // the caller may hand labels_dev to a collective on another stream
     });
 }
@@ -1012,7 +1049,7 @@ int ltm_visibility_partition(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_pos
         const Poses& p = get_poses(c, hp);
         DevBuf labels(c, std::max<size_t>(map.n, 1));
         LTM_HIP(hipMemsetAsync(labels.p, 0, std::max<size_t>(map.n, 1), c->stream));
-        do_vote(c, map, get_ss(c, hs), p, 0, p.n, alpha, thr, mode, labels.as<uint8_t>());
+        do_vote(c, map, hs, get_ss(c, hs), p, 0, p.n, alpha, thr, mode, labels.as<uint8_t>());
         if (host_labels) d2h(c, host_labels, labels.p, map.n);
         do_partition(c, map, labels.as<uint8_t>(), kept, flagged);
     });

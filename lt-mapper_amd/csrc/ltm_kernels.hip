@@ -928,45 +928,48 @@ __global__ void k_bbox_init_seg(uint32_t* b, size_t n_kf)
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_kf * 6) b[i] = ((i % 6) < 3) ? 0xffffffffu : 0u;
 }
+// grid = (chunks, keyframes): every workgroup reduces points of ONE keyframe (wave shuffle, then LDS), 6 atomics per workgroup
 __global__ void __launch_bounds__(kBlock)
-k_bbox_reduce_seg(const float4* __restrict__ pts, const uint64_t* __restrict__ offsets, size_t n_kf, uint64_t n, uint32_t* __restrict__ bbox)
+k_bbox_reduce_seg(const float4* __restrict__ pts, const uint64_t* __restrict__ offsets, uint32_t* __restrict__ bbox)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = i < n;
-    size_t kf = 0;
-    uint32_t e[3] = {0, 0, 0};
-    if (live) {
-        size_t lo = 0, hi = n_kf;
-        while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
-        kf = lo;
+    __shared__ uint32_t smn[3][kBlock / 64], smx[3][kBlock / 64];
+    const size_t kf = blockIdx.y;
+    const uint64_t a = offsets[kf], b = offsets[kf + 1];
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    for (uint64_t i = a + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < b; i += (uint64_t)gridDim.x * blockDim.x) {
         const float4 p = pts[i];
-        e[0] = enc_f32(p.x); e[1] = enc_f32(p.y); e[2] = enc_f32(p.z);
+        const uint32_t e[3] = {enc_f32(p.x), enc_f32(p.y), enc_f32(p.z)};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { mn[d] = min(mn[d], e[d]); mx[d] = max(mx[d], e[d]); }
     }
-    // wave-uniform keyframe (the common case: ~1e5 points per keyframe): reduce in the wave, one lane writes
-    const size_t kf0 = (size_t)__shfl((int)kf, 0, 64);
-    const bool uniform = __all(live && kf == kf0);
-    if (uniform) {
-        uint32_t mn[3] = {e[0], e[1], e[2]}, mx[3] = {e[0], e[1], e[2]};
 #pragma unroll
-        for (int d = 0; d < 3; ++d)
+    for (int d = 0; d < 3; ++d)
 #pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                mn[d] = min(mn[d], (uint32_t)__shfl_xor((int)mn[d], off, 64));
-                mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], off, 64));
-            }
-        if ((threadIdx.x & 63) == 0)
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[d] = min(mn[d], (uint32_t)__shfl_xor((int)mn[d], off, 64));
+            mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], off, 64));
+        }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
 #pragma unroll
-            for (int d = 0; d < 3; ++d) { atomicMin(bbox + 6 * kf + d, mn[d]); atomicMax(bbox + 6 * kf + 3 + d, mx[d]); }
-    } else if (live) {
-#pragma unroll
-        for (int d = 0; d < 3; ++d) { atomicMin(bbox + 6 * kf + d, e[d]); atomicMax(bbox + 6 * kf + 3 + d, e[d]); }
+        for (int d = 0; d < 3; ++d) { smn[d][wave] = mn[d]; smx[d][wave] = mx[d]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        uint32_t lo = smn[d][0], hi = smx[d][0];
+        for (int w = 1; w < kBlock / 64; ++w) { lo = min(lo, smn[d][w]); hi = max(hi, smx[d][w]); }
+        if (lo != 0xffffffffu || hi != 0u) { atomicMin(bbox + 6 * kf + d, lo); atomicMax(bbox + 6 * kf + 3 + d, hi); }
     }
 }
 hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, uint32_t* bbox, hipStream_t s)
 {
     if (!n_kf) return hipSuccess;
     k_bbox_init_seg<<<dim3(grid_for(n_kf * 6)), dim3(kBlock), 0, s>>>(bbox, n_kf);
-    if (n) k_bbox_reduce_seg<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, offsets_dev, n_kf, n, bbox);
+    if (n) {
+        const size_t per_kf = (n + n_kf - 1) / n_kf;
+        const unsigned chunks = (unsigned)std::min<size_t>(std::max<size_t>(per_kf / (kBlock * 16), 1), 64);
+        k_bbox_reduce_seg<<<dim3(chunks, (unsigned)n_kf), dim3(kBlock), 0, s>>>(pts, offsets_dev, bbox);
+    }
     return hipGetLastError();
 }
 
