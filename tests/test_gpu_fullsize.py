@@ -1,0 +1,102 @@
+"""Full-size checks on the BASELINE configs[1] workload (2x500 keyframes, OS1-64-like sensor, ~6.8 M point maps), where the
+CPU oracle is too slow to be the checker: size-independent properties and equality between independent GPU code paths."""
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = [pytest.mark.gpu, pytest.mark.slow]
+
+
+@pytest.fixture(scope="module")
+def full(ltm):
+    import torch
+    from tools import synth
+    S = synth.make_session(1, 500, "os1-64", device="cuda:0")
+    torch.cuda.synchronize()
+    return S
+
+
+def _ctx(ltm, **env):
+    old = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        return ltm.Context(vfov=50.0, hfov=360.0, device=0)     # the kernel-variant switches are read at context creation
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+def _load(ctx, S):
+    scans = ctx.preclean(ctx.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64)), 2.5)
+    poses = ctx.poses(S["poses"], S["inv"])
+    cmap = ctx.voxel_centroid(ctx.merge_to_global(scans, poses), 0.05)
+    return scans, poses, cmap
+
+
+def test_culled_vote_equals_exact_vote_at_full_size(ltm, full):
+    """k_vote_map_cull (bounded-error pre-test) must flag exactly the points the exact-image path flags: 3.4e9 point projections"""
+    import torch
+    labels = {}
+    for cull in (1, 0):
+        ctx = _ctx(ltm, LTM_VOTE_CULL=cull)
+        scans, poses, cmap = _load(ctx, full)
+        M = len(cmap)
+        for alpha in (2.5, 2.375):
+            lab = torch.zeros(M, dtype=torch.uint8, device="cuda")
+            ctx.visibility_vote(cmap, scans, poses, 0, poses.n, alpha, 0.1, 0, lab.data_ptr())
+            labels[(cull, alpha)] = lab.cpu().numpy()
+        if cull:
+            surv, pts = ctx.cull_stats()
+            assert 0 < surv < 0.3 * pts, "the cull is expected to spare most points the exact path"
+        ctx.close()
+    for alpha in (2.5, 2.375):
+        a, b = labels[(1, alpha)], labels[(0, alpha)]
+        assert a.sum() > 1000, "degenerate: nothing flagged"
+        assert (a == b).all(), f"alpha={alpha}: {(a != b).sum()} of {a.size} labels differ between culled and exact vote"
+
+
+def test_blockmin_image_equals_plain_lds_image_at_full_size(ltm, full):
+    """the workgroup-local arg-min pre-filter must give the same reprojection as the un-filtered exact kernel"""
+    out = {}
+    for variant in (2, 1):
+        ctx = _ctx(ltm, LTM_MAP_KERNEL=variant)
+        scans, poses, cmap = _load(ctx, full)
+        pts, off = ctx.reproject(cmap, poses, 3.0, 0, 64).download()
+        out[variant] = (pts, off)
+        ctx.close()
+    assert (out[1][1] == out[2][1]).all()
+    assert (out[1][0].view(np.uint32) == out[2][0].view(np.uint32)).all()
+    # size-independent properties of a reprojection: at most one point per pixel, none of them is map point 0's pixel winner twice
+    off = out[2][1]
+    assert (np.diff(off.astype(np.int64)) <= 150 * 1080).all() and off[-1] > 0
+
+
+def test_partition_and_voxel_properties_at_full_size(ltm, full):
+    import torch
+    ctx = _ctx(ltm)
+    scans, poses, cmap = _load(ctx, full)
+    M = len(cmap)
+    full_lab = torch.zeros(M, dtype=torch.uint8, device="cuda")
+    ctx.visibility_vote(cmap, scans, poses, 0, poses.n, 2.5, 0.1, 0, full_lab.data_ptr())
+    union = torch.zeros(M, dtype=torch.uint8, device="cuda")
+    for a, b in ((0, 63), (63, 250), (250, 251), (251, 500)):          # shards of unequal size, as ranks would hold them
+        part = torch.zeros(M, dtype=torch.uint8, device="cuda")
+        ctx.visibility_vote(cmap, scans, poses, a, b, 2.5, 0.1, 0, part.data_ptr())
+        union = torch.maximum(union, part)
+    assert torch.equal(union, full_lab), "OR of shard labels != labels of the full pass"
+    kept, flagged = ctx.partition_by_labels(cmap, full_lab.data_ptr())
+    nf = int(full_lab.sum().item())
+    assert len(flagged) == nf and len(kept) == M - nf
+    k = kept.download()
+    src = cmap.download()
+    keep_idx = np.nonzero(full_lab.cpu().numpy() == 0)[0]
+    assert (k.view(np.uint32) == src[keep_idx].view(np.uint32)).all(), "partition must be an order-preserving gather"
+    # voxel grid: a second pass can only merge, and every output voxel is occupied exactly once (keys strictly increasing)
+    v1 = ctx.voxel_centroid(kept, 0.05)
+    v2 = ctx.voxel_centroid(v1, 0.05)
+    assert len(v2) <= len(v1) <= len(kept)
+    ctx.close()
