@@ -1,0 +1,109 @@
+// host_selftest.cpp -- CPU-only self test of the host plumbing (no GPU, no libltm_hip.so): PCD v0.7 reader/writer
+// (ascii, binary, binary_compressed), pose-line parsing, the YAML-subset parameter reader, keyframe selection quirks and
+// the VoxelGrid restatement.  Built as lt-mapper_amd/host/host_selftest and run by tests/test_host_cpp.py.
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <string>
+
+#include "removert/RosParamServer.h"
+#include "removert/utility.h"
+
+using namespace ltremovert;
+
+static int fails = 0;
+#define CHECK(cond)                                                              \
+    do {                                                                         \
+        if (!(cond)) { std::printf("FAIL %s:%d  %s\n", __FILE__, __LINE__, #cond); ++fails; } \
+    } while (0)
+
+// minimal LZF compressor (literal runs only -- a valid LZF stream) to fabricate a binary_compressed file
+static std::string lzf_literals(const std::string& in)
+{
+    std::string out;
+    for (size_t i = 0; i < in.size(); i += 32) {
+        const size_t n = std::min<size_t>(32, in.size() - i);
+        out.push_back((char)(n - 1));
+        out.append(in, i, n);
+    }
+    return out;
+}
+
+int main(int argc, char** argv)
+{
+    const std::string dir = argc > 1 ? argv[1] : "/tmp";
+    Cloud c;
+    for (int i = 0; i < 1000; ++i) c.push_back(PointType{0.1f * i, -0.25f * i, 1.0f / (i + 1), (float)(i % 256)});
+
+    // binary round trip, both layouts
+    std::string err;
+    CHECK(savePCDFileBinary(dir + "/a.pcd", c, false, &err));
+    CHECK(savePCDFileBinary(dir + "/b.pcd", c, true, &err));
+    Cloud r;
+    CHECK(loadPCDFile(dir + "/a.pcd", r, &err) && r.size() == c.size() && std::memcmp(r.data(), c.data(), c.size() * 16) == 0);
+    CHECK(loadPCDFile(dir + "/b.pcd", r, &err) && r.size() == c.size() && std::memcmp(r.data(), c.data(), c.size() * 16) == 0);
+    {
+        std::ifstream f(dir + "/b.pcd", std::ios::binary);
+        std::string head((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+        CHECK(head.find("WIDTH 1\nHEIGHT 1000\n") != std::string::npos);
+        CHECK(head.find("FIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n") != std::string::npos);
+    }
+    // ascii with an extra field and a different field order
+    {
+        std::ofstream f(dir + "/c.pcd");
+        f << "# .PCD v0.7\nVERSION 0.7\nFIELDS intensity x y z ring\nSIZE 4 4 4 4 2\nTYPE F F F F U\nCOUNT 1 1 1 1 1\nWIDTH 2\nHEIGHT 1\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS 2\nDATA ascii\n"
+          << "7 1.5 2.5 3.5 11\n9 -1 -2 -3 12\n";
+    }
+    CHECK(loadPCDFile(dir + "/c.pcd", r, &err) && r.size() == 2 && r[0].x == 1.5f && r[0].intensity == 7.0f && r[1].z == -3.0f && r[1].intensity == 9.0f);
+    // binary_compressed: structure-of-arrays payload, LZF literal stream
+    {
+        std::string soa;
+        for (int fld = 0; fld < 4; ++fld)
+            for (const PointType& p : c) { const float v = fld == 0 ? p.x : fld == 1 ? p.y : fld == 2 ? p.z : p.intensity; soa.append(reinterpret_cast<const char*>(&v), 4); }
+        const std::string comp = lzf_literals(soa);
+        std::ofstream f(dir + "/d.pcd", std::ios::binary);
+        f << "VERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 1000\nHEIGHT 1\nPOINTS 1000\nDATA binary_compressed\n";
+        const uint32_t cs = (uint32_t)comp.size(), us = (uint32_t)soa.size();
+        f.write(reinterpret_cast<const char*>(&cs), 4); f.write(reinterpret_cast<const char*>(&us), 4); f.write(comp.data(), cs);
+    }
+    CHECK(loadPCDFile(dir + "/d.pcd", r, &err) && r.size() == c.size() && std::memcmp(r.data(), c.data(), c.size() * 16) == 0);
+    CHECK(!loadPCDFile(dir + "/does_not_exist.pcd", r, &err) && !err.empty());
+
+    // pose lines (Session.cpp:102-114)
+    auto v = splitPoseLine("1 0 0 1.5 0 1 0 -2 0 0 1 0.25", ' ');
+    CHECK(v.size() == 12 && v[3] == 1.5 && v[7] == -2.0 && v[11] == 0.25);
+    double m[16] = {0, -1, 0, 3, 1, 0, 0, -4, 0, 0, 1, 5, 0, 0, 0, 1}, inv[16];
+    CHECK(inverse4x4(m, inv) && std::fabs(inv[3] - 4.0) < 1e-12 && std::fabs(inv[7] - 3.0) < 1e-12 && std::fabs(inv[11] + 5.0) < 1e-12);
+    double sing[16] = {0};
+    CHECK(!inverse4x4(sing, inv));
+    CHECK(resetRimgSize({50.0f, 360.0f}, 2.5f) == std::make_pair(125, 900));
+
+    // YAML subset: the reference's own parameter file layout (config/params_ltmapper.yaml)
+    {
+        std::ofstream f(dir + "/p.yaml");
+        f << "removert:\n\n  # comment\n  isScanFileKITTIFormat: false\n  saveMapPCD: true \n  save_pcd_directory: \"/tmp/out dir/\" # trailing comment\n"
+          << "  sequence_vfov: 50 # including upper\n  ExtrinsicLiDARtoPoseBase: [1.0, 0.0, 0.0, 0.5, \n                             0.0, 1.0, 0.0, 0.0, \n"
+          << "                             0.0, 0.0, 1.0, 0.0, \n                             0.0, 0.0, 0.0, 1.0]\n  start_idx: 1100 # change this\n"
+          << "  remove_resolution_list: [2.5, 2.0, 1.5] # for Ouster\n  num_nn_points_within: 2\n  dist_nn_points_within: 0.01\nother:\n  start_idx: 7\n";
+    }
+    RosParamServer::setParamFile(dir + "/p.yaml");
+    RosParamServer P;
+    CHECK(!P.isScanFileKITTIFormat_ && P.kFlagSaveMapPointcloud && P.save_pcd_directory_ == "/tmp/out dir/");
+    CHECK(P.kVFOV == 50.0f && P.kHFOV == 360.0f && P.start_idx_ == 1100 && P.end_idx_ == 100);
+    CHECK(P.remove_resolution_list_.size() == 3 && P.remove_resolution_list_[2] == 1.5f);
+    CHECK(P.kNumKnnPointsToCompare == 2 && P.kScanKnnAndMapKnnAvgDiffThreshold == 0.01f && P.kDownsampleVoxelSize == 0.05f);
+    CHECK(P.kSE3MatExtrinsicLiDARtoPoseBase[3] == 0.5 && std::fabs(P.kSE3MatExtrinsicPoseBasetoLiDAR[3] + 0.5) < 1e-15);
+    CHECK(!P.gpu_use_self_removert_ && P.keyframe_gap_ == 10 && P.kNumOmpCores == 4);
+
+    // VoxelGrid restatement: centroid per voxel in linear-index order; overflow early-out returns the input
+    Cloud g = {{0.01f, 0.01f, 0.01f, 1}, {0.02f, 0.02f, 0.02f, 3}, {1.01f, 0.0f, 0.0f, 5}}, o;
+    voxelGridFilter(g, 0.05f, o);
+    CHECK(o.size() == 2 && o[0].intensity == 2.0f && o[1].x == 1.01f);
+    Cloud big = {{-1000.f, -1000.f, -100.f, 0}, {1000.f, 1000.f, 100.f, 0}};
+    voxelGridFilter(big, 0.05f, o);
+    CHECK(o.size() == 2 && o[0].x == -1000.f);
+
+    std::printf(fails ? "host_selftest: %d FAILED\n" : "host_selftest: all checks passed\n", fails);
+    return fails ? 1 : 0;
+}
