@@ -30,10 +30,13 @@ import torch  # noqa: E402
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
 WORKLOADS = {
-    # name: (sensor, keyframes per session, 3-res?)
-    "lot-2x500-os1-64-3res": ("os1-64", 500, True),
-    "lot-2x50-os1-64-1res": ("os1-64", 50, False),      # configs[0] shape (plumbing case)
-    "lot-2x100-small-3res": ("small", 100, True),       # quick check
+    # name: (sensor, keyframes per session, 3-res?, scene, kf spacing [m], voxel [m], kNN k, kNN thr)
+    "lot-2x500-os1-64-3res": ("os1-64", 500, True, "lot", 1.0, 0.05, 2, 0.01),        # BASELINE configs[1] (default)
+    "lot-2x50-os1-64-1res": ("os1-64", 50, False, "lot", 1.0, 0.05, 2, 0.01),         # configs[0] shape (plumbing case)
+    "lot-2x100-small-3res": ("small", 100, True, "lot", 1.0, 0.05, 2, 0.01),          # quick check
+    "street-2x2000-hdl64e-1res": ("hdl-64e", 2000, False, "street", 1.0, 0.05, 2, 0.01),   # configs[3], KITTI-scale
+    "street-2x2000-hdl64e-3res": ("hdl-64e", 2000, True, "street", 1.0, 0.05, 2, 0.01),
+    "street-2x200-mls-knn": ("mls", 200, False, "street", 2.0, 0.1, 2, 0.04),         # configs[4], dense MLS kNN stress
 }
 
 
@@ -70,17 +73,17 @@ def main():
     from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
     from tools import synth
 
-    sensor, n_kf, three_res = WORKLOADS[args.workload]
+    sensor, n_kf, three_res, scene, spacing, voxel, knn_k, knn_thr = WORKLOADS[args.workload]
     dev = f"cuda:{local_rank}"
     t0 = time.perf_counter()
     # synthetic sessions 01 / 02, generated on the GPU, already in HBM when the timed region starts
-    sess_t = [synth.make_session(s, n_kf, sensor, device=dev) for s in (1, 2)]
+    sess_t = [synth.make_session(s, n_kf, sensor, device=dev, scene=scene, kf_spacing=spacing) for s in (1, 2)]
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
 
     ctx = capi.Context(vfov=50.0, hfov=360.0, device=local_rank)
     P = Params(gpu_use_self_removert=three_res, remove_resolution_list=[2.5, 2.0, 1.5] if three_res else [2.5],
-               num_nn_points_within=2, dist_nn_points_within=0.01, downsample_voxel_size=0.05)
+               num_nn_points_within=knn_k, dist_nn_points_within=knn_thr, downsample_voxel_size=voxel)
 
     def fresh_sessions():
         out = []
@@ -150,7 +153,7 @@ def main():
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args.cpu_stride, args.verbose)
+        cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args.cpu_stride, args.verbose, knn_k, knn_thr, voxel)
 
     if rank == 0:
         M_c = len(last.outputs["OriginalNoisyCentralMapGlobal"])
@@ -160,9 +163,9 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 rigid transforms, u64 range|index atomics)", "data": "synthetic (tools/synth.py synth-v1, seed 20250224)",
-            "config": {"workload": args.workload, "sessions": "lot 01 vs 02", "keyframes_per_session": n_kf, "sensor": sensor,
+            "config": {"workload": args.workload, "sessions": f"{scene} 01 vs 02", "keyframes_per_session": n_kf, "sensor": sensor,
                        "remove_resolution_list": P.remove_resolution_list if three_res else [2.5], "self_removert": three_res,
-                       "knn": {"k": 2, "thr": 0.01}, "voxel": 0.05, "map_points": [M_c, M_q],
+                       "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points": [M_c, M_q],
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
                        "parallelism": f"keyframe-sharded x{world} (label all-reduce + scan all-gather)" if world > 1 else "single GPU",
                        "step": "makeGlobalMap + Removerter::run Steps 1-3, inputs resident in HBM"},
@@ -189,7 +192,7 @@ def measured_traffic(cls):
         return None
 
 
-def run_cpu_baseline(sess_t, three_res, n_kf, stride, verbose):
+def run_cpu_baseline(sess_t, three_res, n_kf, stride, verbose, knn_k=2, knn_thr=0.01, voxel=0.05):
     """CPU oracle (port of the reference's algorithm, single thread) on a bounded sample: the whole pipeline runs on
     the full-size sessions but every per-keyframe loop visits only each `stride`-th keyframe; per-keyframe stage times are
     scaled by the true visit ratio, whole-map stages (voxel grids, kd-tree builds) are timed in full."""
@@ -205,7 +208,7 @@ def run_cpu_baseline(sess_t, three_res, n_kf, stride, verbose):
     stride = max(1, min(stride, n_kf))
     visited = len(range(0, n_kf, stride))
     scale = n_kf / visited
-    P = orc.make_params(k=2, knn_thr=0.01, use_self_removert=three_res, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,),
+    P = orc.make_params(k=knn_k, knn_thr=knn_thr, voxel=voxel, use_self_removert=three_res, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,),
                         threads=1, kf_sample_stride=stride)
     t0 = time.perf_counter()
     res = orc.pipeline_run(P, C, Q)

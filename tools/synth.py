@@ -98,6 +98,66 @@ def _loop_pose(s):
     return -(hx - r), -hy, 0.0
 
 
+# ---------------------------------------------------------------------------------------- scene `street`
+STREET_N = 6            # blocks per side
+STREET_PITCH = 120.0    # 100 m block + 20 m road
+
+
+def _street_static_boxes(session, seed):
+    """buildings (one per block, 80 x 80 m footprint, 8-30 m high) + cars parked along the kerbs of the east-west roads"""
+    boxes = []
+    for i in range(STREET_N):
+        for j in range(STREET_N):
+            cx, cy = 60.0 + STREET_PITCH * i + 10.0, 60.0 + STREET_PITCH * j + 10.0
+            h = 8.0 + 22.0 * _hash01(seed, 31, i, j)
+            boxes.append([cx - 40.0, cy - 40.0, 0.0, cx + 40.0, cy + 40.0, h])
+    for j in range(STREET_N + 1):                       # east-west roads centred on y = j*120
+        for side in (-1, 1):
+            for b in range(int(STREET_N * STREET_PITCH / 6.0)):
+                bay = (j * 2 + (side > 0)) * 1000 + b
+                epoch = 0
+                for s in range(1, session + 1):
+                    if _hash01(seed, 37, bay, s) < 0.25:
+                        epoch = s
+                if _hash01(seed, 41, bay, epoch) < 0.35:
+                    x0, y0 = 3.0 + 6.0 * b, STREET_PITCH * j + side * 7.5
+                    boxes.append([x0 - 2.25, y0 - 0.9, 0.0, x0 + 2.25, y0 + 0.9, 1.5])
+    return boxes
+
+
+def _street_movers(t, seed):
+    boxes = []
+    for m in range(30):
+        j = m % (STREET_N + 1)
+        y = STREET_PITCH * j + (2.0 if m % 2 else -2.0)
+        span = STREET_N * STREET_PITCH
+        x0 = span * _hash01(seed, 43, m)
+        if m < 18:
+            v, hx, hy, hz = 1.4 * (1 if m % 2 == 0 else -1), 0.3, 0.3, 1.7
+            y += 5.0 if m % 4 < 2 else -5.0
+        else:
+            v, hx, hy, hz = 8.0 * (1 if m % 2 == 0 else -1), 2.25, 0.9, 1.5
+        x = (x0 + v * t) % span
+        boxes.append([x - hx, y - hy, 0.0, x + hx, y + hy, hz])
+    return boxes
+
+
+def _street_pose(s):
+    """lawn-mower path along the east-west roads, connected on the outer north-south roads"""
+    span = STREET_N * STREET_PITCH
+    leg = span + STREET_PITCH
+    total = leg * (STREET_N + 1)
+    s = s % total
+    j = int(s // leg)
+    u = s - j * leg
+    east = (j % 2 == 0)
+    if u <= span:
+        x = u if east else span - u
+        return x, STREET_PITCH * j, 0.0 if east else math.pi
+    x = span if east else 0.0
+    return x, STREET_PITCH * j + (u - span), 0.5 * math.pi
+
+
 def _round_sig(x, sig=6):
     x = np.asarray(x, dtype=np.float64)
     out = np.zeros_like(x)
@@ -108,36 +168,40 @@ def _round_sig(x, sig=6):
     return out
 
 
-def _cast(o, d, boxes):
+def _cast(o, d, boxes, chunk=131072):
     """o (3,), d (R,3) float64, boxes (B,6): nearest positive slab hit per ray -> (R,) range (inf if none)"""
-    inv = 1.0 / d                                   # (R,3); zeros give inf, handled by min/max
-    t0 = (boxes[None, :, 0:3] - o[None, None, :]) * inv[:, None, :]
-    t1 = (boxes[None, :, 3:6] - o[None, None, :]) * inv[:, None, :]
-    tn = torch.minimum(t0, t1).amax(dim=2)
-    tf = torch.maximum(t0, t1).amin(dim=2)
-    hit = (tn <= tf) & (tn > 0.5)
-    tn = torch.where(hit, tn, torch.full_like(tn, float("inf")))
-    return tn.amin(dim=1)
+    out = []
+    for a in range(0, d.shape[0], chunk):
+        inv = 1.0 / d[a:a + chunk]                  # (R,3); zeros give inf, handled by min/max
+        t0 = (boxes[None, :, 0:3] - o[None, None, :]) * inv[:, None, :]
+        t1 = (boxes[None, :, 3:6] - o[None, None, :]) * inv[:, None, :]
+        tn = torch.minimum(t0, t1).amax(dim=2)
+        tf = torch.maximum(t0, t1).amin(dim=2)
+        hit = (tn <= tf) & (tn > 0.5)
+        tn = torch.where(hit, tn, torch.full_like(tn, float("inf")))
+        out.append(tn.amin(dim=1))
+    return torch.cat(out) if len(out) > 1 else out[0]
 
 
 def make_session(session, n_kf, sensor="os1-64", seed=MASTER_SEED, device="cpu", scene="lot", kf_spacing=1.0,
                  max_range=120.0, noise=0.02, dropout=0.05, pose_noise=True):
     """returns dict(scans (P,4) f32, offsets (n_kf+1) u64, poses (n_kf,16) f64, inv (n_kf,16) f64, names)
     with scans/offsets as torch tensors on `device` and poses as numpy."""
-    assert scene == "lot"
+    assert scene in ("lot", "street")
     rings, n_az, el_lo, el_hi = SENSORS[sensor] if isinstance(sensor, str) else sensor
     dev = torch.device(device)
     f64 = torch.float64
     el = torch.deg2rad(torch.linspace(el_lo, el_hi, rings, dtype=f64, device=dev))
     az0 = torch.arange(n_az, dtype=f64, device=dev) * (2 * math.pi / n_az) - math.pi
     room = torch.tensor([[-60.0, -40.0, 0.0, 60.0, 40.0, 10.0]], dtype=f64, device=dev)
-    static_boxes = _bay_boxes(session, seed)
+    static_boxes = _bay_boxes(session, seed) if scene == "lot" else _street_static_boxes(session, seed)
+    static_t = torch.tensor(static_boxes, dtype=f64, device=dev)
     gen = torch.Generator(device=dev)
     scans, offsets, poses = [], [0], []
     for kf in range(n_kf):
         gen.manual_seed((seed * 1000003 + session * 65537 + kf) & 0x7FFFFFFFFFFF)
         s_arc = 37.0 * session + kf_spacing * kf
-        x, y, yaw = _loop_pose(s_arc)
+        x, y, yaw = _loop_pose(s_arc) if scene == "lot" else _street_pose(s_arc)
         o = torch.tensor([x, y, 1.9], dtype=f64, device=dev)
         phase = float(_hash01(seed, 17, session, kf)) * (2 * math.pi / n_az)
         az = az0 + phase
@@ -145,15 +209,26 @@ def make_session(session, n_kf, sensor="os1-64", seed=MASTER_SEED, device="cpu",
         dl = torch.stack([(ce * torch.cos(az)[None, :]), (ce * torch.sin(az)[None, :]), se.expand(rings, n_az)], dim=2).reshape(-1, 3)
         cy, sy = math.cos(yaw), math.sin(yaw)
         dw = torch.stack([cy * dl[:, 0] - sy * dl[:, 1], sy * dl[:, 0] + cy * dl[:, 1], dl[:, 2]], dim=1)
-        # room: exit distance of the enclosing box; a ceiling exit is sky (no return)
-        inv = 1.0 / dw
-        t0 = (room[0, 0:3][None, :] - o[None, :]) * inv
-        t1 = (room[0, 3:6][None, :] - o[None, :]) * inv
-        tmax = torch.maximum(t0, t1)
-        t_exit, axis = tmax.min(dim=1)
-        sky = (axis == 2) & (dw[:, 2] > 0)
-        rng = torch.where(sky, torch.full_like(t_exit, float("inf")), t_exit)
-        boxes = torch.tensor(static_boxes + _mover_boxes(s_arc, seed), dtype=f64, device=dev)
+        if scene == "lot":
+            # room: exit distance of the enclosing box; a ceiling exit is sky (no return)
+            inv = 1.0 / dw
+            t0 = (room[0, 0:3][None, :] - o[None, :]) * inv
+            t1 = (room[0, 3:6][None, :] - o[None, :]) * inv
+            tmax = torch.maximum(t0, t1)
+            t_exit, axis = tmax.min(dim=1)
+            sky = (axis == 2) & (dw[:, 2] > 0)
+            rng = torch.where(sky, torch.full_like(t_exit, float("inf")), t_exit)
+            movers = _mover_boxes(s_arc, seed)
+        else:
+            # open scene: ground plane z = 0 below the horizon, sky above
+            tg = -o[2] / dw[:, 2]
+            rng = torch.where(dw[:, 2] < 0, tg, torch.full_like(tg, float("inf")))
+            movers = _street_movers(s_arc, seed)
+        boxes = torch.cat([static_t, torch.tensor(movers, dtype=f64, device=dev)], dim=0)
+        if scene == "street":   # only boxes within reach of this pose can be hit: keeps the ray x box tensor small
+            c = 0.5 * (boxes[:, 0:2] + boxes[:, 3:5]); h = 0.5 * (boxes[:, 3:5] - boxes[:, 0:2])
+            near = (torch.clamp((c - o[None, 0:2]).abs() - h, min=0.0).norm(dim=1) < max_range)
+            boxes = boxes[near]
         rng = torch.minimum(rng, _cast(o, dw, boxes))
         u = torch.rand(rng.shape[0], 3, generator=gen, device=dev, dtype=f64)
         g4 = torch.rand(rng.shape[0], 4, generator=gen, device=dev, dtype=f64).sum(dim=1)   # Irwin-Hall(4): var 1/3
