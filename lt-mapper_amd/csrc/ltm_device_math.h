@@ -207,6 +207,16 @@ __device__ __forceinline__ float atan2_approx(float y, float x)
     return (y < 0.0f) ? -r : r;
 }
 
+// same for x >= 0 (elevation: second argument is a norm)
+__device__ __forceinline__ float atan2_approx_xpos(float y, float x)
+{
+    const float ay = fabsf(y);
+    const float mx = fmaxf(x, ay), mn = fminf(x, ay);
+    float r = atan_unit_approx(mn * __builtin_amdgcn_rcpf(mx));
+    r = (ay > x) ? (1.57079632679f - r) : r;
+    return (y < 0.0f) ? -r : r;
+}
+
 // PCL transformPointCloud<PointXYZI,double>: (float)(((m0*x + m1*y) + m2*z) + m3) per row, double math.
 struct Mat34 { double m[12]; };
 

@@ -241,7 +241,9 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // not (culled points are absent), which is why ltm_debug_range_image / reprojection / mode 1 use k_map_rimg_lds.
 static constexpr float kCullEpsPx = 3.0e-3f;
 
-struct CullCand { int r0, r1, c0, c1; float r_lo; bool unusual; };
+// rb/cb: the pixel if it is certain; multi: within kCullEpsPx of a rounding boundary (candidates r0..r1 x c0..c1, filled by
+// cull_expand); r_lo: lower bound of the exact range (upper bound = r_lo * (1 + 3e-6)); unusual: outside the fast forms' domain
+struct CullCand { int rb, cb, r0, r1, c0, c1; float rowh, colh, r_lo; bool multi, unusual; };
 
 // p' = A (p - c): the inverse pose (composed with base->lidar) rewritten around the sensor position c so that the
 // subtraction happens between nearby numbers; c is carried as a float-float pair.  Relative error of p' <= 5e-7
@@ -260,28 +262,37 @@ __device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, flo
 __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale)
 {
     CullCand cc;
-    const uint32_t ix = f2u(p.x) & 0x7fffffffu, iy = f2u(p.y) & 0x7fffffffu, iz = f2u(p.z) & 0x7fffffffu;
     const float xy2 = __builtin_fmaf(p.x, p.x, p.y * p.y);
     const float rxy = __builtin_amdgcn_sqrtf(xy2);
     const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(p.z, p.z, xy2));
-    // fast forms cover: x, y, z finite and non-zero, moderate magnitudes (no under/overflow in the squares)
-    const bool usual = (ix - 0x20000000u < 0x3e000000u) & (iy - 0x20000000u < 0x3e000000u) & (iz - 0x20000000u < 0x3e000000u);
-    cc.unusual = !usual | !(r < 9000.0f);
     const float az = atan2_approx(p.y, p.x);
-    const float el = atan2_approx(p.z, rxy);
+    const float el = atan2_approx_xpos(p.z, rxy);
     // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
-    const float rowh = __builtin_fmaf(-el, row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5
-    const float colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
-    const float rfl = floorf(rowh), cfl = floorf(colh);
-    const float rfr = rowh - rfl, cfr = colh - cfl;                             // in [0,1): distance above the rounding boundary
+    cc.rowh = __builtin_fmaf(-el, row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5: floor() of it is the rounded pixel
+    cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
+    // Outside the fast forms' domain (every such case ends in the exact path): y == +-0 (the sign of a zero y picks the side of
+    // the +-180 deg seam in the reference), anything that made a NaN/inf (x = y = 0, under/overflowing squares), absurd ranges.
+    cc.unusual = (p.y == 0.0f) | !(fmaxf(fabsf(cc.rowh), fabsf(cc.colh)) < 1.0e9f) | !(r < 9000.0f);
+    const float rfr = __builtin_amdgcn_fractf(cc.rowh), cfr = __builtin_amdgcn_fractf(cc.colh);   // distance above the rounding boundary
+    cc.multi = (fabsf(rfr - 0.5f) > 0.5f - kCullEpsPx) | (fabsf(cfr - 0.5f) > 0.5f - kCullEpsPx);
+    cc.rb = min(max((int)floorf(cc.rowh), 0), g.rows - 1);
+    cc.cb = min(max((int)floorf(cc.colh), 0), g.cols - 1);
+    cc.r0 = cc.r1 = cc.rb; cc.c0 = cc.c1 = cc.cb;
+    cc.r_lo = r * (1.0f - 1.5e-6f);
+    return cc;
+}
+
+// candidate pixel rectangle of a point that sits within kCullEpsPx of a rounding boundary (rare)
+__device__ __forceinline__ void cull_expand(const RimgGeom& g, CullCand& cc)
+{
+    const float rfl = floorf(cc.rowh), cfl = floorf(cc.colh);
+    const float rfr = cc.rowh - rfl, cfr = cc.colh - cfl;
     const int rc = (int)rfl, ccn = (int)cfl;
     const int rmax = g.rows - 1, cmax = g.cols - 1;
     cc.r0 = min(max(rc - (rfr < kCullEpsPx ? 1 : 0), 0), rmax);
     cc.r1 = min(max(rc + (rfr > 1.0f - kCullEpsPx ? 1 : 0), 0), rmax);
     cc.c0 = min(max(ccn - (cfr < kCullEpsPx ? 1 : 0), 0), cmax);
     cc.c1 = min(max(ccn + (cfr > 1.0f - kCullEpsPx ? 1 : 0), 0), cmax);
-    cc.r_lo = r * (1.0f - 1.5e-6f);
-    return cc;
 }
 
 __device__ __forceinline__ bool cull_matters(const CullCand& cc, const uint32_t* __restrict__ scan, int cols, float thr)
@@ -349,14 +360,14 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 const float3 p = xform_approx(ap, pt[u], ok);
                 cc[u] = cull_candidates(g, p, row_scale, col_scale);
                 cc[u].unusual |= !ok;
-                s0[u] = scank[cc[u].r0 * g.cols + cc[u].c0];
+                s0[u] = scank[cc[u].rb * g.cols + cc[u].cb];
             }
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 const float thr_lo = thr - (1.0e-3f + cc[u].r_lo * 3.0e-6f);
                 const float s = u2f(s0[u]);
                 bool m = cc[u].unusual | ((s < 9000.0f) & ((s - cc[u].r_lo) > thr_lo));
-                if (__builtin_expect((cc[u].r1 != cc[u].r0) | (cc[u].c1 != cc[u].c0), 0)) m |= cull_matters(cc[u], scank, g.cols, thr);
+                if (__builtin_expect(cc[u].multi & !m, 0)) { cull_expand(g, cc[u]); m = cull_matters(cc[u], scank, g.cols, thr); }
                 if (m & live[u]) queue[atomicAdd(&qcount, 1u)] = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
             }
         }
@@ -442,8 +453,9 @@ k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, const float* 
     bool ok = true;
     if (ap) { pe = xform(to_dev(T), pe); pa = xform_approx(ap, p4, ok); }
     const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
-    const CullCand cc = cull_candidates(g, pa, row_scale, col_scale);
+    CullCand cc = cull_candidates(g, pa, row_scale, col_scale);
     if (cc.unusual || !ok) return;
+    if (cc.multi) cull_expand(g, cc);
     const Sph s = cart2sph(pe.x, pe.y, pe.z);
     int row, col;
     pixel_row_col(g, s.az, s.el, row, col);
@@ -509,9 +521,9 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         const CullCand cc = cull_candidates(g, p, row_scale, col_scale);
         rlo[j] = cc.r_lo;
         slot_of[j] = 0xffff;
-        if (cc.unusual | !ok | (cc.r0 != cc.r1) | (cc.c0 != cc.c1)) continue;
-        const uint32_t px = (uint32_t)(cc.r0 * g.cols + cc.c0);
-        const int slot = ((cc.r0 & 15) << 6) | (cc.c0 & 63);
+        if (cc.unusual | !ok | cc.multi) continue;
+        const uint32_t px = (uint32_t)(cc.rb * g.cols + cc.cb);
+        const int slot = ((cc.rb & 15) << 6) | (cc.cb & 63);
         uint32_t t = tags[slot];
         if (t == kEmptyTag) {
             const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
