@@ -6,6 +6,7 @@ Layout:
   capi.py    ctypes binding of the C ABI (tests, bench.py)
   removerter.py  Python mirror of Removerter::run() over the C ABI (bench.py, parity tests)
   dist.py    keyframe sharding + label/all-gather exchange over torch.distributed (RCCL / gloo)
+  cascade.py lifelong loop: scans_updated of run j become the central session of run j+1 (configs[2])
 
 There is no CPU implementation in this package: every stage runs in libltm_hip.so on a gfx950 device.
 """

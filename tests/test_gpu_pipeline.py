@@ -101,3 +101,48 @@ def test_sharded_ops_world1_rccl_plumbing(ltm, orc, small_pair):
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_cascade_feeds_updated_scans_forward(ltm, orc):
+    """configs[2] in miniature: 01 -> (02, 03); run j+1 must see exactly the scans_updated of run j as its central session"""
+    from ltmapper_amd.cascade import run_cascade
+    from ltmapper_amd.removerter import HipOps, Params
+    from tools import synth
+    S = [synth.to_numpy(synth.make_session(s, 5, "small")) for s in (1, 2, 3)]
+    ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    up = lambda T: (ctx.upload_scans(T["scans"], T["offsets"]), ctx.poses(T["poses"], T["inv"]))
+    c_scans, c_poses = up(S[0])
+    runs = run_cascade(HipOps(ctx), Params(), c_scans, c_poses, [up(S[1]), up(S[2])])
+    assert len(runs) == 2
+    # oracle: run 1, then run 2 with central := scans_updated of run 1 (same central poses)
+    ref1 = orc.pipeline_run(orc.make_params(), S[0], S[1])
+    upd_pts, upd_off = ref1.scanset("scans_updated")
+    C2 = dict(scans=upd_pts, offsets=upd_off, poses=S[0]["poses"], inv=S[0]["inv"])
+    ref2 = orc.pipeline_run(orc.make_params(), C2, S[2])
+    _compare(runs[0], ref1)
+    _compare(runs[1], ref2)
+    ctx.close()
+
+
+def test_reproject_and_vote_across_small_keyframe_batches(ltm, orc, small_pair):
+    """max_kf_batch smaller than the keyframe count: images are processed in several batches and stitched"""
+    import numpy as np
+    from conftest import assert_clouds_equal
+    C, _ = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], np.eye(4)), 0.05)
+    ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0, max_kf_batch=4)      # 6 keyframes -> batches of 4 + 2
+    g = ctx.reproject(ctx.upload(cmap), ctx.poses(C["poses"], C["inv"]), 3.0)
+    g_pts, g_off = g.download()
+    o_pts, o_off = orc.reproject(cmap, C["inv"], np.eye(4), 50.0, 360.0, 3.0)
+    assert (g_off == o_off).all()
+    assert_clouds_equal(g_pts, o_pts, "reprojection stitched over batches")
+    # the scan-image cache must not leak between scan sets or survive a clear
+    scans = ctx.upload_scans(C["scans"], C["offsets"])
+    poses = ctx.poses(C["poses"], C["inv"])
+    a = ctx.visibility_partition(ctx.upload(cmap), scans, poses, 2.5, 0.1, 0, want_labels=True)[2]
+    b = ctx.visibility_partition(ctx.upload(cmap), scans, poses, 2.5, 0.1, 0, want_labels=True)[2]   # served from the cache
+    ctx.clear_caches()
+    c3 = ctx.visibility_partition(ctx.upload(cmap), scans, poses, 2.5, 0.1, 0, want_labels=True)[2]
+    want = orc.vote_labels(cmap, C["scans"], C["offsets"], C["inv"], np.eye(4), 50.0, 360.0, 2.5, 0.1, 0)
+    assert (a == want).all() and (b == want).all() and (c3 == want).all()
+    ctx.close()
