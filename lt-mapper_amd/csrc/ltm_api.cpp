@@ -99,7 +99,7 @@ struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = n
 struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0; };
 // scan2RangeImg depends only on (scan set, image shape, keyframe range): the remove / revert / remove passes of one
 // resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
-struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; size_t bytes; uint64_t stamp; };
+struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; };
 struct Pending { int cls; hipEvent_t a, b; };
 
 } // namespace
@@ -297,7 +297,20 @@ void approx_pose(const double* b2l16, const double* inv16, float* out)
         out[12 + r] = (float)(cr - (double)out[9 + r]);
         for (int k = 0; k < 3; ++k) out[3 * r + k] = (float)T[4 * r + k];
     }
-    out[15] = 1.0f;
+    // out[15] doubles as a lower bound of the smallest singular value of A (Gershgorin on A^T A, rounded down): the tile
+    // range cull needs |A v| >= smin |v|.  Poses from 6-significant-digit text are rotations up to ~1e-6.
+    double gmin = 1e300;
+    for (int a2 = 0; a2 < 3; ++a2) {
+        double diag = 0, off = 0;
+        for (int b2 = 0; b2 < 3; ++b2) {
+            double g2 = 0;
+            for (int r = 0; r < 3; ++r) g2 += T[4 * r + a2] * T[4 * r + b2];
+            if (a2 == b2) diag = g2; else off += std::fabs(g2);
+        }
+        gmin = std::min(gmin, diag - off);
+    }
+    const double smin = gmin > 0.25 ? std::sqrt(gmin) * (1.0 - 1e-6) : 0.0;
+    out[15] = smin > 0.5 ? (float)std::nextafter((float)smin, 0.0f) : 1.0e-30f;   // tiny = usable transform, no tile cull
 }
 
 // utility.cpp:222-236 resetRimgSize
@@ -351,17 +364,17 @@ size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, siz
 void scan_cache_drop(ltm_ctx* c, uint64_t ss_handle)
 {
     for (size_t i = 0; i < c->scan_cache.size();) {
-        if (ss_handle == 0 || c->scan_cache[i].ss == ss_handle) { c->pool.free(c->scan_cache[i].buf); c->scan_cache.erase(c->scan_cache.begin() + i); }
+        if (ss_handle == 0 || c->scan_cache[i].ss == ss_handle) { c->pool.free(c->scan_cache[i].buf); c->pool.free(c->scan_cache[i].smax); c->scan_cache.erase(c->scan_cache.begin() + i); }
         else ++i;
     }
 }
 
 // returns the finished scan range images of keyframes [kb, kb+nb) (cached or freshly computed and then cached)
-const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size_t kb, size_t nb, const Geom& g)
+const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size_t kb, size_t nb, const Geom& g, const uint32_t** smax_out)
 {
     const size_t npx = (size_t)g.rows * g.cols;
     for (ScanImgEntry& e : c->scan_cache)
-        if (e.ss == ss_handle && e.rows == g.rows && e.cols == g.cols && e.kb == kb && e.nb == nb) { e.stamp = ++c->scan_cache_stamp; return e.buf; }
+        if (e.ss == ss_handle && e.rows == g.rows && e.cols == g.cols && e.kb == kb && e.nb == nb) { e.stamp = ++c->scan_cache_stamp; *smax_out = e.smax; return e.buf; }
     const size_t bytes = nb * npx * sizeof(uint32_t);
     size_t held = 0;
     for (const ScanImgEntry& e : c->scan_cache) held += e.bytes;
@@ -370,16 +383,20 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
         for (size_t i = 1; i < c->scan_cache.size(); ++i) if (c->scan_cache[i].stamp < c->scan_cache[lru].stamp) lru = i;
         held -= c->scan_cache[lru].bytes;
         c->pool.free(c->scan_cache[lru].buf);
+        c->pool.free(c->scan_cache[lru].smax);
         c->scan_cache.erase(c->scan_cache.begin() + lru);
     }
     uint32_t* buf = reinterpret_cast<uint32_t*>(c->pool.alloc(bytes));
+    uint32_t* smax = reinterpret_cast<uint32_t*>(c->pool.alloc(nb * sizeof(uint32_t)));
     const uint64_t first = ss.off[kb], npts = ss.off[kb + nb] - first;
     {
         ProfScope p(c, "vote_scan", (double)npts, (double)npts * 16 + (double)(nb * npx) * 4);
         LTM_HIP(fill_u32(buf, kNoPointBits, nb * npx, c->stream));
-        LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, buf, c->stream));
+        LTM_HIP(hipMemsetAsync(smax, 0, nb * sizeof(uint32_t), c->stream));
+        LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, buf, smax, c->stream));
     }
-    c->scan_cache.push_back(ScanImgEntry{ss_handle, g.rows, g.cols, kb, nb, buf, bytes, ++c->scan_cache_stamp});
+    c->scan_cache.push_back(ScanImgEntry{ss_handle, g.rows, g.cols, kb, nb, buf, smax, bytes, ++c->scan_cache_stamp});
+    *smax_out = smax;
     return buf;
 }
 
@@ -396,9 +413,13 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
     const size_t npx = (size_t)g.rows * g.cols;
     const size_t KB = std::min(c->kf_batch, kf_end - kf_begin);
     DevBuf map_img(c, KB * npx * sizeof(uint64_t));
+    const size_t n_tiles = (map.n + 4095) / 4096;
+    DevBuf tb(c, n_tiles * 6 * sizeof(float));
+    if (mode == 0) LTM_HIP(tile_bounds(map.d, map.n, tb.as<float>(), c->stream));
     for (size_t kb = kf_begin; kb < kf_end; kb += KB) {
         const size_t nb = std::min(KB, kf_end - kb);
-        const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g);
+        const uint32_t* smax = nullptr;
+        const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g, &smax);
         {
             ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 8));
             LTM_HIP(fill_u64(map_img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
@@ -408,7 +429,7 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
             const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
             ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
             LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img,
-                                          thr, mode, map_img.as<uint64_t>(), c->stream));
+                                          mode == 0 ? tb.as<float>() : nullptr, smax, thr, mode, map_img.as<uint64_t>(), c->stream));
         }
         {
             ProfScope p(c, "vote_compare", (double)(nb * npx), (double)(nb * npx) * 12 + (double)nb * map.n / 8.0);
@@ -648,6 +669,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     if (const char* v = getenv("LTM_MAP_KERNEL")) set_map_kernel_variant(atoi(v));   // A/B switch for profiling
     if (const char* v = getenv("LTM_VOTE_CULL")) set_vote_cull(atoi(v));
     if (const char* v = getenv("LTM_KF_PER_BLOCK")) set_kf_per_block(atoi(v));
+    if (const char* v = getenv("LTM_TILE_CULL")) set_tile_cull(atoi(v));
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's
     // constants; they are enabled only if they reproduce the exact IEEE results for every input.
     {

@@ -24,8 +24,12 @@ hipError_t fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 
 // ---- projection / vote ----
 // scan2RangeImg for keyframes [kb, kb+nb): scan_img[(kf-kb)*npx + px] = min range bits
+// smax_bits (nb entries, zero-initialised by the caller, may be null): per keyframe the float bits of the largest scan range
 hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb,
-                             uint64_t first_pt, uint64_t n_pts, Geom g, uint32_t* scan_img, hipStream_t s);
+                             uint64_t first_pt, uint64_t n_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s);
+// bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
+hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);
+void set_tile_cull(int v);
 // transformGlobalMapToLocal + map2RangeImg: map_img[(kf-kb)*npx+px] = min (range_bits<<32 | idx)
 // inv_poses_dev: 12 doubles per keyframe (3x4 row-major).  b2l: 12 doubles, b2l_identity skips the arithmetic.
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
@@ -36,8 +40,8 @@ hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, s
 // vote form of the above: mode 0 may cull points that provably cannot be flagged (needs the finished scan images)
 // approx_poses_dev: 16 floats per keyframe {A[9], c_hi[3], c_lo[3], ok} with p_local ~= A (p - c) (see xform_approx)
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, float thr, int mode, uint64_t* map_img,
-                                 hipStream_t s);
+                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, const float* tile_bounds_dev,
+                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s);
 void set_vote_cull(int v);
 int vote_cull_enabled();
 void set_kf_per_block(int v);    // keyframes that share one map-tile read inside a workgroup (1, 2, 4, 8)

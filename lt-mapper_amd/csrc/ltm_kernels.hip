@@ -118,11 +118,75 @@ k_scan_rimg(const float4* __restrict__ scans, const uint64_t* __restrict__ offse
     img_min_u32(img + (lo - kb) * (size_t)(g.rows * g.cols) + px, f2u(s.r));
 }
 
-hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t first_pt,
-                             uint64_t n_pts, Geom g, uint32_t* scan_img, hipStream_t s)
+// smax[kf] = float bits of the largest VALID (< 9000) pixel of the finished scan image of keyframe kf: a map point farther than
+// smax - thr cannot be flagged in mode 0.  grid = (chunks, keyframes); positive floats order like their bit patterns.
+__global__ void __launch_bounds__(kBlock)
+k_image_max(const uint32_t* __restrict__ img, uint32_t npx, uint32_t* __restrict__ smax)
 {
-    if (!n_pts) return hipSuccess;
-    k_scan_rimg<<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, nb, first_pt, n_pts, g, scan_img);
+    __shared__ uint32_t sm[kBlock / 64];
+    const uint32_t* __restrict__ imgk = img + (size_t)blockIdx.y * npx;
+    uint32_t m = 0;
+    for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
+        const uint32_t v = imgk[i];
+        m = max(m, (v < 0x460ca000u /* 9000.0f */) ? v : 0u);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < kBlock / 64; ++w) m = max(m, sm[w]);
+        m = max(m, sm[0]);
+        if (m) atomicMax(smax + blockIdx.y, m);
+    }
+}
+
+hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t first_pt,
+                             uint64_t n_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s)
+{
+    if (n_pts) k_scan_rimg<<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, nb, first_pt, n_pts, g, scan_img);
+    if (smax_bits && nb) {
+        const uint32_t npx = (uint32_t)(g.rows * g.cols);
+        k_image_max<<<dim3(std::min<unsigned>(grid_for(npx, kBlock * 8), 64), (unsigned)nb), dim3(kBlock), 0, s>>>(scan_img, npx, smax_bits);
+    }
+    return hipGetLastError();
+}
+
+// axis-aligned bounds of every 4096-point map tile (map frame): 6 floats per tile {min xyz, max xyz}
+__global__ void __launch_bounds__(kBlock)
+k_tile_bounds(const float4* __restrict__ map, uint32_t M, float* __restrict__ bounds)
+{
+    __shared__ float smn[3][kBlock / 64], smx[3][kBlock / 64];
+    const uint32_t per_block = (uint32_t)kBlock * 16u;
+    const uint32_t base = blockIdx.x * per_block;
+    const uint32_t nloc = min(per_block, M - base);
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (uint32_t li = threadIdx.x; li < nloc; li += kBlock) {
+        const float4 p = map[base + li];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64)); }
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { smn[d][wave] = mn[d]; smx[d][wave] = mx[d]; }
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        float a = smn[d][0], b = smx[d][0];
+        for (int w = 1; w < kBlock / 64; ++w) { a = fminf(a, smn[d][w]); b = fmaxf(b, smx[d][w]); }
+        bounds[6 * (size_t)blockIdx.x + d] = a; bounds[6 * (size_t)blockIdx.x + 3 + d] = b;
+    }
+}
+hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s)
+{
+    if (!M) return hipSuccess;
+    const size_t per_block = (size_t)kBlock * 16;
+    k_tile_bounds<<<dim3((unsigned)((M + per_block - 1) / per_block)), dim3(kBlock), 0, s>>>(map, (uint32_t)M, bounds);
     return hipGetLastError();
 }
 
@@ -316,8 +380,8 @@ static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's
 template <bool B2L_IDENTITY>
 __global__ void __launch_bounds__(kBlock)
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const uint32_t* __restrict__ scan_img, float thr,
-                uint64_t* __restrict__ img)
+                uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const uint32_t* __restrict__ scan_img,
+                const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img)
 {
     __shared__ uint64_t vals[kCullSlots];
     __shared__ uint32_t tags[kCullSlots];
@@ -326,6 +390,29 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     if (!tk.valid) return;
+    if (tile_bounds) {
+        // Whole-tile range cull: no point of this tile can be nearer to the sensor than the distance from the sensor position
+        // to the tile's bounding box; if that already exceeds the keyframe's longest scan return (minus thr, with margins for a
+        // slightly non-orthonormal pose and float rounding) nothing here can be flagged and the workgroup is done.
+        const float* __restrict__ ap = approx_poses + 16 * (size_t)(kb + tk.kfb);
+        const float* __restrict__ tb = tile_bounds + 6 * (size_t)tk.tile;
+        float d2 = 0.0f, far2 = 0.0f;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const float c = ap[9 + d] + ap[12 + d];
+            const float lo = tb[d] - c, hi = c - tb[3 + d];
+            const float e = fmaxf(fmaxf(lo, hi), 0.0f);          // distance to the box along this axis
+            const float f = fmaxf(fabsf(lo), fabsf(hi));          // distance to its farthest face
+            d2 = __builtin_fmaf(e, e, d2);
+            far2 = __builtin_fmaf(f, f, far2);
+        }
+        // exact local range of any point of the tile: |A (p - c)| >= smin * |p - c| >= smin * dist(c, box); ap[15] = lower bound of smin
+        const float smin = ap[15];
+        const float smax = u2f(smax_bits[tk.kfb]);                // longest scan return of this keyframe (0 if none)
+        const float reach = fmaxf(smax - thr, 0.0f) + 1.0e-2f + smax * 1.0e-3f;
+        // far2 guard: beyond ~8.9 km the reference's "empty pixel = 10000" sentinel arithmetic could flag a point; never cull there
+        if (smin > 0.5f && far2 < 8.0e7f && d2 * smin * smin * 0.996f > reach * reach) return;
+    }
     for (int s = threadIdx.x; s < kCullSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
     if (threadIdx.x == 0) qcount = 0;
     __syncthreads();
@@ -422,21 +509,24 @@ hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s)
 
 static int g_kf_per_block = 8;         // keyframes that reuse one map tile on an XCD (tile_kf_of_block); env LTM_KF_PER_BLOCK
 void set_kf_per_block(int v) { g_kf_per_block = v < 1 ? 1 : (v > 64 ? 64 : v); }
+static int g_tile_cull = 1;   // whole-tile range cull inside k_vote_map_cull (env LTM_TILE_CULL)
+void set_tile_cull(int v) { g_tile_cull = v; }
 static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
 void set_vote_cull(int v) { g_vote_cull = v; }
 int vote_cull_enabled() { return g_vote_cull != 0; }
 
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, float thr, int mode, uint64_t* map_img,
-                                 hipStream_t s)
+                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, const float* tile_bounds_dev,
+                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s)
 {
     if (!M || !nb) return hipSuccess;
     if (mode != 0 || !g_vote_cull || !approx_poses_dev) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
     const unsigned kfg = (unsigned)g_kf_per_block;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-    if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, thr, map_img);
-    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, thr, map_img);
+    const float* tb = (g_tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
+    if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, tb, smax_bits_dev, thr, map_img);
+    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, tb, smax_bits_dev, thr, map_img);
     return hipGetLastError();
 }
 

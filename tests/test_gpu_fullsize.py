@@ -100,3 +100,26 @@ def test_partition_and_voxel_properties_at_full_size(ltm, full):
     v2 = ctx.voxel_centroid(v1, 0.05)
     assert len(v2) <= len(v1) <= len(kept)
     ctx.close()
+
+
+def test_tile_cull_equals_no_tile_cull_on_kitti_scale_street(ltm):
+    """street scene, 300 keyframes x 120 k rays: whole-tile range cull on/off must give identical labels (and be much faster)"""
+    import time
+    import torch
+    from tools import synth
+    S = synth.make_session(1, 300, "hdl-64e", device="cuda:0", scene="street", kf_spacing=2.0)
+    torch.cuda.synchronize()
+    out, dt = {}, {}
+    for tc in (1, 0):
+        ctx = _ctx(ltm, LTM_TILE_CULL=tc)
+        scans, poses, cmap = _load(ctx, S)
+        lab = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda")
+        ctx.visibility_vote(cmap, scans, poses, 0, poses.n, 2.5, 0.1, 0, lab.data_ptr())      # warm (scan images cached)
+        lab.zero_()
+        ctx.synchronize(); t0 = time.perf_counter()
+        ctx.visibility_vote(cmap, scans, poses, 0, poses.n, 2.5, 0.1, 0, lab.data_ptr())
+        ctx.synchronize(); dt[tc] = time.perf_counter() - t0
+        out[tc] = lab.cpu().numpy()
+        ctx.close()
+    assert out[1].sum() > 100 and (out[1] == out[0]).all()
+    print(f"tile cull: {dt[1] * 1e3:.1f} ms vs {dt[0] * 1e3:.1f} ms without")

@@ -273,3 +273,16 @@ def test_cull_projection_bounds_hold(gpu_ctx):
         for pts in (sets[0], sets[3], sets[4]):
             glob = (T[:3, :3] @ pts[:1_000_000].T).T + T[:3, 3]
             assert gpu_ctx.cull_check(glob.astype(np.float32), 2.5, Tinv) == 0
+
+
+def test_tile_range_cull_on_a_long_street(gpu_ctx, orc):
+    """a 300 m drive: most map tiles are out of reach of any single keyframe and are culled as a whole -- labels must not change"""
+    from tools import synth
+    S = synth.to_numpy(synth.make_session(1, 30, "small", scene="street", kf_spacing=10.0))
+    cmap = orc.voxel_centroid(orc.merge_to_global(S["scans"], S["offsets"], S["poses"], I4), 0.05)
+    ext = cmap[:, :2].max(0) - cmap[:, :2].min(0)
+    assert ext.max() > 350.0, "the map must be much larger than the 120 m sensor range for this test to mean anything"
+    want = orc.vote_labels(cmap, S["scans"], S["offsets"], S["inv"], I4, VFOV, HFOV, 2.5, 0.1, 0)
+    kept, flagged, got = gpu_ctx.visibility_partition(gpu_ctx.upload(cmap), gpu_ctx.upload_scans(S["scans"], S["offsets"]),
+                                                      gpu_ctx.poses(S["poses"], S["inv"]), 2.5, 0.1, 0, want_labels=True)
+    assert want.sum() > 0 and (got == want).all(), f"{(got != want).sum()} labels differ"
