@@ -1,0 +1,73 @@
+// removert_main_ros.cpp -- ROS1 entry point of the MI355X build: same node name, parameter namespace and launch file as
+// ltremovert/src/removert_main.cpp:3-12, so `roslaunch removert run_ltmapper.launch` keeps working.
+//
+// NOT COMPILED IN THIS REPOSITORY'S CI: the build container has no ROS.  It is deliberately thin: it copies the 26
+// `removert/` parameters from the ROS parameter server into the YAML subset the ROS-free RosParamServer mirror reads,
+// then runs the same Removerter::run() as `ltm_run`.
+#include <ros/ros.h>
+
+#include <cstdio>
+#include <fstream>
+#include <sstream>
+#include <string>
+#include <vector>
+
+#include "removert/Removerter.h"
+
+namespace {
+template <class T> void put(ros::NodeHandle& nh, std::ostream& o, const char* key)
+{
+    T v;
+    if (nh.getParam(std::string("removert/") + key, v)) o << "  " << key << ": " << v << "\n";
+}
+template <> void put<std::string>(ros::NodeHandle& nh, std::ostream& o, const char* key)
+{
+    std::string v;
+    if (nh.getParam(std::string("removert/") + key, v)) o << "  " << key << ": \"" << v << "\"\n";
+}
+template <class T> void put_list(ros::NodeHandle& nh, std::ostream& o, const char* key)
+{
+    std::vector<T> v;
+    if (!nh.getParam(std::string("removert/") + key, v)) return;
+    o << "  " << key << ": [";
+    o.precision(17);
+    for (size_t i = 0; i < v.size(); ++i) o << (i ? ", " : "") << v[i];
+    o << "]\n";
+}
+} // namespace
+
+int main(int argc, char** argv)
+{
+    ros::init(argc, argv, "removert");
+    ros::NodeHandle nh;
+    ROS_INFO("\033[1;32m----> Removert Main Started (MI355X build).\033[0m");
+
+    const std::string tmp = "/tmp/removert_params_" + std::to_string(::getpid()) + ".yaml";
+    {
+        std::ofstream o(tmp);
+        o << "removert:\n";
+        for (const char* k : {"isScanFileKITTIFormat", "use_keyframe_gap", "use_keyframe_meter", "saveMapPCD", "saveCleanScansPCD", "gpu_use_self_removert", "gpu_skip_hd_knn"})
+            put<bool>(nh, o, k);
+        for (const char* k : {"num_nn_points_within", "start_idx", "end_idx", "keyframe_gap", "repeat_removert_iter", "num_omp_cores", "gpu_device"})
+            put<int>(nh, o, k);
+        for (const char* k : {"rimg_color_min", "rimg_color_max", "sequence_vfov", "sequence_hfov", "dist_nn_points_within", "downsample_voxel_size", "keyframe_meter"})
+            put<double>(nh, o, k);
+        for (const char* k : {"central_sess_scan_dir", "central_sess_pose_path", "query_sess_scan_dir", "query_sess_pose_path", "save_pcd_directory"})
+            put<std::string>(nh, o, k);
+        put_list<double>(nh, o, "remove_resolution_list");
+        put_list<double>(nh, o, "revert_resolution_list");
+        put_list<double>(nh, o, "ExtrinsicLiDARtoPoseBase");
+    }
+    try {
+        RosParamServer::setParamFile(tmp);
+        ltremovert::Removerter RMV;
+        RMV.run();
+    } catch (const std::exception& e) {
+        ROS_FATAL("removert: %s", e.what());
+        std::remove(tmp.c_str());
+        return 1;
+    }
+    std::remove(tmp.c_str());
+    ros::spin();   // the reference node stays alive after run() (removert_main.cpp:11)
+    return 0;
+}
