@@ -375,6 +375,43 @@ __device__ __forceinline__ bool cull_matters(const CullCand& cc, const uint32_t*
 
 __device__ unsigned long long g_cull_stats[2];   // {survivors, points}: diagnostic, read by cull_stats()
 
+static constexpr int kCullQueue = 2048;   // survivor queue capacity (~370 of 4096 expected); overflow sends the whole tile down the exact path
+
+// exact projection of one map point into image `imgk`, reduced through the workgroup's LDS table
+template <bool B2L_IDENTITY, int SLOTS_R, int SLOTS_C>
+__device__ __forceinline__ void exact_insert(const float4* __restrict__ map, uint32_t i, const Mat34& Tinv, const HostMat34& b2l_h, const RimgGeom& g,
+                                             uint64_t* __restrict__ vals, uint32_t* __restrict__ tags, uint64_t* __restrict__ imgk)
+{
+    const float4 p4 = map[i];
+    float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+    const Sph s = cart2sph(p.x, p.y, p.z);
+    int row, col;
+    pixel_row_col(g, s.az, s.el, row, col);
+    const uint32_t px = (uint32_t)(row * g.cols + col);
+    const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
+    const int slot = ((row & (SLOTS_R - 1)) * SLOTS_C) | (col & (SLOTS_C - 1));
+    uint32_t t = tags[slot];
+    if (t == kEmptyTag) {
+        const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+        t = (old == kEmptyTag) ? px : old;
+    }
+    if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+    else img_min_u64(imgk + px, v);
+}
+
+// Exact range of a map point whose pixel is already certain (single candidate of the bounded-error projection, which
+// ltm_debug_cull_check validates to contain the exact pixel): the reference arithmetic up to sqrtf only --
+// r = sqrtf((x*x + y*y) + z*z) on the float-rounded fp64 transform -- without the atan2f / rad2deg / pixel chain.
+template <bool B2L_IDENTITY>
+__device__ __forceinline__ uint32_t exact_range_bits(const float4 p4, const Mat34& Tinv, const HostMat34& b2l_h)
+{
+    float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+    const float xy = p.x * p.x + p.y * p.y;
+    return f2u(__builtin_sqrtf(xy + p.z * p.z));
+}
+
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
 template <bool B2L_IDENTITY>
@@ -385,8 +422,9 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
 {
     __shared__ uint64_t vals[kCullSlots];
     __shared__ uint32_t tags[kCullSlots];
-    __shared__ uint16_t queue[kBlock * kPtsPerThread];
-    __shared__ uint32_t qcount;
+    __shared__ uint16_t queue[kCullQueue];     // tile-local indices: certain-pixel survivors from the bottom, the others from the top
+    __shared__ uint32_t q_rc[kCullQueue];      // certain pixel (row << 16 | col) of the bottom entries
+    __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     if (!tk.valid) return;
@@ -414,7 +452,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         if (smin > 0.5f && far2 < 8.0e7f && d2 * smin * smin * 0.996f > reach * reach) return;
     }
     for (int s = threadIdx.x; s < kCullSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
-    if (threadIdx.x == 0) qcount = 0;
+    if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
     __syncthreads();
     const RimgGeom g = make_geom(gg);
     const uint32_t npx = (uint32_t)(g.rows * g.cols);
@@ -455,41 +493,53 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 const float s = u2f(s0[u]);
                 bool m = cc[u].unusual | ((s < 9000.0f) & ((s - cc[u].r_lo) > thr_lo));
                 if (__builtin_expect(cc[u].multi & !m, 0)) { cull_expand(g, cc[u]); m = cull_matters(cc[u], scank, g.cols, thr); }
-                if (m & live[u]) queue[atomicAdd(&qcount, 1u)] = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
+                if (m & live[u]) {
+                    const uint16_t li16 = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
+                    if (cc[u].unusual | cc[u].multi) {
+                        const uint32_t pos = atomicAdd(&ucount, 1u);
+                        if (pos < (uint32_t)kCullQueue) queue[kCullQueue - 1 - pos] = li16;
+                    } else {
+                        const uint32_t pos = atomicAdd(&qcount, 1u);
+                        if (pos < (uint32_t)kCullQueue) { queue[pos] = li16; q_rc[pos] = ((uint32_t)cc[u].rb << 16) | (uint32_t)cc[u].cb; }
+                    }   // overflow (the two ends meet; rare): the whole tile takes the exact path below
+                }
             }
         }
     }
     __syncthreads();
-    // ---- phase 2: exact arithmetic for the survivors, LDS pre-reduction as in k_map_rimg_lds
-    const uint32_t nq = qcount;
+    // ---- phase 2: survivors.  Certain pixel: only the exact range is computed; otherwise the full exact projection.
+    const uint32_t nc = qcount, nu = ucount;
     if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled 1/64: same-address atomics from every workgroup would serialise the grid
-        atomicAdd(&g_cull_stats[0], (unsigned long long)nq);
+        atomicAdd(&g_cull_stats[0], (unsigned long long)(nc + nu));
         atomicAdd(&g_cull_stats[1], (unsigned long long)nloc);
     }
-    if (nq) {
+    if (nc + nu) {
         const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
-        for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
-            const uint32_t i = block_base + queue[q];
-            const float4 p4 = map[i];
-            float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
-            if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
-            const Sph s = cart2sph(p.x, p.y, p.z);
-            int row, col;
-            pixel_row_col(g, s.az, s.el, row, col);
-            const uint32_t px = (uint32_t)(row * g.cols + col);
-            const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
-            const int slot = ((row & 7) << 6) | (col & 63);
-            uint32_t t = tags[slot];
-            if (t == kEmptyTag) {
-                const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-                t = (old == kEmptyTag) ? px : old;
+        if (__builtin_expect(nc + nu > (uint32_t)kCullQueue, 0)) {      // queue overflow: a superset is always correct (min is idempotent)
+            for (uint32_t li = threadIdx.x; li < nloc; li += kBlock)
+                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
+        } else {
+            for (uint32_t q = threadIdx.x; q < nc; q += kBlock) {
+                const uint32_t rc = q_rc[q];
+                const uint32_t i = block_base + queue[q];
+                const int row = (int)(rc >> 16), col = (int)(rc & 0xffffu);
+                const uint32_t px = (uint32_t)(row * g.cols + col);
+                const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
+                const int slot = ((row & 7) << 6) | (col & 63);
+                uint32_t t = tags[slot];
+                if (t == kEmptyTag) {
+                    const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+                    t = (old == kEmptyTag) ? px : old;
+                }
+                if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+                else img_min_u64(imgk + px, v);
             }
-            if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
-            else img_min_u64(imgk + px, v);
+            for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
+                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + queue[kCullQueue - 1 - q], Tinv, b2l_h, g, vals, tags, imgk);
         }
     }
     __syncthreads();
-    if (nq)
+    if (nc + nu)
         for (int s = threadIdx.x; s < kCullSlots; s += kBlock) {
             const uint32_t t = tags[s];
             if (t != kEmptyTag) img_min_u64(imgk + t, vals[s]);
