@@ -196,7 +196,9 @@ class Context:
         iv = None if inv is None else np.ascontiguousarray(inv, dtype=np.float64).reshape(-1, 16)
         out = _u64()
         self._ck(self.lib.ltm_poses_create(self.h, p.shape[0], p.ctypes.data, None if iv is None else iv.ctypes.data, C.byref(out)))
-        return Poses(self, out.value, p.shape[0])
+        if iv is None:
+            iv = np.stack([np.linalg.inv(m.reshape(4, 4)).reshape(16) for m in p]) if p.shape[0] else p.copy()
+        return Poses(self, out.value, p.shape[0], p.copy(), iv.copy())
 
     # ---- stages
     def preclean(self, scans, radius):
@@ -403,6 +405,7 @@ class ScanSet(_Handle):
 class Poses(_Handle):
     _free = "ltm_poses_free"
 
-    def __init__(self, ctx, h, n):
+    def __init__(self, ctx, h, n, host_poses=None, host_inv=None):
         super().__init__(ctx, h)
         self.n = n
+        self.host_poses, self.host_inv = host_poses, host_inv     # kept so that keyframe shards can be sliced off

@@ -2,14 +2,17 @@
 node with an RCCL all-gather over xGMI to assemble the final maps").
 
 One process per GPU.  The session maps are replicated (a 10 M point map is 160 MB of 288 GB); every
-per-keyframe stage runs on this rank's contiguous block of keyframes and exactly one exchange follows it:
+per-keyframe stage runs on this rank's contiguous block of keyframes:
 
   visibility vote   -> MAX all-reduce of the M-byte label mask (the union of Removerter.cpp:589-590), after which
                        every rank performs the same deterministic partition + voxel grid (replicated, no broadcast)
-  reprojection/kNN  -> all-gather of the per-keyframe clouds (sizes, then padded payload), reassembled in
-                       keyframe order so every rank holds the full scan set
+  reprojection/kNN  -> the per-keyframe clouds STAY on the rank that produced them (LazyScans) as long as the next
+                       consumer is another per-keyframe stage of the same keyframes (kNN on the reprojected scans,
+                       votes that use them as source scans, the scan-wise merge + voxel grid); they are all-gathered
+                       (sizes, then padded payload; reassembled in keyframe order) only when a stage needs every
+                       keyframe: merging scans into a global map, and the final outputs.
 
-Everything else (merge, voxel grids, the tiny weak->strong ND split) is replicated.  The collectives are
+Everything else (merge, voxel grids of maps, the tiny weak->strong ND split) is replicated.  The collectives are
 torch.distributed calls (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests), so the same code is exercised
 on CPU with world_size 2.  `ops` is any object with the stage interface of removerter.HipOps.
 """
@@ -21,24 +24,50 @@ def shard_range(n, rank, world):
     return (n * rank) // world, (n * (rank + 1)) // world
 
 
+class LazyScans:
+    """a scan set of n keyframes of which this rank holds [kb, ke); `full()` all-gathers it once"""
+
+    def __init__(self, sops, local, kb, ke, n):
+        self.sops, self.local, self.kb, self.ke, self.n = sops, local, kb, ke, n
+        self._full = None
+
+    def full(self):
+        if self._full is None:
+            self._full = self.sops._allgather_scanset(self.local)
+        return self._full
+
+    # so that code written for plain scan sets (tests, scan_outputs) keeps working
+    def download(self):
+        return self.full().download()
+
+    def info(self):
+        return self.full().info()
+
+
 class ShardedOps:
     def __init__(self, ops, dist, rank, world, group=None):
         self.ops, self.dist, self.rank, self.world, self.group = ops, dist, rank, world, group
+        self._pose_slices = {}
 
     def __getattr__(self, name):           # replicated stages are forwarded untouched
         return getattr(self.ops, name)
 
-    # ---- vote: local keyframes, label union across ranks, replicated partition
-    def vote_partition(self, cmap, scans, poses, alpha, thr, mode):
-        n = self.ops.n_keyframes(poses)
-        kb, ke = shard_range(n, self.rank, self.world)
-        labels = self.ops.new_labels(self.ops.size(cmap))
-        self.ops.vote(cmap, scans, poses, kb, ke, alpha, thr, mode, labels)
-        if labels.numel():
-            self.dist.all_reduce(labels, op=self.dist.ReduceOp.MAX, group=self.group)
-        return self.ops.partition(cmap, labels)
+    # ---- helpers
+    def _range(self, poses):
+        return shard_range(self.ops.n_keyframes(poses), self.rank, self.world)
 
-    # ---- per-keyframe outputs: all-gather in keyframe order
+    def _local_poses(self, poses):
+        kb, ke = self._range(poses)
+        key = (id(poses), kb, ke)
+        if key not in self._pose_slices:
+            self._pose_slices[key] = (poses, self.ops.poses_slice(poses, kb, ke))     # keep `poses` alive with its slice
+        return self._pose_slices[key][1]
+
+    def _check(self, scans, poses):
+        kb, ke = self._range(poses)
+        assert (scans.kb, scans.ke, scans.n) == (kb, ke, self.ops.n_keyframes(poses)), "scan shard and pose shard disagree"
+        return kb, ke
+
     def _allgather_scanset(self, local):
         pts, off = self.ops.scanset_to_tensors(local)
         counts = [None] * self.world
@@ -52,11 +81,49 @@ class ShardedOps:
         parts = [self.ops.scanset_from_tensors(bufs[r][: sizes[r]].contiguous(), counts[r]) for r in range(self.world)]
         return self.ops.concat_scansets(parts)
 
+    def materialize(self, scans):
+        """full scan set on every rank (used for the final per-keyframe outputs)"""
+        return scans.full() if isinstance(scans, LazyScans) else scans
+
+    # ---- vote: local keyframes, label union across ranks, replicated partition
+    def vote_partition(self, cmap, scans, poses, alpha, thr, mode):
+        labels = self.ops.new_labels(self.ops.size(cmap))
+        if isinstance(scans, LazyScans):
+            kb, ke = self._check(scans, poses)
+            self.ops.vote(cmap, scans.local, self._local_poses(poses), 0, ke - kb, alpha, thr, mode, labels)
+        else:
+            kb, ke = self._range(poses)
+            self.ops.vote(cmap, scans, poses, kb, ke, alpha, thr, mode, labels)
+        if labels.numel():
+            self.dist.all_reduce(labels, op=self.dist.ReduceOp.MAX, group=self.group)
+        return self.ops.partition(cmap, labels)
+
+    # ---- per-keyframe stages: results stay rank-local
     def reproject(self, cmap, poses, alpha):
-        kb, ke = shard_range(self.ops.n_keyframes(poses), self.rank, self.world)
-        return self._allgather_scanset(self.ops.reproject_range(cmap, poses, alpha, kb, ke))
+        kb, ke = self._range(poses)
+        return LazyScans(self, self.ops.reproject_range(cmap, poses, alpha, kb, ke), kb, ke, self.ops.n_keyframes(poses))
 
     def knn_partition(self, target, scans, poses, k, thr):
-        kb, ke = shard_range(self.ops.n_keyframes(poses), self.rank, self.world)
-        co, di = self.ops.knn_partition_range(target, scans, poses, k, thr, kb, ke)
-        return self._allgather_scanset(co), self._allgather_scanset(di)
+        n = self.ops.n_keyframes(poses)
+        if isinstance(scans, LazyScans):
+            kb, ke = self._check(scans, poses)
+            co, di = self.ops.knn_partition_range(target, scans.local, self._local_poses(poses), k, thr, 0, ke - kb)
+        else:
+            kb, ke = self._range(poses)
+            co, di = self.ops.knn_partition_range(target, scans, poses, k, thr, kb, ke)
+        return LazyScans(self, co, kb, ke, n), LazyScans(self, di, kb, ke, n)
+
+    def zip_concat(self, a, b, c):
+        if all(isinstance(x, LazyScans) for x in (a, b, c) if x is not None):
+            loc = self.ops.zip_concat(a.local, b.local, c.local if c is not None else None)
+            return LazyScans(self, loc, a.kb, a.ke, a.n)
+        return self.ops.zip_concat(self.materialize(a), self.materialize(b), self.materialize(c) if c is not None else None)
+
+    def voxel_scanset(self, s, leaf):
+        if isinstance(s, LazyScans):
+            return LazyScans(self, self.ops.voxel_scanset(s.local, leaf), s.kb, s.ke, s.n)
+        return self.ops.voxel_scanset(s, leaf)
+
+    # ---- stages that need every keyframe
+    def merge_to_global(self, scans, poses):
+        return self.ops.merge_to_global(self.materialize(scans), poses)

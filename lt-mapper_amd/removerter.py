@@ -52,9 +52,11 @@ class HipOps:
     def knn_split(self, target, query, k, thr): return self.ctx.knn_split_cloud(target, query, k, thr)
     def zip_concat(self, a, b, c): return self.ctx.zip_concat(a, b, c)
     def sync(self): self.ctx.synchronize()
+    def materialize(self, scans): return scans          # single GPU: scan sets are always whole
 
     # ---- pieces used by dist.ShardedOps (keyframe ranges + tensors for the collectives)
     def n_keyframes(self, poses): return poses.n
+    def poses_slice(self, poses, kb, ke): return self.ctx.poses(poses.host_poses[kb:ke], poses.host_inv[kb:ke])
 
     def new_labels(self, n):
         import torch
@@ -300,6 +302,11 @@ class Removerter:
         self.parseLDScansViaProjection()
         self.updateScansScanwise()
         C, Q = self.central_sess_, self.query_sess_
+        # the five per-keyframe outputs are assembled on every rank (no-op on one GPU): this is the "all-gather to assemble the
+        # final maps" of the north star and is part of the timed step
+        for name in ("keyframe_scans_updated_", "keyframe_scans_updated_strong_", "keyframe_scans_pd_", "keyframe_scans_strong_pd_",
+                     "keyframe_scans_strong_nd_"):
+            setattr(C, name, self.ops.materialize(getattr(C, name)))
         self.outputs.update(central_map_static=C.map_global_curr_static_, central_map_dynamic=C.map_global_curr_dynamic_,
                             query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
 

@@ -58,6 +58,8 @@ class OracleOps:
 
     # ---- sharding pieces
     def n_keyframes(self, p): return p.n
+    def poses_slice(self, p, kb, ke): return OPoses(p.poses[kb:ke], p.inv[kb:ke])
+    def materialize(self, scans): return scans
     def new_labels(self, n): return torch.zeros(n, dtype=torch.uint8)
 
     def vote(self, cmap, scans, poses, kb, ke, alpha, thr, mode, labels):
