@@ -7,6 +7,7 @@
 
 #include <cstddef>
 #include <cstdint>
+#include <functional>
 #include <string>
 #include <utility>
 #include <vector>
@@ -43,6 +44,9 @@ bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_
 // pcl::VoxelGrid as used by Session::loadKeyframes (Session.cpp:284-289), including the int32 overflow early-out
 // (output = input) that PCL takes for large extents.  Points inside a voxel are summed in input order.
 void voxelGridFilter(const Cloud& in, float leaf, Cloud& out);
+
+// runs f(i) for i in [0, n) on up to `threads` host threads (0 = hardware concurrency); exceptions are re-thrown on the caller
+void parallelFor(size_t n, const std::function<void(size_t)>& f, unsigned threads = 0);
 
 void fsmkdir(const std::string& _path);    // Removerter.cpp:6-10
 std::vector<std::string> listDirectorySorted(const std::string& dir, std::vector<std::string>* names);

@@ -297,12 +297,12 @@ void Removerter::saveStrongNDScans(Session& _sess) { saveScans(_sess, _sess.keyf
 
 void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout)   // Removerter.cpp:1637-1650
 {
-    const std::vector<Cloud> scans = _scans->download();
-    for (std::size_t idx_scan = 0; idx_scan < scans.size(); idx_scan++) {
+    const std::vector<Cloud> scans = _scans->download();      // one D2H for the whole scan set
+    parallelFor(scans.size(), [&](size_t idx_scan) {           // the files are independent: written from all host cores
         const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(idx_scan);   // same file name as the input scan
         std::string err;
         if (!savePCDFileBinary(file_name, scans[idx_scan], octree_layout, &err)) throw std::runtime_error(err);
-    }
+    }, (unsigned)std::max(1, kNumOmpCores));
     LTM_INFO(" " << scans.size() << " scans saved under " << _save_dir);
 }
 

@@ -144,17 +144,24 @@ void Session::loadKeyframes(void)
     const int cout_interval{10};
     int cout_counter{0};
     std::cout << std::endl << " ... (display every " << cout_interval << " readings) ..." << std::endl;
+    // PCD decode + per-scan VoxelGrid are independent per keyframe: done on all host cores, concatenated in keyframe order
+    std::vector<Cloud> per_kf(keyframe_paths_.size());
+    std::vector<size_t> raw_sizes(keyframe_paths_.size(), 0);
+    parallelFor(keyframe_paths_.size(), [&](size_t k) {
+        Cloud points;
+        std::string err;
+        if (!loadPCDFile(keyframe_paths_[k], points, &err)) throw std::runtime_error(err);
+        raw_sizes[k] = points.size();
+        voxelGridFilter(points, kDownsampleVoxelSize, per_kf[k]);
+    }, (unsigned)std::max(1, kNumOmpCores));
     Cloud all;
     std::vector<uint64_t> offsets(1, 0);
-    for (auto& _scan_path : keyframe_paths_) {
-        Cloud points, downsampled;
-        std::string err;
-        if (!loadPCDFile(_scan_path, points, &err)) throw std::runtime_error(err);
-        voxelGridFilter(points, kDownsampleVoxelSize, downsampled);
-        all.insert(all.end(), downsampled.begin(), downsampled.end());
+    for (size_t k = 0; k < per_kf.size(); ++k) {
+        all.insert(all.end(), per_kf[k].begin(), per_kf[k].end());
         offsets.push_back(all.size());
         if (++cout_counter % cout_interval == 0)
-            std::cout << _scan_path << std::endl << "Read a pointcloud with " << points.size() << " points (downsampled size: " << downsampled.size() << " points)" << std::endl;
+            std::cout << keyframe_paths_[k] << std::endl << "Read a pointcloud with " << raw_sizes[k] << " points (downsampled size: " << per_kf[k].size() << " points)" << std::endl;
+        Cloud().swap(per_kf[k]);
     }
     ltm_scanset h = 0;
     ltmCheck(dev_->ctx, ltm_scanset_upload(dev_->ctx, all.data(), sizeof(PointType), offsets.data(), offsets.size() - 1, &h), "ltm_scanset_upload");

@@ -3,6 +3,10 @@
 #include "removert/utility.h"
 
 #include <algorithm>
+#include <atomic>
+#include <exception>
+#include <mutex>
+#include <thread>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -55,6 +59,29 @@ bool inverse4x4(const double* m, double* inv)
     }
     for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = a[r][4 + k];
     return true;
+}
+
+void parallelFor(size_t n, const std::function<void(size_t)>& f, unsigned threads)
+{
+    if (threads == 0) threads = std::max(1u, std::thread::hardware_concurrency());
+    threads = (unsigned)std::min<size_t>(threads, n);
+    if (threads <= 1) { for (size_t i = 0; i < n; ++i) f(i); return; }
+    std::atomic<size_t> next{0};
+    std::exception_ptr err;
+    std::mutex m;
+    std::vector<std::thread> pool;
+    for (unsigned t = 0; t < threads; ++t)
+        pool.emplace_back([&] {
+            try {
+                for (size_t i = next++; i < n; i = next++) f(i);
+            } catch (...) {
+                std::lock_guard<std::mutex> g(m);
+                if (!err) err = std::current_exception();
+                next = n;
+            }
+        });
+    for (auto& th : pool) th.join();
+    if (err) std::rethrow_exception(err);
 }
 
 void fsmkdir(const std::string& _path)
