@@ -422,8 +422,9 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
 {
     __shared__ uint64_t vals[kCullSlots];
     __shared__ uint32_t tags[kCullSlots];
-    __shared__ uint16_t queue[kCullQueue];     // tile-local indices: certain-pixel survivors from the bottom, the others from the top
-    __shared__ uint32_t q_rc[kCullQueue];      // certain pixel (row << 16 | col) of the bottom entries
+    __shared__ uint16_t queue[kCullQueue];     // tile-local indices of the survivors of phase 1
+    __shared__ uint32_t q_rc[kCullQueue];      // their certain pixel (row << 16 | col), or 0xffffffff = needs the full exact projection
+    __shared__ uint16_t uqueue[kCullQueue];    // the latter, re-queued densely in phase 2
     __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
@@ -487,40 +488,57 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 cc[u].unusual |= !ok;
                 s0[u] = scank[cc[u].rb * g.cols + cc[u].cb];
             }
+            bool mt[kInFlight];
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 const float thr_lo = thr - (1.0e-3f + cc[u].r_lo * 3.0e-6f);
                 const float s = u2f(s0[u]);
                 bool m = cc[u].unusual | ((s < 9000.0f) & ((s - cc[u].r_lo) > thr_lo));
                 if (__builtin_expect(cc[u].multi & !m, 0)) { cull_expand(g, cc[u]); m = cull_matters(cc[u], scank, g.cols, thr); }
-                if (m & live[u]) {
-                    const uint16_t li16 = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
-                    if (cc[u].unusual | cc[u].multi) {
-                        const uint32_t pos = atomicAdd(&ucount, 1u);
-                        if (pos < (uint32_t)kCullQueue) queue[kCullQueue - 1 - pos] = li16;
-                    } else {
-                        const uint32_t pos = atomicAdd(&qcount, 1u);
-                        if (pos < (uint32_t)kCullQueue) { queue[pos] = li16; q_rc[pos] = ((uint32_t)cc[u].rb << 16) | (uint32_t)cc[u].cb; }
-                    }   // overflow (the two ends meet; rare): the whole tile takes the exact path below
+                mt[u] = m & live[u];
+            }
+            // One LDS atomic per wave for the four points of every lane (hand-rolled ballot/mbcnt aggregation: letting the compiler
+            // aggregate four separate atomicAdd(&qcount, 1) costs ~40 instructions each and one of them is taken almost always).
+            const uint64_t b0 = __builtin_amdgcn_ballot_w64(mt[0]), b1 = __builtin_amdgcn_ballot_w64(mt[1]),
+                           b2 = __builtin_amdgcn_ballot_w64(mt[2]), b3 = __builtin_amdgcn_ballot_w64(mt[3]);
+            const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
+            const uint32_t total = n0 + n1 + n2 + n3;
+            if (total) {
+                uint32_t base = 0;
+                if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&qcount, total);
+                base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+                const uint64_t bal[kInFlight] = {b0, b1, b2, b3};
+                const uint32_t off[kInFlight] = {0u, n0, n0 + n1, n0 + n1 + n2};
+#pragma unroll
+                for (int u = 0; u < kInFlight; ++u) {
+                    if (!mt[u]) continue;
+                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
+                    const uint32_t pos = base + off[u] + below;
+                    if (pos < (uint32_t)kCullQueue) {       // overflow (rare): the whole tile takes the exact path below
+                        queue[pos] = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
+                        q_rc[pos] = (cc[u].unusual | cc[u].multi) ? 0xffffffffu : (((uint32_t)cc[u].rb << 16) | (uint32_t)cc[u].cb);
+                    }
                 }
             }
         }
     }
     __syncthreads();
-    // ---- phase 2: survivors.  Certain pixel: only the exact range is computed; otherwise the full exact projection.
-    const uint32_t nc = qcount, nu = ucount;
+    // ---- phase 2: survivors.  Certain pixel: only the exact range is computed; the ~1 % others are re-queued densely at the
+    // top of the same array and get the full exact projection afterwards (keeps both loops free of divergence).
+    const uint32_t nq_all = qcount;
     if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled 1/64: same-address atomics from every workgroup would serialise the grid
-        atomicAdd(&g_cull_stats[0], (unsigned long long)(nc + nu));
+        atomicAdd(&g_cull_stats[0], (unsigned long long)nq_all);
         atomicAdd(&g_cull_stats[1], (unsigned long long)nloc);
     }
-    if (nc + nu) {
+    if (nq_all) {
         const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
-        if (__builtin_expect(nc + nu > (uint32_t)kCullQueue, 0)) {      // queue overflow: a superset is always correct (min is idempotent)
+        if (__builtin_expect(nq_all > (uint32_t)kCullQueue, 0)) {      // queue overflow: a superset is always correct (min is idempotent)
             for (uint32_t li = threadIdx.x; li < nloc; li += kBlock)
                 exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
         } else {
-            for (uint32_t q = threadIdx.x; q < nc; q += kBlock) {
+            for (uint32_t q = threadIdx.x; q < nq_all; q += kBlock) {
                 const uint32_t rc = q_rc[q];
+                if (rc == 0xffffffffu) { uqueue[atomicAdd(&ucount, 1u)] = queue[q]; continue; }
                 const uint32_t i = block_base + queue[q];
                 const int row = (int)(rc >> 16), col = (int)(rc & 0xffffu);
                 const uint32_t px = (uint32_t)(row * g.cols + col);
@@ -534,12 +552,14 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
                 else img_min_u64(imgk + px, v);
             }
+            __syncthreads();
+            const uint32_t nu = ucount;
             for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
-                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + queue[kCullQueue - 1 - q], Tinv, b2l_h, g, vals, tags, imgk);
+                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
         }
     }
     __syncthreads();
-    if (nc + nu)
+    if (nq_all)
         for (int s = threadIdx.x; s < kCullSlots; s += kBlock) {
             const uint32_t t = tags[s];
             if (t != kEmptyTag) img_min_u64(imgk + t, vals[s]);
