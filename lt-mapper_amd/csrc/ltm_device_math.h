@@ -204,7 +204,7 @@ __device__ __forceinline__ float atan2_approx(float y, float x)
     float r = atan_unit_approx(mn * __builtin_amdgcn_rcpf(mx));
     r = (ay > ax) ? (1.57079632679f - r) : r;
     r = (x < 0.0f) ? (3.14159265359f - r) : r;
-    return (y < 0.0f) ? -r : r;
+    return __builtin_copysignf(r, y);          // r >= 0: one v_bfi instead of compare + select
 }
 
 // same for x >= 0 (elevation: second argument is a norm)
@@ -214,7 +214,7 @@ __device__ __forceinline__ float atan2_approx_xpos(float y, float x)
     const float mx = fmaxf(x, ay), mn = fminf(x, ay);
     float r = atan_unit_approx(mn * __builtin_amdgcn_rcpf(mx));
     r = (ay > x) ? (1.57079632679f - r) : r;
-    return (y < 0.0f) ? -r : r;
+    return __builtin_copysignf(r, y);
 }
 
 // PCL transformPointCloud<PointXYZI,double>: (float)(((m0*x + m1*y) + m2*z) + m3) per row, double math.

@@ -336,11 +336,14 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
     // Outside the fast forms' domain (every such case ends in the exact path): y == +-0 (the sign of a zero y picks the side of
     // the +-180 deg seam in the reference), anything that made a NaN/inf (x = y = 0, under/overflowing squares), absurd ranges.
-    cc.unusual = (p.y == 0.0f) | !(fmaxf(fabsf(cc.rowh), fabsf(cc.colh)) < 1.0e9f) | !(r < 9000.0f);
+    // rowh/colh are bounded (|atan| <= pi) unless something upstream made a NaN, and a NaN fails the "<=" below as well.
     const float rfr = __builtin_amdgcn_fractf(cc.rowh), cfr = __builtin_amdgcn_fractf(cc.colh);   // distance above the rounding boundary
-    cc.multi = (fabsf(rfr - 0.5f) > 0.5f - kCullEpsPx) | (fabsf(cfr - 0.5f) > 0.5f - kCullEpsPx);
-    cc.rb = min(max((int)floorf(cc.rowh), 0), g.rows - 1);
-    cc.cb = min(max((int)floorf(cc.colh), 0), g.cols - 1);
+    const bool certain = fmaxf(fabsf(rfr - 0.5f), fabsf(cfr - 0.5f)) <= 0.5f - kCullEpsPx;
+    cc.unusual = (p.y == 0.0f) | !(cc.rowh + cc.colh + r < 3.0e4f);   // NaN anywhere, absurd ranges (r >= ~2.8e4 incl. inf)
+    cc.multi = !certain;
+    // clamp(floor(v), 0, n-1) == trunc(med3(v, 0, n-1)): the bounds are integers and the clamped value is non-negative
+    cc.rb = (int)__builtin_amdgcn_fmed3f(cc.rowh, 0.0f, g.frows - 1.0f);
+    cc.cb = (int)__builtin_amdgcn_fmed3f(cc.colh, 0.0f, g.fcols - 1.0f);
     cc.r0 = cc.r1 = cc.rb; cc.c0 = cc.c1 = cc.cb;
     cc.r_lo = r * (1.0f - 1.5e-6f);
     return cc;
@@ -486,7 +489,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 const float3 p = xform_approx(ap, pt[u], ok);
                 cc[u] = cull_candidates(g, p, row_scale, col_scale);
                 cc[u].unusual |= !ok;
-                s0[u] = scank[cc[u].rb * g.cols + cc[u].cb];
+                s0[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(scank) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
             }
             bool mt[kInFlight];
 #pragma unroll
