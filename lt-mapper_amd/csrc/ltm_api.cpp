@@ -670,6 +670,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     if (const char* v = getenv("LTM_VOTE_CULL")) set_vote_cull(atoi(v));
     if (const char* v = getenv("LTM_KF_PER_BLOCK")) set_kf_per_block(atoi(v));
     if (const char* v = getenv("LTM_TILE_CULL")) set_tile_cull(atoi(v));
+    if (const char* v = getenv("LTM_STATS_BLOCKMIN")) set_stats_select(atoi(v));
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's
     // constants; they are enabled only if they reproduce the exact IEEE results for every input.
     {

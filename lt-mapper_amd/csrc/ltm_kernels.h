@@ -29,6 +29,7 @@ hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, s
                              uint64_t first_pt, uint64_t n_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s);
 // bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);
+void set_stats_select(int v);
 void set_tile_cull(int v);
 // transformGlobalMapToLocal + map2RangeImg: map_img[(kf-kb)*npx+px] = min (range_bits<<32 | idx)
 // inv_poses_dev: 12 doubles per keyframe (3x4 row-major).  b2l: 12 doubles, b2l_identity skips the arithmetic.

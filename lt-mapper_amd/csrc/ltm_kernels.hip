@@ -376,7 +376,9 @@ __device__ __forceinline__ bool cull_matters(const CullCand& cc, const uint32_t*
     return m;
 }
 
-__device__ unsigned long long g_cull_stats[2];   // {survivors, points}: diagnostic, read by cull_stats()
+__device__ unsigned long long g_cull_stats[4];   // {survivors, points} of k_vote_map_cull, then of k_map_rimg_blockmin: diagnostic, read by cull_stats()
+static int g_stats_select = 0;             // which pair cull_stats() reports (env LTM_STATS_BLOCKMIN=1: the reprojection kernel)
+void set_stats_select(int v) { g_stats_select = v ? 1 : 0; }
 
 static constexpr int kCullQueue = 2048;   // survivor queue capacity (~370 of 4096 expected); overflow sends the whole tile down the exact path
 
@@ -571,12 +573,12 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
 
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s)
 {
-    hipError_t e = hipMemcpyFromSymbolAsync(out2, HIP_SYMBOL(g_cull_stats), 16, 0, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipMemcpyFromSymbolAsync(out2, HIP_SYMBOL(g_cull_stats), 16, 16 * (size_t)g_stats_select, hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
     if (e != hipSuccess || !reset) return e;
-    const unsigned long long z[2] = {0, 0};
-    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cull_stats), z, 16, 0, hipMemcpyHostToDevice, s);
+    const unsigned long long z[4] = {0, 0, 0, 0};
+    e = hipMemcpyToSymbolAsync(HIP_SYMBOL(g_cull_stats), z, 32, 0, hipMemcpyHostToDevice, s);
     return e == hipSuccess ? hipStreamSynchronize(s) : e;
 }
 
@@ -673,41 +675,77 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     // per-lane record of the 16 points: slot (0xffff = survive unconditionally) and range lower bound
     float rlo[kPtsPerThread];
     uint16_t slot_of[kPtsPerThread];
-    // ---- phase 1a
+    // ---- phase 1a (four points per lane in flight, as in k_vote_map_cull)
 #pragma unroll
-    for (int j = 0; j < kPtsPerThread; ++j) {
-        const uint32_t li = (uint32_t)j * kBlock + threadIdx.x;
-        rlo[j] = 0.0f; slot_of[j] = 0xfffe;                       // 0xfffe = not a point
-        if (li >= nloc) continue;
-        bool ok;
-        const float3 p = xform_approx(ap, mapb[li], ok);
-        const CullCand cc = cull_candidates(g, p, row_scale, col_scale);
-        rlo[j] = cc.r_lo;
-        slot_of[j] = 0xffff;
-        if (cc.unusual | !ok | cc.multi) continue;
-        const uint32_t px = (uint32_t)(cc.rb * g.cols + cc.cb);
-        const int slot = ((cc.rb & 15) << 6) | (cc.cb & 63);
-        uint32_t t = tags[slot];
-        if (t == kEmptyTag) {
-            const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-            t = (old == kEmptyTag) ? px : old;
+    for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
+        float4 pt[4];
+        bool live[4];
+        CullCand cc[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint32_t li = (uint32_t)(j0 + u) * kBlock + threadIdx.x;
+            live[u] = li < nloc;
+            pt[u] = live[u] ? mapb[li] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
         }
-        if (t != px) continue;                                     // slot owned by another pixel: survive unconditionally
-        slot_of[j] = (uint16_t)slot;
-        atomicMin(&amin[slot], f2u(cc.r_lo * (1.0f + 3.5e-6f)));   // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6))
+        bool ok = true;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float3 p = xform_approx(ap, pt[u], ok);
+            cc[u] = cull_candidates(g, p, row_scale, col_scale);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int j = j0 + u;
+            rlo[j] = cc[u].r_lo;
+            slot_of[j] = live[u] ? 0xffff : 0xfffe;                   // 0xfffe = not a point, 0xffff = survive unconditionally
+            if (!live[u] | cc[u].unusual | !ok | cc[u].multi) continue;
+            const uint32_t px = (uint32_t)(cc[u].rb * g.cols + cc[u].cb);
+            const int slot = ((cc[u].rb & 15) << 6) | (cc[u].cb & 63);
+            uint32_t t = tags[slot];
+            if (t == kEmptyTag) {
+                const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+                t = (old == kEmptyTag) ? px : old;
+            }
+            if (t != px) continue;                                     // slot owned by another pixel: survive unconditionally
+            slot_of[j] = (uint16_t)slot;
+            atomicMin(&amin[slot], f2u(cc[u].r_lo * (1.0f + 3.5e-6f)));   // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6))
+        }
     }
     __syncthreads();
     // ---- phase 1b
 #pragma unroll
-    for (int j = 0; j < kPtsPerThread; ++j) {
-        const uint16_t sl = slot_of[j];
-        if (sl == 0xfffe) continue;
-        const bool survive = (sl == 0xffff) || !(rlo[j] > u2f(amin[sl]));
-        if (survive) queue[atomicAdd(&qcount, 1u)] = (uint16_t)((uint32_t)j * kBlock + threadIdx.x);
+    for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
+        bool sv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const uint16_t sl = slot_of[j0 + u];
+            sv[u] = (sl != 0xfffe) && ((sl == 0xffff) || !(rlo[j0 + u] > u2f(amin[sl & (kBmSlots - 1)])));
+        }
+        // one LDS atomic per wave and group of four (see k_vote_map_cull)
+        const uint64_t b0 = __builtin_amdgcn_ballot_w64(sv[0]), b1 = __builtin_amdgcn_ballot_w64(sv[1]),
+                       b2 = __builtin_amdgcn_ballot_w64(sv[2]), b3 = __builtin_amdgcn_ballot_w64(sv[3]);
+        const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
+        const uint32_t total = n0 + n1 + n2 + n3;
+        if (!total) continue;
+        uint32_t base = 0;
+        if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&qcount, total);
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        const uint64_t bal[4] = {b0, b1, b2, b3};
+        const uint32_t off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!sv[u]) continue;
+            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
+            queue[base + off[u] + below] = (uint16_t)((uint32_t)(j0 + u) * kBlock + threadIdx.x);
+        }
     }
     __syncthreads();
     // ---- phase 2: exact arithmetic for the survivors
     const uint32_t nq = qcount;
+    if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled diagnostic
+        atomicAdd(&g_cull_stats[2], (unsigned long long)nq);
+        atomicAdd(&g_cull_stats[3], (unsigned long long)nloc);
+    }
     const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
     for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
         const uint32_t i = block_base + queue[q];
