@@ -107,6 +107,10 @@ int ltm_merge_to_global(ltm_ctx*, ltm_scanset scans, ltm_poses poses, ltm_cloud*
 
 /* utility.cpp:204-219 octreeDownsampling (PCL OctreePointCloudVoxelCentroid): voxel centroids in octree DFS order */
 int ltm_voxel_centroid(ltm_ctx*, ltm_cloud in, float leaf, ltm_cloud* out);
+/* multi-GPU form of the above: only the voxels of shard `shard` of `n_shards`.  The Morton key space of the
+ * octree is cut into n_shards contiguous ranges of about equal point count (a pure function of `in`), so the outputs of
+ * shards 0..n_shards-1 concatenated in order ARE ltm_voxel_centroid(in); each rank sorts 1/n_shards of the points. */
+int ltm_voxel_centroid_shard(ltm_ctx*, ltm_cloud in, float leaf, uint32_t shard, uint32_t n_shards, ltm_cloud* out);
 /* the same applied to every keyframe of a scan set (Session.cpp:362-380 updateScansScanwise) */
 int ltm_voxel_centroid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset* out);
 

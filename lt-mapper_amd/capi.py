@@ -63,6 +63,7 @@ SIGNATURES = {
     "ltm_preclean": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_merge_to_global": (_i, [_vp, _u64, _u64, _pu64]),
     "ltm_voxel_centroid": (_i, [_vp, _u64, _f, _pu64]),
+    "ltm_voxel_centroid_shard": (_i, [_vp, _u64, _f, C.c_uint32, C.c_uint32, _pu64]),
     "ltm_voxel_centroid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
@@ -214,6 +215,11 @@ class Context:
     def voxel_centroid(self, cloud, leaf):
         out = _u64()
         self._ck(self.lib.ltm_voxel_centroid(self.h, cloud.h, leaf, C.byref(out)))
+        return Cloud(self, out.value)
+
+    def voxel_centroid_shard(self, cloud, leaf, shard, n_shards):
+        out = _u64()
+        self._ck(self.lib.ltm_voxel_centroid_shard(self.h, cloud.h, leaf, shard, n_shards, C.byref(out)))
         return Cloud(self, out.value)
 
     def voxel_centroid_scanset(self, scans, leaf):

@@ -496,19 +496,60 @@ void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3])
 }
 
 // voxel centroids of pts[0..n) into a freshly pooled array; returns count
-size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n, float leaf, float4** out)
+// With n_shards > 1 only the voxels of shard `shard` are produced: the Morton key space is cut into n_shards contiguous
+// ranges holding about n/n_shards points each (cut points on a 4096-bin histogram of the key prefix, so they are a pure
+// function of the input), and the outputs of shards 0..n_shards-1 concatenated are exactly the unsharded output.
+size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf, float4** out, uint32_t shard = 0, uint32_t n_shards = 1)
 {
     *out = nullptr;
-    if (n == 0) return 0;
+    if (n_in == 0) return 0;
     LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
-    LTM_REQUIRE(n < 0xffffffffull, "cloud too large for 32-bit point indices");
-    ProfScope p(c, "voxel", (double)n, 64.0 * n);
+    LTM_REQUIRE(n_in < 0xffffffffull, "cloud too large for 32-bit point indices");
+    ProfScope p(c, "voxel", (double)n_in, 64.0 * n_in);
     float mn[3], mx[3];
-    bbox_of(c, pts, n, mn, mx);
+    bbox_of(c, pts, n_in, mn, mx);
     OctreeFrame f;
     if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
-    DevBuf keys(c, n * 8), keys2(c, n * 8), idx(c, n * 4), idx2(c, n * 4);
+    size_t n = n_in;
+    DevBuf keys(c, n * 8), idx(c, n * 4);
     LTM_HIP(morton_keys(pts, n, f, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
+    if (n_shards > 1) {
+        const unsigned bits = 3 * f.depth;
+        const unsigned shift = bits > 12 ? bits - 12 : 0;
+        std::vector<uint32_t> hist(kVoxelKeyBins);
+        {
+            DevBuf hd(c, kVoxelKeyBins * sizeof(uint32_t));
+            LTM_HIP(key_histogram(keys.as<uint64_t>(), n, shift, hd.as<uint32_t>(), c->stream));
+            d2h(c, hist.data(), hd.p, kVoxelKeyBins * sizeof(uint32_t));
+        }
+        // cut b (1..n_shards-1) = first bin whose preceding count reaches b*n/n_shards
+        auto cut = [&](uint32_t b) -> uint64_t {
+            if (b == 0) return 0;
+            if (b >= n_shards) return kVoxelKeyBins;
+            const uint64_t want = (uint64_t)n * b / n_shards;
+            uint64_t cum = 0;
+            for (uint64_t s = 0; s < (uint64_t)kVoxelKeyBins; ++s) {
+                if (cum >= want) return s;
+                cum += hist[s];
+            }
+            return kVoxelKeyBins;
+        };
+        const uint64_t lo = cut(shard) << shift;
+        const uint64_t hi = (shard + 1 >= n_shards) ? ~0ull : (cut(shard + 1) << shift);
+        DevBuf flags(c, n), pos(c, n * 4);
+        LTM_HIP(key_range_flags(keys.as<uint64_t>(), n, lo, hi, flags.as<uint8_t>(), c->stream));
+        const size_t tb = scan_temp_bytes(n);
+        DevBuf temp(c, tb);
+        LTM_HIP(exclusive_scan_u8(flags.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+        const size_t nsel = scan_total_u8(c, flags.as<uint8_t>(), pos.as<uint32_t>(), n);
+        if (nsel == 0) return 0;
+        DevBuf ck(c, nsel * 8), ci(c, nsel * 4);
+        LTM_HIP(compact_pairs(keys.as<uint64_t>(), idx.as<uint32_t>(), flags.as<uint8_t>(), pos.as<uint32_t>(), n,
+                              ck.as<uint64_t>(), ci.as<uint32_t>(), c->stream));
+        std::swap(keys.p, ck.p); std::swap(idx.p, ci.p);
+        n = nsel;
+    }
+    DevBuf keys2(c, n * 8), idx2(c, n * 4);
     const size_t stb = sort_temp_bytes(n);
     {
         DevBuf stemp(c, stb);
@@ -977,6 +1018,19 @@ int ltm_voxel_centroid(ltm_ctx* c, ltm_cloud hin, float leaf, ltm_cloud* out)
         const Cloud in = get_cloud(c, hin);
         float4* d = nullptr;
         const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d);
+        if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+        *out = new_cloud(c, d, nv);
+    });
+}
+
+int ltm_voxel_centroid_shard(ltm_ctx* c, ltm_cloud hin, float leaf, uint32_t shard, uint32_t n_shards, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        LTM_REQUIRE(n_shards >= 1 && n_shards <= 4096 && shard < n_shards, "shard index out of range");
+        const Cloud in = get_cloud(c, hin);
+        float4* d = nullptr;
+        const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d, shard, n_shards);
         if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
         *out = new_cloud(c, d, nv);
     });

@@ -100,6 +100,12 @@ size_t sort_temp_bytes(size_t n);
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
                           unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s);
+// sharded voxel grid: 4096-bin histogram of (key >> shift), range flags, order-preserving compaction of (key, index)
+static constexpr int kVoxelKeyBins = 4096;
+hipError_t key_histogram(const uint64_t* keys, size_t n, unsigned shift, uint32_t* hist, hipStream_t s);
+hipError_t key_range_flags(const uint64_t* keys, size_t n, uint64_t lo, uint64_t hi, uint8_t* flags, hipStream_t s);
+hipError_t compact_pairs(const uint64_t* keys, const uint32_t* idx, const uint8_t* flags, const uint32_t* pos, size_t n,
+                         uint64_t* keys_out, uint32_t* idx_out, hipStream_t s);
 // starts[u] = j for every head j (u = pos[j])
 hipError_t segment_starts(const uint8_t* heads, const uint32_t* pos, size_t n, uint32_t* starts, hipStream_t s);
 hipError_t voxel_centroids(const float4* pts, const uint32_t* sorted_idx, const uint32_t* starts, size_t n_vox, size_t n,

@@ -1258,6 +1258,60 @@ hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uin
     return rocprim::radix_sort_pairs(temp, temp_bytes, keys_in, keys_out, val_in, val_out, n, 0, end_bit, s);
 }
 
+// ---- sharded voxel grid (multi-GPU: every rank owns a contiguous range of Morton keys, i.e. whole voxels)
+static constexpr int kKeyBins = 4096;
+__global__ void __launch_bounds__(kBlock)
+k_key_histogram(const uint64_t* __restrict__ keys, size_t n, unsigned shift, uint32_t* __restrict__ hist)
+{
+    __shared__ uint32_t h[kKeyBins];
+    for (int b = threadIdx.x; b < kKeyBins; b += kBlock) h[b] = 0;
+    __syncthreads();
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        atomicAdd(&h[min((uint64_t)(kKeyBins - 1), keys[i] >> shift)], 1u);
+    __syncthreads();
+    for (int b = threadIdx.x; b < kKeyBins; b += kBlock)
+        if (h[b]) atomicAdd(&hist[b], h[b]);
+}
+hipError_t key_histogram(const uint64_t* keys, size_t n, unsigned shift, uint32_t* hist, hipStream_t s)
+{
+    hipError_t e = hipMemsetAsync(hist, 0, kKeyBins * sizeof(uint32_t), s);
+    if (e != hipSuccess || !n) return e;
+    const size_t blocks = std::min<size_t>(grid_for(n), 2048);
+    k_key_histogram<<<dim3((unsigned)blocks), dim3(kBlock), 0, s>>>(keys, n, shift, hist);
+    return hipGetLastError();
+}
+__global__ void __launch_bounds__(kBlock)
+k_key_range_flags(const uint64_t* __restrict__ keys, size_t n, uint64_t lo, uint64_t hi, uint8_t* __restrict__ flags)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint64_t k = keys[i];
+    flags[i] = (k >= lo && k < hi) ? 1 : 0;
+}
+hipError_t key_range_flags(const uint64_t* keys, size_t n, uint64_t lo, uint64_t hi, uint8_t* flags, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_key_range_flags<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(keys, n, lo, hi, flags);
+    return hipGetLastError();
+}
+// order-preserving compaction of (key, index) pairs by flag; pos = exclusive scan of flags
+__global__ void __launch_bounds__(kBlock)
+k_compact_pairs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ idx, const uint8_t* __restrict__ flags,
+                const uint32_t* __restrict__ pos, size_t n, uint64_t* __restrict__ keys_out, uint32_t* __restrict__ idx_out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    keys_out[pos[i]] = keys[i];
+    idx_out[pos[i]] = idx[i];
+}
+hipError_t compact_pairs(const uint64_t* keys, const uint32_t* idx, const uint8_t* flags, const uint32_t* pos, size_t n,
+                         uint64_t* keys_out, uint32_t* idx_out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_compact_pairs<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(keys, idx, flags, pos, n, keys_out, idx_out);
+    return hipGetLastError();
+}
+
 __global__ void __launch_bounds__(kBlock)
 k_head_flags(const uint64_t* __restrict__ keys, size_t n, uint8_t* __restrict__ heads)
 {

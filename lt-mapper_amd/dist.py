@@ -12,7 +12,11 @@ per-keyframe stage runs on this rank's contiguous block of keyframes:
                        (sizes, then padded payload; reassembled in keyframe order) only when a stage needs every
                        keyframe: merging scans into a global map, and the final outputs.
 
-Everything else (merge, voxel grids of maps, the tiny weak->strong ND split) is replicated.  The collectives are
+  voxel grids of    -> the octree's Morton key space is cut into `world` contiguous ranges of equal point count; every
+  (replicated) maps    rank sorts/reduces its range (ltm_voxel_centroid_shard) and the centroid lists are all-gathered in
+                       rank order, which IS the single-GPU output (small clouds stay replicated).
+
+Everything else (merge, the tiny weak->strong ND split) is replicated.  The collectives are
 torch.distributed calls (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests), so the same code is exercised
 on CPU with world_size 2.  `ops` is any object with the stage interface of removerter.HipOps.
 """
@@ -45,6 +49,9 @@ class LazyScans:
 
 
 class ShardedOps:
+    # clouds below this many points are voxelised on every rank (replicated) instead of sharded + all-gathered
+    VOXEL_SHARD_MIN = 1 << 18
+
     def __init__(self, ops, dist, rank, world, group=None):
         self.ops, self.dist, self.rank, self.world, self.group = ops, dist, rank, world, group
         self._pose_slices = {}
@@ -80,6 +87,26 @@ class ShardedOps:
         self.dist.all_gather(bufs, pad, group=self.group)
         parts = [self.ops.scanset_from_tensors(bufs[r][: sizes[r]].contiguous(), counts[r]) for r in range(self.world)]
         return self.ops.concat_scansets(parts)
+
+    def _allgather_cloud(self, local):
+        """concatenation, in rank order, of every rank's cloud (sizes first, then one padded all-gather)"""
+        t = self.ops.cloud_to_tensor(local)
+        mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
+        sizes = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(sizes, mine, group=self.group)
+        sizes = [int(x.item()) for x in sizes]
+        cap = max(max(sizes), 1)
+        pad = torch.zeros((cap, 4), dtype=torch.float32, device=t.device)
+        pad[: t.shape[0]] = t
+        bufs = [torch.empty_like(pad) for _ in range(self.world)]
+        self.dist.all_gather(bufs, pad, group=self.group)
+        return self.ops.cloud_from_tensor(torch.cat([bufs[r][: sizes[r]] for r in range(self.world)]).contiguous())
+
+    # ---- voxel grid of a (replicated) cloud: each rank sorts and reduces one contiguous range of Morton keys
+    def voxel(self, c, leaf):
+        if self.world == 1 or self.ops.size(c) < self.VOXEL_SHARD_MIN:
+            return self.ops.voxel(c, leaf)
+        return self._allgather_cloud(self.ops.voxel_shard(c, leaf, self.rank, self.world))
 
     def materialize(self, scans):
         """full scan set on every rank (used for the final per-keyframe outputs)"""

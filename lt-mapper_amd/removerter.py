@@ -45,6 +45,7 @@ class HipOps:
     # stages
     def merge_to_global(self, scans, poses): return self.ctx.merge_to_global(scans, poses)
     def voxel(self, c, leaf): return self.ctx.voxel_centroid(c, leaf)
+    def voxel_shard(self, c, leaf, shard, n_shards): return self.ctx.voxel_centroid_shard(c, leaf, shard, n_shards)
     def voxel_scanset(self, s, leaf): return self.ctx.voxel_centroid_scanset(s, leaf)
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
     def reproject(self, cmap, poses, alpha): return self.ctx.reproject(cmap, poses, alpha)
@@ -84,6 +85,22 @@ class HipOps:
             return torch.zeros((0, 4), dtype=torch.float32, device=f"cuda:{self.ctx.device}"), off
         view = _DeviceArray(ss.device_ptr(), (n, 4), "<f4")
         return torch.as_tensor(view, device=f"cuda:{self.ctx.device}").clone(), off
+
+    def cloud_to_tensor(self, c):
+        """zero-copy (n, 4) float32 view of a device cloud; valid while `c` lives"""
+        import torch
+        n = len(c)
+        self.ctx.synchronize()
+        if n == 0:
+            return torch.zeros((0, 4), dtype=torch.float32, device=f"cuda:{self.ctx.device}")
+        return torch.as_tensor(_DeviceArray(c.device_ptr(), (n, 4), "<f4"), device=f"cuda:{self.ctx.device}")
+
+    def cloud_from_tensor(self, t):
+        import torch
+        torch.cuda.current_stream().synchronize()
+        if t.shape[0] == 0:
+            return self.empty_cloud()
+        return self.ctx.cloud_from_device(t.data_ptr(), t.shape[0])
 
     def scanset_from_tensors(self, pts, offsets):
         import torch

@@ -46,6 +46,14 @@ class OracleOps:
     def merge_to_global(self, s, p): return _c(orc.merge_to_global(s.pts, s.off, p.poses, self.l2b))
     def voxel(self, c, leaf): return _c(orc.voxel_centroid(c, leaf))
 
+    def voxel_shard(self, c, leaf, shard, n_shards):
+        # any contiguous split of the full output has the property ShardedOps relies on (concatenation == unsharded)
+        full = orc.voxel_centroid(c, leaf)
+        return _c(full[(len(full) * shard) // n_shards:(len(full) * (shard + 1)) // n_shards])
+
+    def cloud_to_tensor(self, c): return torch.from_numpy(np.ascontiguousarray(np.asarray(c), dtype=np.float32).reshape(-1, 4))
+    def cloud_from_tensor(self, t): return _c(t.numpy())
+
     def voxel_scanset(self, s, leaf):
         parts = [orc.voxel_centroid(s.pts[int(s.off[k]):int(s.off[k + 1])], leaf) for k in range(len(s.off) - 1)]
         return self._pack(parts)

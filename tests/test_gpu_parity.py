@@ -137,6 +137,27 @@ def test_voxel_centroid_matches_oracle(gpu_ctx, orc, small_pair):
     assert_clouds_equal(gpu_ctx.voxel_centroid(gpu_ctx.upload(same), 0.05).download(), orc.voxel_centroid(same, 0.05), "all in one voxel")
 
 
+def test_voxel_centroid_shards_concatenate_to_the_unsharded_output(gpu_ctx, orc, small_pair):
+    """multi-GPU form: every shard owns a contiguous Morton-key range; shards in order must reproduce the full output exactly"""
+    C, _ = small_pair
+    merged = orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4)
+    g_in = gpu_ctx.upload(merged)
+    for leaf in (0.05, 0.4):
+        want = orc.voxel_centroid(merged, leaf)
+        for n_shards in (1, 2, 3, 8, 61):
+            parts = [gpu_ctx.voxel_centroid_shard(g_in, leaf, r, n_shards).download() for r in range(n_shards)]
+            assert_clouds_equal(np.concatenate(parts), want, f"voxel shards leaf={leaf} n={n_shards}")
+            if n_shards in (2, 8) and leaf == 0.05:     # balanced: no shard more than twice the mean
+                assert max(len(p) for p in parts) <= 2 * len(want) / n_shards + 16
+    # degenerate: empty input, everything in one voxel (all but one shard empty)
+    assert len(gpu_ctx.voxel_centroid_shard(gpu_ctx.upload(np.zeros((0, 4), np.float32)), 0.05, 1, 2)) == 0
+    same = np.repeat(np.array([[1, 2, 3, 4]], np.float32), 1000, axis=0)
+    parts = [gpu_ctx.voxel_centroid_shard(gpu_ctx.upload(same), 0.05, r, 4).download() for r in range(4)]
+    assert_clouds_equal(np.concatenate(parts), orc.voxel_centroid(same, 0.05), "one voxel, four shards")
+    with pytest.raises(Exception):
+        gpu_ctx.voxel_centroid_shard(g_in, 0.05, 2, 2)
+
+
 def test_merge_and_preclean(gpu_ctx, orc, small_pair):
     C, _ = small_pair
     g_scans = gpu_ctx.upload_scans(C["scans"], C["offsets"])

@@ -95,12 +95,88 @@ def test_sharded_ops_world1_rccl_plumbing(ltm, orc, small_pair):
         C, Q = small_pair
         ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
         sessions = [Session(n, ctx.upload_scans(S["scans"], S["offsets"]), ctx.poses(S["poses"], S["inv"])) for n, S in (("Central", C), ("Query", Q))]
-        rmv = Removerter(ShardedOps(HipOps(ctx), dist, 0, 1), Params(), *sessions)
+        sops = ShardedOps(HipOps(ctx), dist, 0, 1)
+        rmv = Removerter(sops, Params(), *sessions)
         rmv.run()
         _compare(rmv, orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C, Q))
+        # the sharded voxel grid's exchange (bypassed by voxel() itself when world == 1)
+        cmap = rmv.outputs["OriginalNoisyCentralMapGlobal"]
+        via = sops._allgather_cloud(sops.ops.voxel_shard(cmap, 0.4, 0, 1))
+        np.testing.assert_array_equal(via.download(), sops.ops.voxel(cmap, 0.4).download())
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def _two_rank_worker(rank, world, port, q, C, Q):
+    import os
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here); sys.path.insert(0, os.path.dirname(here))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd import capi
+    from ltmapper_amd.dist import ShardedOps
+    from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
+    from staged_dist import StagedDist
+    ctx = capi.Context(vfov=50.0, hfov=360.0, device=0)
+    sessions = [Session(n, ctx.upload_scans(S["scans"], S["offsets"]), ctx.poses(S["poses"], S["inv"])) for n, S in (("Central", C), ("Query", Q))]
+    sops = ShardedOps(HipOps(ctx), StagedDist, rank, world)
+    sops.VOXEL_SHARD_MIN = 0
+    rmv = Removerter(sops, Params(), *sessions)
+    rmv.run()
+    maps = {k: v.download() for k, v in rmv.outputs.items() if v is not None}
+    scans = {k: sops.materialize(v).download() for k, v in rmv.scan_outputs().items()}
+    q.put((rank, maps, scans))
+    dist.barrier()
+    dist.destroy_process_group()
+    ctx.close()
+
+
+def test_sharded_ops_two_ranks_sharing_the_gpu(orc, small_pair):
+    """world_size 2 with the real HIP stages (keyframe shards, label union, rank-local scan sets, sharded voxel grids):
+    both ranks must end with the single-GPU (= oracle) result.  Collectives are staged through the host over gloo because
+    the test box has one GPU."""
+    import socket
+    import torch.multiprocessing as mp
+    C, Q = small_pair
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q, C, Q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    import queue
+    import time
+    results, deadline = [], time.time() + 240
+    while len(results) < 2:
+        try:
+            results.append(q.get(timeout=2))
+        except queue.Empty:
+            dead = [p for p in procs if p.exitcode not in (None, 0)]
+            if dead or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    ref = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C, Q)
+    for rank, maps, scans in results:
+        for name in MAPS:
+            want = ref.cloud(name)
+            if want is None:
+                assert name not in maps
+                continue
+            assert_clouds_equal(maps[name], want, f"rank {rank} {name}")
+        for name in SCANS:
+            w_pts, w_off = ref.scanset(name)
+            g_pts, g_off = scans[name]
+            assert (g_off == w_off).all(), f"rank {rank} {name}: per-keyframe counts differ"
+            assert_clouds_equal(g_pts, w_pts, f"rank {rank} {name}")
 
 
 def test_cascade_feeds_updated_scans_forward(ltm, orc):

@@ -67,7 +67,9 @@ def _worker(rank, world, port, q):
     from ltmapper_amd.dist import ShardedOps
     from oracle_ops import OracleOps
     C, Q = _tiny_pair()
-    out, scans = _run(ShardedOps(OracleOps(), dist, rank, world), C, Q)
+    sops = ShardedOps(OracleOps(), dist, rank, world)
+    sops.VOXEL_SHARD_MIN = 0          # the tiny maps of this test would otherwise stay replicated
+    out, scans = _run(sops, C, Q)
     q.put((rank, out, {k: (np.asarray(p), np.asarray(o)) for k, (p, o) in scans.items()}))
     dist.barrier()
     dist.destroy_process_group()
@@ -81,7 +83,18 @@ def test_keyframe_sharding_over_gloo_world2_matches_single_process(orc):
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    results = [q.get(timeout=300) for _ in range(2)]
+    import queue
+    import time
+    results, deadline = [], time.time() + 300
+    while len(results) < 2:
+        try:
+            results.append(q.get(timeout=2))
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs) or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
