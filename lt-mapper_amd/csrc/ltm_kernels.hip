@@ -14,6 +14,7 @@
 
 #include <algorithm>
 #include <cstring>
+#include <type_traits>
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
@@ -1457,19 +1458,47 @@ hipError_t hash_build(const uint64_t* sorted_keys, const uint32_t* starts, size_
 
 static constexpr int kMaxK = 16;
 
-// returns the coexist/near predicate of Session.cpp:590-599 for a global-frame query point
+// returns the coexist/near predicate of Session.cpp:590-599 for a global-frame query point.
+// KT > 0: k is the compile-time constant KT (and the target holds at least KT points): the k best distances live in
+// registers and are maintained by a branch-free insertion network.  KT == 0: any k <= kMaxK, indexed array.
+template <int KT>
 __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const float4* __restrict__ tgt, size_t Mt, const KnnGrid& g,
                                          const HashEntry* __restrict__ table, uint32_t mask, int k_param, float thr, float cell2_lo)
 {
     if (Mt == 0) return false;                        // reference: undefined; defined here as "far"
-    const int k = (int)min((size_t)k_param, Mt);      // pcl::KdTreeFLANN::nearestKSearch clamps k
-    float best[kMaxK];
+    const int k = KT ? KT : (int)min((size_t)k_param, Mt);      // pcl::KdTreeFLANN::nearestKSearch clamps k
+    float best[KT ? KT : kMaxK];
     int cnt = 0;
+    if (KT) {
+#pragma unroll
+        for (int j = 0; j < (KT ? KT : 1); ++j) best[j] = __builtin_inff();
+    }
     auto push = [&](float d) {
-        if (cnt == k && !(d < best[k - 1])) return;
-        int j = (cnt < k) ? cnt++ : k - 1;
-        while (j > 0 && best[j - 1] > d) { best[j] = best[j - 1]; --j; }
-        best[j] = d;
+        if (KT) {
+            // sorted insert: slot j takes its left neighbour if d goes before it, else the smaller of itself and d
+#pragma unroll
+            for (int j = (KT ? KT : 1) - 1; j >= 0; --j) {
+                if (j > 0) best[j] = (d < best[j - 1]) ? best[j - 1] : fminf(best[j], d);
+                else best[0] = fminf(best[0], d);
+            }
+            cnt = min(cnt + 1, k);
+        } else {
+            if (cnt == k && !(d < best[k - 1])) return;
+            int j = (cnt < k) ? cnt++ : k - 1;
+            while (j > 0 && best[j - 1] > d) { best[j] = best[j - 1]; --j; }
+            best[j] = d;
+        }
+    };
+    // float sum = accumulate(begin, end, 0.0): double accumulation in ascending order, narrowed to float
+    auto mean_below_thr = [&]() {
+        double acc = 0.0;
+        if (KT) {
+#pragma unroll
+            for (int j = 0; j < (KT ? KT : 1); ++j) if (j < cnt) acc = acc + (double)best[j];
+        } else {
+            for (int j = 0; j < cnt; ++j) acc = acc + (double)best[j];
+        }
+        return fabsf((float)acc / (float)k_param) < thr;
     };
     if (Mt <= 64 || (size_t)k_param > Mt) {
         for (size_t j = 0; j < Mt; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
@@ -1498,24 +1527,15 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
             }
             if (a == b) continue;
             for (uint32_t j = a; j < b; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
-            if (cnt == k && best[k - 1] < cell2_lo) {
-                double acc = 0.0;
-                for (int j = 0; j < k; ++j) acc = acc + (double)best[j];
-                if (fabsf((float)acc / (float)k_param) < thr) return true;
-            }
+            if (cnt == k && best[k - 1] < cell2_lo && mean_below_thr()) return true;
         }
         // fewer than k neighbours inside the provably-complete radius => the k-th neighbour is >= cell away => "diff"
         if (cnt < k || !(best[k - 1] < cell2_lo)) return false;
     }
-    // float sum = accumulate(begin, end, 0.0): double accumulation in ascending order, narrowed to float
-    double acc = 0.0;
-    for (int j = 0; j < cnt; ++j) acc = acc + (double)best[j];
-    const float sum = (float)acc;
-    const float avg = sum / (float)k_param;
-    return fabsf(avg) < thr;
+    return mean_below_thr();
 }
 
-template <bool B2L_IDENTITY>
+template <bool B2L_IDENTITY, int KT>
 __global__ void __launch_bounds__(kBlock)
 k_knn_query_scans(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
                   uint64_t n_pts, const double* __restrict__ poses, const double* __restrict__ inv_poses, HostMat34 b2l_h,
@@ -1535,7 +1555,7 @@ k_knn_query_scans(const float4* __restrict__ scans, const uint64_t* __restrict__
     float3 l = xform(load_mat(inv_poses + 12 * kf), gp);
     if (B2L_IDENTITY) l = xform_identity(l); else l = xform(to_dev(b2l_h), l);
     local_out[i] = make_float4(l.x, l.y, l.z, p4.w);
-    coexist[i] = knn_near(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
+    coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
 }
 hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
                            const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
@@ -1544,15 +1564,26 @@ hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, siz
 {
     if (!n_pts) return hipSuccess;
     if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
-    if (b2l_identity)
-        k_knn_query_scans<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, ke, first_pt, n_pts, poses_dev, inv_poses_dev,
-                                                                            b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, coexist, local_out);
-    else
-        k_knn_query_scans<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, ke, first_pt, n_pts, poses_dev, inv_poses_dev,
-                                                                             b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, coexist, local_out);
+    const int kt = (k <= 4 && Mt >= (size_t)k) ? k : 0;     // register-resident specialisations for the usual k (yaml 2, default 3)
+    auto launch = [&](auto b2l_tag, auto kt_tag) {
+        k_knn_query_scans<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(
+            scans, offsets_dev, kb, ke, first_pt, n_pts, poses_dev, inv_poses_dev, b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo,
+            coexist, local_out);
+    };
+    auto by_kt = [&](auto b2l_tag) {
+        switch (kt) {
+        case 1: launch(b2l_tag, std::integral_constant<int, 1>{}); break;
+        case 2: launch(b2l_tag, std::integral_constant<int, 2>{}); break;
+        case 3: launch(b2l_tag, std::integral_constant<int, 3>{}); break;
+        case 4: launch(b2l_tag, std::integral_constant<int, 4>{}); break;
+        default: launch(b2l_tag, std::integral_constant<int, 0>{}); break;
+        }
+    };
+    if (b2l_identity) by_kt(std::true_type{}); else by_kt(std::false_type{});
     return hipGetLastError();
 }
 
+template <int KT>
 __global__ void __launch_bounds__(kBlock)
 k_knn_query_cloud(const float4* __restrict__ query, size_t Q, const float4* __restrict__ tgt, size_t Mt, KnnGrid g,
                   const HashEntry* __restrict__ table, uint32_t mask, int k, float thr, float cell2_lo, uint8_t* __restrict__ near)
@@ -1560,14 +1591,24 @@ k_knn_query_cloud(const float4* __restrict__ query, size_t Q, const float4* __re
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= Q) return;
     const float4 q = query[i];
-    near[i] = knn_near(q.x, q.y, q.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
+    near[i] = knn_near<KT>(q.x, q.y, q.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
 }
 hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table,
                            uint32_t table_mask, int k, float thr, float cell2_lo, uint8_t* near, hipStream_t s)
 {
     if (!Q) return hipSuccess;
     if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
-    k_knn_query_cloud<<<dim3(grid_for(Q)), dim3(kBlock), 0, s>>>(query, Q, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, near);
+    const int kt = (k <= 4 && Mt >= (size_t)k) ? k : 0;
+    auto launch = [&](auto kt_tag) {
+        k_knn_query_cloud<decltype(kt_tag)::value><<<dim3(grid_for(Q)), dim3(kBlock), 0, s>>>(query, Q, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo, near);
+    };
+    switch (kt) {
+    case 1: launch(std::integral_constant<int, 1>{}); break;
+    case 2: launch(std::integral_constant<int, 2>{}); break;
+    case 3: launch(std::integral_constant<int, 3>{}); break;
+    case 4: launch(std::integral_constant<int, 4>{}); break;
+    default: launch(std::integral_constant<int, 0>{}); break;
+    }
     return hipGetLastError();
 }
 

@@ -184,7 +184,7 @@ def test_reproject_matches_oracle(gpu_ctx, orc, small_pair):
     assert gp.shape[0] == 1 and gp[0, 3] == 2.0
 
 
-@pytest.mark.parametrize("k,thr", [(2, 0.01), (3, 0.1), (1, 0.05)])
+@pytest.mark.parametrize("k,thr", [(2, 0.01), (3, 0.1), (1, 0.05), (4, 0.02), (6, 0.05)])   # k <= 4: register specialisations, 6: generic path
 def test_knn_partition_matches_oracle(gpu_ctx, orc, small_pair, k, thr):
     C, Q = small_pair
     target = orc.voxel_centroid(orc.merge_to_global(Q["scans"], Q["offsets"], Q["poses"], I4), 0.05)
