@@ -1424,10 +1424,12 @@ hipError_t gather_u64(const uint64_t* in, const uint32_t* idx, size_t n, uint64_
     return hipGetLastError();
 }
 
+// 32-bit mixer (two 32-bit multiplies; a 64-bit finaliser costs ~8 on this ISA and runs up to 27 times per query)
 __device__ __forceinline__ uint32_t hash64(uint64_t k)
 {
-    k ^= k >> 33; k *= 0xff51afd7ed558ccdull; k ^= k >> 33; k *= 0xc4ceb9fe1a85ec53ull; k ^= k >> 33;
-    return (uint32_t)k;
+    uint32_t x = (uint32_t)k ^ ((uint32_t)(k >> 32) * 0x9e3779b1u);
+    x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16;
+    return x;
 }
 static constexpr uint64_t kEmptyKey = ~0ull;
 
@@ -1503,8 +1505,14 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
     if (Mt <= 64 || (size_t)k_param > Mt) {
         for (size_t j = 0; j < Mt; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
     } else {
-        long long cx, cy, cz;
-        cell_of(g, qx, qy, qz, cx, cy, cz);
+        // 32-bit cell coordinates (every axis has < 2^20 cells); a query farther than one cell outside the grid gets the
+        // sentinel -2 so that all of its 27 cells fail the range test below
+        const double fx = floor(((double)qx - g.ox) * g.inv_cell), fy = floor(((double)qy - g.oy) * g.inv_cell),
+                     fz = floor(((double)qz - g.oz) * g.inv_cell);
+        const int nx = (int)g.nx, ny = (int)g.ny, nz = (int)g.nz;
+        const int cx = (fx >= -1.0 && fx <= (double)nx) ? (int)fx : -2;
+        const int cy = (fy >= -1.0 && fy <= (double)ny) ? (int)fy : -2;
+        const int cz = (fz >= -1.0 && fz <= (double)nz) ? (int)fz : -2;
         // 27 cells, centre first, then faces, edges, corners.  Early exit: as soon as the current k best already
         // satisfy the predicate the answer is final -- further neighbours can only lower the (monotonically
         // rounded) sum, so "coexist" cannot flip back.  Most queries of a static scene stop after the first cell.
@@ -1514,9 +1522,9 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
             {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1}, {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
             {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
         for (int c = 0; c < 27; ++c) {
-            const long long x = cx + kOrder[c][0], y = cy + kOrder[c][1], z = cz + kOrder[c][2];
-            if (x < 0 || y < 0 || z < 0 || x >= g.nx || y >= g.ny || z >= g.nz) continue;
-            const uint64_t key = cell_id(g, x, y, z);
+            const int x = cx + kOrder[c][0], y = cy + kOrder[c][1], z = cz + kOrder[c][2];
+            if ((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz) continue;
+            const uint64_t key = ((uint64_t)(uint32_t)x * (uint32_t)ny + (uint32_t)y) * (uint32_t)nz + (uint32_t)z;   // == cell_id()
             uint32_t h = hash64(key) & mask;
             uint32_t a = 0, b = 0;
             while (true) {
