@@ -146,6 +146,15 @@ int ltm_knn_split_cloud(ltm_ctx*, ltm_cloud target, ltm_cloud query, int k, floa
  * ptidx R*C int32 or NULL.  Host output buffers. */
 int ltm_debug_range_image(ltm_ctx*, ltm_cloud pts, const double* T1, const double* T2, float res_alpha,
                           float* rimg, int32_t* ptidx);
+/* The four RViz images of one keyframe (Removerter.cpp:580-585 pubRangeImg x4; utility.h:114-127 convertColorMappedImg =
+ * 255*(img-min)/(max-min) -> 8 bit -> cv::COLORMAP_JET), computed and colour-mapped on the device so that a ROS host only
+ * pays for them when somebody subscribes: scan range image, map range image (both on [range_min, range_max] =
+ * rimg_color_min/max), their difference (scan-map for mode 0, map-scan for mode 1, on [diff_min, diff_max] = 0..0.5 in
+ * RosParamServer.cpp:12) and the map point-index image (on [0, M]).  Each output is rows*cols*3 bytes BGR8
+ * (ltm_rimg_size) in host memory, or NULL to skip it. */
+int ltm_debug_viz_images(ltm_ctx*, ltm_cloud map, ltm_scanset scans, ltm_poses poses, size_t kf, float res_alpha, int mode,
+                         float range_min, float range_max, float diff_min, float diff_max,
+                         uint8_t* scan_bgr, uint8_t* map_bgr, uint8_t* diff_bgr, uint8_t* ptidx_bgr);
 /* element-wise device evaluation of the projection arithmetic: out_az_el_r (3n), out_row_col (2n) */
 int ltm_debug_project(ltm_ctx*, const float* xyz, size_t n, float res_alpha, float* out_az_el_r, int32_t* out_row_col);
 void ltm_rimg_size(float vfov, float hfov, float res_alpha, int* rows, int* cols);   /* utility.cpp:222-236 */

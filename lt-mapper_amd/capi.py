@@ -72,6 +72,7 @@ SIGNATURES = {
     "ltm_knn_partition": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _i, _f, _pu64, _pu64]),
     "ltm_knn_split_cloud": (_i, [_vp, _u64, _u64, _i, _f, _pu64, _pu64]),
     "ltm_debug_range_image": (_i, [_vp, _u64, _vp, _vp, _f, _vp, _vp]),
+    "ltm_debug_viz_images": (_i, [_vp, _u64, _u64, _u64, _sz, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ltm_debug_project": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
     "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
     "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),
@@ -221,6 +222,15 @@ class Context:
         out = _u64()
         self._ck(self.lib.ltm_voxel_centroid_shard(self.h, cloud.h, leaf, shard, n_shards, C.byref(out)))
         return Cloud(self, out.value)
+
+    def viz_images(self, cmap, scans, poses, kf, alpha, mode=0, range_axis=(0.0, 10.0), diff_axis=(0.0, 0.5)):
+        """the four RViz images of keyframe `kf` (Removerter.cpp:580-585) as (rows, cols, 3) BGR8 arrays"""
+        rows, cols = self.rimg_size(alpha)
+        out = {k: np.empty((rows, cols, 3), dtype=np.uint8) for k in ("scan", "map", "diff", "ptidx")}
+        self._ck(self.lib.ltm_debug_viz_images(self.h, cmap.h, scans.h, poses.h, kf, alpha, mode, range_axis[0], range_axis[1],
+                                               diff_axis[0], diff_axis[1], out["scan"].ctypes.data, out["map"].ctypes.data,
+                                               out["diff"].ctypes.data, out["ptidx"].ctypes.data))
+        return out
 
     def voxel_centroid_scanset(self, scans, leaf):
         out = _u64()

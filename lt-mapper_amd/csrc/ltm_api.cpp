@@ -1258,6 +1258,71 @@ int ltm_debug_range_image(ltm_ctx* c, ltm_cloud h, const double* T1, const doubl
     });
 }
 
+// cv::COLORMAP_JET as OpenCV builds it: 256 float samples of the piecewise-linear jet ramps, times 255, round half to even
+static void jet_lut_bgr(uint8_t* lut)
+{
+    for (int i = 0; i < 256; ++i) {
+        const double x = (double)i / 255.0;
+        const double bgr[3] = {std::min(4.0 * x + 0.5, 2.5 - 4.0 * x), std::min(4.0 * x - 0.5, 3.5 - 4.0 * x), std::min(4.0 * x - 1.5, 4.5 - 4.0 * x)};
+        for (int ch = 0; ch < 3; ++ch) {
+            const float sample = (float)std::min(1.0, std::max(0.0, bgr[ch]));
+            lut[3 * i + ch] = (uint8_t)std::min(255l, std::max(0l, std::lrint((double)(sample * 255.0f))));
+        }
+    }
+}
+
+int ltm_debug_viz_images(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hscans, ltm_poses hposes, size_t kf, float alpha, int mode,
+                         float range_min, float range_max, float diff_min, float diff_max,
+                         uint8_t* scan_bgr, uint8_t* map_bgr, uint8_t* diff_bgr, uint8_t* ptidx_bgr)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(mode == 0 || mode == 1, "mode must be 0 (scan-map) or 1 (map-scan)");
+        LTM_REQUIRE(range_max != range_min && diff_max != diff_min, "empty colour axis");
+        const Cloud map = get_cloud(c, hmap);
+        const ScanSet& ss = get_ss(c, hscans);
+        const Poses& ps = get_poses(c, hposes);
+        LTM_REQUIRE(ss.nkf() == ps.n && kf < ps.n, "keyframe out of range");
+        LTM_REQUIRE(map.n < 0x7fffffffull, "map too large for an int32 index image");
+        const Geom g = geom_for(c, alpha);
+        const size_t npx = (size_t)g.rows * g.cols;
+        const uint32_t* smax = nullptr;
+        const uint32_t* scan_img = scan_images(c, hscans, ss, kf, 1, g, &smax);          // scan2RangeImg
+        DevBuf img(c, npx * 8), mr(c, npx * 4), mi(c, npx * 4), df(c, npx * 4), out(c, npx * 3), lutd(c, 768);
+        LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, npx, c->stream));
+        if (map.n)                                                                         // transformGlobalMapToLocal + map2RangeImg (exact image)
+            LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kf, 1, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream));
+        LTM_HIP(decode_image(img.as<uint64_t>(), npx, mr.as<float>(), mi.as<int32_t>(), c->stream));
+        uint8_t lut[768];
+        jet_lut_bgr(lut);
+        h2d(c, lutd.p, lut, sizeof lut);
+        // cv::MatExpr folds 255 * (src - min) / (max - min) into src * a + b with a = 255 * (1/(max-min)), b = -255*min * (1/(max-min))
+        auto axis = [](float lo, float hi, double* a, double* b) {
+            const double inv = 1.0 / (double)(float)(hi - lo);
+            *a = 255.0 * inv; *b = -((double)lo * 255.0) * inv;
+        };
+        double a, b;
+        auto emit_f32 = [&](const float* src, uint8_t* host) {
+            if (!host) return;
+            LTM_HIP(viz_colormap_f32(src, npx, (float)a, (float)b, lutd.as<uint8_t>(), out.as<uint8_t>(), c->stream));
+            d2h(c, host, out.p, npx * 3);
+        };
+        axis(range_min, range_max, &a, &b);
+        emit_f32(reinterpret_cast<const float*>(scan_img), scan_bgr);
+        emit_f32(mr.as<float>(), map_bgr);
+        if (diff_bgr) {
+            LTM_HIP(viz_diff(scan_img, mr.as<float>(), npx, mode, df.as<float>(), c->stream));
+            axis(diff_min, diff_max, &a, &b);
+            emit_f32(df.as<float>(), diff_bgr);
+        }
+        if (ptidx_bgr) {
+            LTM_REQUIRE(map.n > 0, "index image of an empty map has no colour axis");
+            axis(0.0f, (float)map.n, &a, &b);                                              // Removerter.cpp:583
+            LTM_HIP(viz_colormap_i32(mi.as<int32_t>(), npx, a, b, lutd.as<uint8_t>(), out.as<uint8_t>(), c->stream));
+            d2h(c, ptidx_bgr, out.p, npx * 3);
+        }
+    });
+}
+
 int ltm_debug_project(ltm_ctx* c, const float* xyz, size_t n, float alpha, float* sph, int32_t* rc)
 {
     return guarded(c, [&] {

@@ -53,6 +53,10 @@ void set_map_kernel_variant(int v);   // 0 = per-point global atomics, 1 = LDS p
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,
                               uint64_t* img, hipStream_t s);
 hipError_t decode_image(const uint64_t* img, size_t npx, float* rimg, int32_t* ptidx, hipStream_t s);
+// RViz images: diff of a scan image (float bits) and a decoded map image; JET colour mapping of float / int32 images (BGR8)
+hipError_t viz_diff(const uint32_t* scan_bits, const float* map_r, size_t n, int mode, float* out, hipStream_t s);
+hipError_t viz_colormap_f32(const float* src, size_t n, float a, float b, const uint8_t* lut, uint8_t* bgr, hipStream_t s);
+hipError_t viz_colormap_i32(const int32_t* src, size_t n, double a, double b, const uint8_t* lut, uint8_t* bgr, hipStream_t s);
 hipError_t debug_project(const float* xyz_dev, size_t n, Geom g, float* az_el_r, int32_t* row_col, hipStream_t s);
 // exhaustive device self-check of the fast arithmetic forms against their exact definitions for (vfov, hfov):
 // counts[0] rad2deg mismatches, counts[1] /vfov mismatches, counts[2] /hfov mismatches over all 2^32 binary32 inputs

@@ -1620,4 +1620,52 @@ hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_t
     return hipGetLastError();
 }
 
+// ---- RViz images: convertColorMappedImg (utility.h:114-127) evaluated on the device
+__global__ void __launch_bounds__(kBlock)
+k_viz_diff(const uint32_t* __restrict__ scan_bits, const float* __restrict__ map_r, size_t n, int mode, float* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float s = u2f(scan_bits[i]), m = map_r[i];
+    out[i] = mode == 0 ? s - m : m - s;          // Removerter.cpp:572 (scan - map) / :519 (map - scan)
+}
+__global__ void __launch_bounds__(kBlock)
+k_viz_colormap_f32(const float* __restrict__ src, size_t n, float a, float b, const uint8_t* __restrict__ lut, uint8_t* __restrict__ bgr)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float v = src[i] * a + b;              // cv::Mat::convertTo on a float image: float multiply-add, not fused
+    int q = (v != v) ? 0 : (v <= -1.0f ? 0 : (v >= 256.0f ? 255 : __float2int_rn(v)));   // saturate_cast<uchar>: round half to even
+    q = min(max(q, 0), 255);
+    bgr[3 * i + 0] = lut[3 * q + 0]; bgr[3 * i + 1] = lut[3 * q + 1]; bgr[3 * i + 2] = lut[3 * q + 2];
+}
+__global__ void __launch_bounds__(kBlock)
+k_viz_colormap_i32(const int32_t* __restrict__ src, size_t n, double a, double b, const uint8_t* __restrict__ lut, uint8_t* __restrict__ bgr)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const double v = (double)src[i] * a + b;     // int32 image: double arithmetic, rounded to int, then saturated to 8 bits
+    int q = v <= -1.0 ? 0 : (v >= 256.0 ? 255 : __double2int_rn(v));
+    q = min(max(q, 0), 255);
+    bgr[3 * i + 0] = lut[3 * q + 0]; bgr[3 * i + 1] = lut[3 * q + 1]; bgr[3 * i + 2] = lut[3 * q + 2];
+}
+hipError_t viz_diff(const uint32_t* scan_bits, const float* map_r, size_t n, int mode, float* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_viz_diff<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(scan_bits, map_r, n, mode, out);
+    return hipGetLastError();
+}
+hipError_t viz_colormap_f32(const float* src, size_t n, float a, float b, const uint8_t* lut, uint8_t* bgr, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_viz_colormap_f32<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(src, n, a, b, lut, bgr);
+    return hipGetLastError();
+}
+hipError_t viz_colormap_i32(const int32_t* src, size_t n, double a, double b, const uint8_t* lut, uint8_t* bgr, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_viz_colormap_i32<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(src, n, a, b, lut, bgr);
+    return hipGetLastError();
+}
+
 } // namespace ltm

@@ -1,6 +1,7 @@
 // Removerter.h -- mirror of ltremovert::Removerter (ltremovert/include/removert/Removerter.h:67-201) over the C ABI.
 // Same public method names and the same run() script (Removerter.cpp:1653-1678); the bodies are calls into
-// libltm_hip.so.  ROS publishers / image transport (Removerter.cpp:55-71, 580-585) are visualisation only and absent.
+// libltm_hip.so.  The four RViz images of Removerter.cpp:580-585 come colour-mapped from the device (ltm_debug_viz_images)
+// through publishDebugImages(); point-cloud publishers (Removerter.cpp:55-71) are visualisation only and absent.
 #pragma once
 #include <memory>
 #include <string>
@@ -28,10 +29,18 @@ private:
     CloudPtr union_q_, union_c_;
 
     void saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout = true);
+    std::pair<CloudPtr, CloudPtr> votePartition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode);
+    int viz_pass_ = 0;
 
 public:
     Removerter();
-    ~Removerter();
+    virtual ~Removerter();
+
+    // pubRangeImg x4 (Removerter.cpp:580-585): called for every gpu_viz_every-th source keyframe of a vote pass with the
+    // BGR8 images /scan_rimg_single, /map_rimg_single, /diff_rimg_single, /map_rimg_ptidx_single.  The default writes
+    // <save_pcd_directory>viz/<pass>_<kf>_{scan,map,diff,ptidx}.ppm; the ROS wrapper overrides it with image_transport.
+    virtual void publishDebugImages(int pass, size_t kf, int rows, int cols, const uint8_t* scan_bgr, const uint8_t* map_bgr,
+                                    const uint8_t* diff_bgr, const uint8_t* ptidx_bgr);
 
     void loadSessionInfo(void);
     void parseKeyframes(void);

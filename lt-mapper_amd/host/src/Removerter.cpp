@@ -2,6 +2,8 @@
 #include "removert/Removerter.h"
 
 #include <chrono>
+#include <cstdio>
+#include <fstream>
 #include <iostream>
 #include <stdexcept>
 
@@ -72,12 +74,47 @@ void Removerter::makeGlobalMap(Session& _sess)
 void Removerter::makeGlobalMap(void) { makeGlobalMap(central_sess_); makeGlobalMap(query_sess_); }
 
 // Removerter.cpp:801-828 / :771-799 / :740-768 : one visibility vote + index-ascending split
-static std::pair<CloudPtr, CloudPtr> vote_partition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode)
+std::pair<CloudPtr, CloudPtr> Removerter::votePartition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode)
 {
+    ltm_ctx* ctx = tgt.dev_->ctx;
+    if (gpu_viz_every_ > 0 && map->size() > 0) {     // Removerter.cpp:580-585, only when asked for: it serialises the pass
+        int rows = 0, cols = 0;
+        ltm_rimg_size(kVFOV, kHFOV, res, &rows, &cols);
+        std::vector<uint8_t> img[4];
+        for (auto& v : img) v.resize((size_t)rows * cols * 3);
+        size_t n_kf = 0, n_pts = 0;
+        ltmCheck(ctx, ltm_scanset_info(ctx, scans->h, &n_kf, &n_pts), "ltm_scanset_info");
+        for (size_t kf = 0; kf < n_kf; kf += (size_t)gpu_viz_every_) {
+            ltmCheck(ctx, ltm_debug_viz_images(ctx, map->h, scans->h, src.poses_h_, kf, res, mode, kRangeColorAxis.first, kRangeColorAxis.second,
+                                               kRangeColorAxisForDiff.first, kRangeColorAxisForDiff.second, img[0].data(), img[1].data(),
+                                               img[2].data(), img[3].data()),
+                     "ltm_debug_viz_images");
+            publishDebugImages(viz_pass_, kf, rows, cols, img[0].data(), img[1].data(), img[2].data(), img[3].data());
+        }
+    }
+    ++viz_pass_;
     ltm_cloud kept = 0, flagged = 0;
-    ltmCheck(tgt.dev_->ctx, ltm_visibility_partition(tgt.dev_->ctx, map->h, scans->h, src.poses_h_, res, 0.1f, mode, &kept, &flagged, nullptr),
+    ltmCheck(ctx, ltm_visibility_partition(ctx, map->h, scans->h, src.poses_h_, res, 0.1f, mode, &kept, &flagged, nullptr),
              "ltm_visibility_partition");
     return {tgt.wrap(kept), tgt.wrap(flagged)};
+}
+
+void Removerter::publishDebugImages(int pass, size_t kf, int rows, int cols, const uint8_t* scan_bgr, const uint8_t* map_bgr,
+                                    const uint8_t* diff_bgr, const uint8_t* ptidx_bgr)
+{
+    const std::string dir = save_pcd_directory_ + "viz/";
+    fsmkdir(dir);
+    const uint8_t* src[4] = {scan_bgr, map_bgr, diff_bgr, ptidx_bgr};
+    const char* name[4] = {"scan", "map", "diff", "ptidx"};
+    std::vector<uint8_t> rgb((size_t)rows * cols * 3);
+    for (int i = 0; i < 4; ++i) {
+        for (size_t p = 0; p < (size_t)rows * cols; ++p) { rgb[3 * p] = src[i][3 * p + 2]; rgb[3 * p + 1] = src[i][3 * p + 1]; rgb[3 * p + 2] = src[i][3 * p]; }
+        char file[64];
+        std::snprintf(file, sizeof file, "%03d_%06zu_%s.ppm", pass, kf, name[i]);
+        std::ofstream o(dir + file, std::ios::binary);
+        o << "P6\n" << cols << " " << rows << "\n255\n";
+        o.write(reinterpret_cast<const char*>(rgb.data()), (std::streamsize)rgb.size());
+    }
 }
 
 std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMap(const Session& _target_sess, const Session& _source_sess, float _res_alpha)
@@ -88,7 +125,7 @@ std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMap(const Session& _ta
     LTM_INFO(" -- The range image size is: [" << curr_rimg_shape_.first << ", " << curr_rimg_shape_.second << "].");
     LTM_INFO(" -- The number of " << _target_sess.sess_type_ << " map points: " << _target_sess.map_global_curr_->size());
     LTM_INFO(" -- ... starts cleaning ... ");
-    auto r = vote_partition(_target_sess, _target_sess.map_global_curr_, _source_sess.keyframe_scans_, _source_sess, _res_alpha, 0);
+    auto r = votePartition(_target_sess, _target_sess.map_global_curr_, _source_sess.keyframe_scans_, _source_sess, _res_alpha, 0);
     LTM_INFO(" -- The number of dynamic points: " << r.second->size());
     LTM_INFO(" -- The number of static points: " << r.first->size());
     return r;
@@ -99,7 +136,7 @@ std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMapForND(const Session
     curr_rimg_shape_ = resetRimgSize(kFOV, _res_alpha);
     LTM_INFO(" -- The number of " << _target_sess.sess_type_ << " ND map points: " << _target_sess.map_global_nd_->size());
     LTM_INFO(" -- ... starts to clean ambiguous ND ... ");
-    return vote_partition(_target_sess, _target_sess.map_global_nd_, _source_sess.keyframe_scans_static_projected_, _source_sess, _res_alpha, 1);
+    return votePartition(_target_sess, _target_sess.map_global_nd_, _source_sess.keyframe_scans_static_projected_, _source_sess, _res_alpha, 1);
 }
 std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMapForPD(const Session& _target_sess, const Session& _source_sess, float _res_alpha)
 {
@@ -107,7 +144,7 @@ std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMapForPD(const Session
     curr_rimg_shape_ = resetRimgSize(kFOV, _res_alpha);
     LTM_INFO(" -- The number of " << _target_sess.sess_type_ << " PD map points: " << _target_sess.map_global_pd_->size());
     LTM_INFO(" -- ... starts to clean non-volume-extending PD ... ");
-    return vote_partition(_target_sess, _target_sess.map_global_pd_, _source_sess.keyframe_scans_static_projected_, _source_sess, _res_alpha, 0);
+    return votePartition(_target_sess, _target_sess.map_global_pd_, _source_sess.keyframe_scans_static_projected_, _source_sess, _res_alpha, 0);
 }
 
 static CloudPtr append(const Session& s, const CloudPtr& a, const CloudPtr& b) { return a ? s.concat({a, b}) : s.concat({b}); }

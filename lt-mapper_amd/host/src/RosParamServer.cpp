@@ -137,4 +137,5 @@ RosParamServer::RosParamServer()
     gpu_use_self_removert_ = getb("gpu_use_self_removert", false);
     gpu_skip_hd_knn_ = getb("gpu_skip_hd_knn", false);
     gpu_device_ = geti("gpu_device", 0);
+    gpu_viz_every_ = geti("gpu_viz_every", 0);
 }

@@ -859,3 +859,59 @@ int orc_run_timings(const orc_run* rr, const char** names, double* secs, int cap
 void orc_run_free(orc_run* r) { delete reinterpret_cast<Run*>(r); }
 
 } // extern "C"
+
+/* ------------------------------------------------------------------ RViz images (visualisation only) */
+extern "C" void orc_jet_lut(uint8_t* lut)
+{
+    /* OpenCV's Jet base map: 256 samples of r(x) = clamp(min(4x - 1.5, -4x + 4.5)), g(x) = clamp(min(4x - 0.5, -4x + 3.5)),
+       b(x) = clamp(min(4x + 0.5, -4x + 2.5)) at x = i/255, stored as float, then convertTo(CV_8U, 255.) */
+    for (int i = 0; i < 256; ++i) {
+        const double x = (double)i / 255.0;
+        const double ch[3] = {std::min(4.0 * x + 0.5, -4.0 * x + 2.5), std::min(4.0 * x - 0.5, -4.0 * x + 3.5),
+                              std::min(4.0 * x - 1.5, -4.0 * x + 4.5)};                       /* B, G, R */
+        for (int c = 0; c < 3; ++c) {
+            const float lit = (float)std::min(1.0, std::max(0.0, ch[c]));
+            const float v = lit * 255.0f;
+            const long q = std::lrint((double)v);               /* round half to even, as cv::saturate_cast<uchar> */
+            lut[3 * i + c] = (uint8_t)(q < 0 ? 0 : q > 255 ? 255 : q);
+        }
+    }
+}
+
+static inline void orc_axis(float cmin, float cmax, double* a, double* b)
+{
+    const double inv = 1.0 / (double)(float)(cmax - cmin);    /* cv::MatExpr: e / s == e * (1./s) */
+    *a = 255.0 * inv;
+    *b = -((double)cmin * 255.0) * inv;
+}
+
+extern "C" void orc_colormap_f32(const float* src, size_t n, float cmin, float cmax, uint8_t* bgr)
+{
+    uint8_t lut[768];
+    orc_jet_lut(lut);
+    double a, b;
+    orc_axis(cmin, cmax, &a, &b);
+    const float fa = (float)a, fb = (float)b;
+    for (size_t i = 0; i < n; ++i) {
+        const float v = src[i] * fa + fb;                    /* float image: float arithmetic, no FMA */
+        long q = std::isnan(v) ? 0 : (v <= -1.f ? 0 : v >= 256.f ? 255 : std::lrint((double)v));
+        if (q < 0) q = 0;
+        if (q > 255) q = 255;
+        std::memcpy(bgr + 3 * i, lut + 3 * q, 3);
+    }
+}
+
+extern "C" void orc_colormap_i32(const int32_t* src, size_t n, float cmin, float cmax, uint8_t* bgr)
+{
+    uint8_t lut[768];
+    orc_jet_lut(lut);
+    double a, b;
+    orc_axis(cmin, cmax, &a, &b);
+    for (size_t i = 0; i < n; ++i) {
+        const double v = (double)src[i] * a + b;             /* int32 image: double arithmetic, rounded to int first */
+        long q = v <= -1.0 ? 0 : v >= 256.0 ? 255 : std::lrint(v);
+        if (q < 0) q = 0;
+        if (q > 255) q = 255;
+        std::memcpy(bgr + 3 * i, lut + 3 * q, 3);
+    }
+}

@@ -82,6 +82,16 @@ void orc_merge_to_global(const float* scans, const uint64_t* offsets, size_t n_k
 size_t orc_preclean(const float* pts, size_t n, float radius, float* out);
 
 /* ---- full pipeline: Removerter::run() Steps 1-3 (Removerter.cpp:1653-1678) on in-memory sessions ---- */
+/* ---- RViz images (utility.h:114-127 convertColorMappedImg, utility.cpp:248-256 pubRangeImg, Removerter.cpp:580-585) ----
+ * dst8 = saturate_u8(round_half_even(src*a + b)), a = 255*(1/(max-min)), b = -255*min*(1/(max-min)) as cv::MatExpr folds
+ * them (double scalars, float arithmetic for float images, double for int32 images), then cv::COLORMAP_JET, BGR order.
+ * PARITY UNPINNED: OpenCV 4.2 is not in /root/reference; the JET table is restated from its published construction
+ * (256 float samples of the piecewise-linear jet ramps, *255.f, round-half-even); every ramp entry is a rounding tie
+ * (127.5 + 4i), so single entries may differ by 1 LSB from the library's table. */
+void orc_jet_lut(uint8_t* lut_bgr /* 256*3 */);
+void orc_colormap_f32(const float* src, size_t n, float cmin, float cmax, uint8_t* bgr);
+void orc_colormap_i32(const int32_t* src, size_t n, float cmin, float cmax, uint8_t* bgr);
+
 typedef struct {
     float vfov, hfov;                 /* sequence_vfov / sequence_hfov */
     int   k;                          /* num_nn_points_within */

@@ -122,6 +122,24 @@ def vote_labels(cmap, scans, offsets, inv_poses, b2l, vfov, hfov, alpha, thr=0.1
     return labels
 
 
+def jet_lut():
+    lut = np.empty((256, 3), dtype=np.uint8)
+    lib().orc_jet_lut(_p(lut))
+    return lut
+
+
+def colormap(img, cmin, cmax):
+    """convertColorMappedImg (utility.h:114-127): float32 or int32 image -> BGR8"""
+    a = np.ascontiguousarray(img)
+    out = np.empty(a.shape + (3,), dtype=np.uint8)
+    if a.dtype == np.int32:
+        lib().orc_colormap_i32(_p(a), _sz(a.size), _f(cmin), _f(cmax), _p(out))
+    else:
+        a = np.ascontiguousarray(a, dtype=np.float32)
+        lib().orc_colormap_f32(_p(a), _sz(a.size), _f(cmin), _f(cmax), _p(out))
+    return out
+
+
 def voxel_centroid(pts, leaf):
     a = _pts(pts)
     out = np.empty((max(a.shape[0], 1), 4), dtype=np.float32)

@@ -116,6 +116,8 @@ def test_ltm_run_file_protocol(tmp_path, orc):
   num_nn_points_within: 2
   dist_nn_points_within: 0.01
   num_omp_cores: 16
+  rimg_color_max: 20.0
+  gpu_viz_every: 7      # RViz images of every 7th source keyframe of each vote pass -> <out>/viz/*.ppm
 """)
     r = subprocess.run([exe, str(yaml)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
@@ -173,3 +175,24 @@ def test_ltm_run_file_protocol(tmp_path, orc):
             assert hdr == (HDR.format(w=1, h=n, n=n) if octree else HDR.format(w=n, h=1, n=n))
             close(got, w_pts[int(w_off[j]):int(w_off[j + 1])], f"{d}/{nm}")
     assert (outdir / "map_static").is_dir() and (outdir / "map_dynamic").is_dir()
+
+    # ---- the device-rendered RViz images of pass 0 (central self-removal at 2.5), keyframe 0
+    viz = sorted(os.listdir(outdir / "viz"))
+    n_src = len(c_kf)
+    assert sum(1 for v in viz if v.startswith("000_")) == 4 * ((n_src + 6) // 7), viz[:8]
+    rows, cols = orc.rimg_size(50.0, 360.0, 2.5)
+
+    def read_ppm(path):
+        raw = open(path, "rb").read()
+        head = f"P6\n{cols} {rows}\n255\n".encode()
+        assert raw.startswith(head) and len(raw) == len(head) + rows * cols * 3
+        return np.frombuffer(raw[len(head):], np.uint8).reshape(rows, cols, 3)[:, :, ::-1]      # RGB file -> BGR
+
+    _, cmap0 = read_pcd(str(outdir / "OriginalNoisyCentralMapGlobal.pcd"))
+    map_r, map_i = orc.range_image(cmap0, 50.0, 360.0, rows, cols, T1=C["inv"][0], T2=np.eye(4))
+    scan_r, _ = orc.range_image(C["scans"][int(C["offsets"][0]):int(C["offsets"][1])], 50.0, 360.0, rows, cols, want_idx=False)
+    for name, want in (("scan", orc.colormap(scan_r, 0.0, 20.0)), ("map", orc.colormap(map_r, 0.0, 20.0)),
+                       ("diff", orc.colormap(scan_r - map_r, 0.0, 0.5)), ("ptidx", orc.colormap(map_i, 0.0, float(len(cmap0))))):
+        got = read_ppm(str(outdir / "viz" / f"000_000000_{name}.ppm"))
+        bad = (got != want).any(axis=2).mean()
+        assert bad <= (0.0 if name == "scan" else 5e-3), f"viz {name}: {bad:.4%} of the pixels differ"   # inverse-pose last bits may move a few map pixels

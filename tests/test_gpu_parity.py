@@ -158,6 +158,26 @@ def test_voxel_centroid_shards_concatenate_to_the_unsharded_output(gpu_ctx, orc,
         gpu_ctx.voxel_centroid_shard(g_in, 0.05, 2, 2)
 
 
+@pytest.mark.parametrize("mode", [0, 1])
+def test_viz_images_match_oracle_colormap(gpu_ctx, orc, small_pair, mode):
+    """the four RViz images (pubRangeImg x4, Removerter.cpp:580-585) colour-mapped on the device"""
+    C, _ = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), 0.05)
+    g_map, g_scans, g_poses = gpu_ctx.upload(cmap), gpu_ctx.upload_scans(C["scans"], C["offsets"]), gpu_ctx.poses(C["poses"], C["inv"])
+    kf, alpha = 3, 2.5
+    rows, cols = orc.rimg_size(50.0, 360.0, alpha)
+    a, b = int(C["offsets"][kf]), int(C["offsets"][kf + 1])
+    scan_r, _ = orc.range_image(C["scans"][a:b], 50.0, 360.0, rows, cols, want_idx=False)
+    map_r, map_i = orc.range_image(cmap, 50.0, 360.0, rows, cols, T1=C["inv"][kf], T2=I4)
+    diff = (scan_r - map_r) if mode == 0 else (map_r - scan_r)
+    got = gpu_ctx.viz_images(g_map, g_scans, g_poses, kf, alpha, mode=mode, range_axis=(0.0, 20.0), diff_axis=(0.0, 0.5))
+    np.testing.assert_array_equal(got["scan"], orc.colormap(scan_r, 0.0, 20.0))
+    np.testing.assert_array_equal(got["map"], orc.colormap(map_r, 0.0, 20.0))
+    np.testing.assert_array_equal(got["diff"], orc.colormap(diff, 0.0, 0.5))
+    np.testing.assert_array_equal(got["ptidx"], orc.colormap(map_i, 0.0, float(len(cmap))))
+    assert len(np.unique(got["map"].reshape(-1, 3), axis=0)) > 20        # a real picture, not a constant
+
+
 def test_merge_and_preclean(gpu_ctx, orc, small_pair):
     C, _ = small_pair
     g_scans = gpu_ctx.upload_scans(C["scans"], C["offsets"])

@@ -126,3 +126,20 @@ def test_atan2f_restatement_matches_host_libm_bitwise():
     out = subprocess.run([os.path.join(here, "pin_atan2f"), "26", "1"], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "atanf exhaustive 2^32 inputs: 0 mismatches" in out.stdout
+
+
+def test_jet_colormap_known_entries(orc):
+    """cv::COLORMAP_JET anchor colours (BGR): dark blue, blue, cyan-ish, green-ish centre, yellow-ish, red, dark red; and the
+    saturating 8-bit conversion of convertColorMappedImg (utility.h:114-127)"""
+    lut = orc.jet_lut()
+    assert tuple(lut[0]) == (128, 0, 0) and tuple(lut[255]) == (0, 0, 128)
+    assert tuple(lut[32]) == (255, 0, 0) and tuple(lut[33]) == (255, 4, 0)      # blue saturates where green starts
+    assert tuple(lut[96]) == (254, 255, 2) and tuple(lut[159]) == (2, 255, 254)  # cyan -> yellow through the green plateau
+    assert tuple(lut[223]) == (0, 0, 255) and tuple(lut[224]) == (0, 0, 252)     # red plateau ends
+    assert (np.diff(lut[:, 2].astype(int)[:200]) >= 0).all()                     # red channel rises monotonically up to its plateau
+    img = np.array([[-5.0, 0.0, 10.0, 20.0, 10000.0]], np.float32)
+    out = orc.colormap(img, 0.0, 20.0)
+    assert (out[0, 0] == lut[0]).all() and (out[0, 1] == lut[0]).all() and (out[0, 3] == lut[255]).all() and (out[0, 4] == lut[255]).all()
+    assert (out[0, 2] == lut[128]).all()                                         # 127.5 rounds half to even -> 128
+    idx = np.array([[0, 50, 100]], np.int32)
+    assert (orc.colormap(idx, 0.0, 100.0)[0, 2] == lut[255]).all()
