@@ -647,6 +647,11 @@ hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const 
 //   phase 2   survivors (a few per pixel) get the exact arithmetic and the usual 64-bit LDS/global min.
 // The result is bit-identical to k_map_rimg_lds / the serial reference: discarded points are provably not arg-mins.
 static constexpr int kBmSlots = 1024;
+static constexpr int kBmQueue = 2048;     // survivor queue capacity (~11 % of 4096 expected); overflow: the whole tile goes exact
+// per-point record / queue entry: tile-local index (12 bits) | row (9) | column (11).  Row field 511 = pixel not certain
+// (needs the full exact projection).  Images with >= 511 rows or >= 2048 columns mark every point that way.
+static constexpr uint32_t kBmRowUncertain = 511u;
+static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain survivors (~1 % of the tile); beyond it they are handled in place
 
 template <bool B2L_IDENTITY>
 __global__ void __launch_bounds__(kBlock)
@@ -656,13 +661,14 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     __shared__ uint64_t vals[kBmSlots];
     __shared__ uint32_t tags[kBmSlots];
     __shared__ uint32_t amin[kBmSlots];
-    __shared__ uint16_t queue[kBlock * kPtsPerThread];
-    __shared__ uint32_t qcount;
+    __shared__ uint32_t queue[kBmQueue];
+    __shared__ uint16_t uqueue[kBmUQueue];
+    __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     if (!tk.valid) return;
     for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; amin[s] = 0x7f800000u; }
-    if (threadIdx.x == 0) qcount = 0;
+    if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
     __syncthreads();
     const RimgGeom g = make_geom(gg);
     const uint32_t npx = (uint32_t)(g.rows * g.cols);
@@ -673,9 +679,10 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
     const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
     const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
-    // per-lane record of the 16 points: slot (0xffff = survive unconditionally) and range lower bound
+    const bool packable = g.rows < (int)kBmRowUncertain && g.cols <= 2048;
+    // per-lane record of the 16 points: range lower bound and (row | col | flags); flags: bit 31 = owns an amin slot, bit 30 = a point
     float rlo[kPtsPerThread];
-    uint16_t slot_of[kPtsPerThread];
+    uint32_t rec[kPtsPerThread];
     // ---- phase 1a (four points per lane in flight, as in k_vote_map_cull)
 #pragma unroll
     for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
@@ -698,8 +705,9 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u;
             rlo[j] = cc[u].r_lo;
-            slot_of[j] = live[u] ? 0xffff : 0xfffe;                   // 0xfffe = not a point, 0xffff = survive unconditionally
-            if (!live[u] | cc[u].unusual | !ok | cc[u].multi) continue;
+            const bool certain = packable & ok & !cc[u].unusual & !cc[u].multi;
+            rec[j] = (live[u] ? 0x40000000u : 0u) | ((certain ? (uint32_t)cc[u].rb : kBmRowUncertain) << 11) | (uint32_t)(cc[u].cb & 2047);
+            if (!live[u] | !certain) continue;
             const uint32_t px = (uint32_t)(cc[u].rb * g.cols + cc[u].cb);
             const int slot = ((cc[u].rb & 15) << 6) | (cc[u].cb & 63);
             uint32_t t = tags[slot];
@@ -708,19 +716,23 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
                 t = (old == kEmptyTag) ? px : old;
             }
             if (t != px) continue;                                     // slot owned by another pixel: survive unconditionally
-            slot_of[j] = (uint16_t)slot;
-            atomicMin(&amin[slot], f2u(cc[u].r_lo * (1.0f + 3.5e-6f)));   // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6))
+            rec[j] |= 0x80000000u;
+            // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6)).  amin only ever decreases, so a plain read that is
+            // already smaller makes the (same-address, hence serialised) atomic unnecessary for most points of a pixel
+            const uint32_t hi = f2u(cc[u].r_lo * (1.0f + 3.5e-6f));
+            if (hi < amin[slot]) atomicMin(&amin[slot], hi);
         }
     }
     __syncthreads();
-    // ---- phase 1b
+    // ---- phase 1b: a point survives unless it owns a slot and some point of the tile is provably nearer in the same pixel
 #pragma unroll
     for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
         bool sv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const uint16_t sl = slot_of[j0 + u];
-            sv[u] = (sl != 0xfffe) && ((sl == 0xffff) || !(rlo[j0 + u] > u2f(amin[sl & (kBmSlots - 1)])));
+            const uint32_t rc = rec[j0 + u];
+            const int slot = (int)((((rc >> 11) & 15u) << 6) | (rc & 63u));
+            sv[u] = (rc & 0x40000000u) && (!(rc & 0x80000000u) || !(rlo[j0 + u] > u2f(amin[slot])));
         }
         // one LDS atomic per wave and group of four (see k_vote_map_cull)
         const uint64_t b0 = __builtin_amdgcn_ballot_w64(sv[0]), b1 = __builtin_amdgcn_ballot_w64(sv[1]),
@@ -737,35 +749,49 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         for (int u = 0; u < 4; ++u) {
             if (!sv[u]) continue;
             const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-            queue[base + off[u] + below] = (uint16_t)((uint32_t)(j0 + u) * kBlock + threadIdx.x);
+            const uint32_t pos = base + off[u] + below;
+            if (pos < (uint32_t)kBmQueue)
+                queue[pos] = (((uint32_t)(j0 + u) * kBlock + threadIdx.x) << 20) | (rec[j0 + u] & 0xfffffu);
         }
     }
     __syncthreads();
-    // ---- phase 2: exact arithmetic for the survivors
+    // ---- phase 2: survivors.  Certain pixel: only the exact range; the others are re-queued densely and get the full exact projection
     const uint32_t nq = qcount;
     if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled diagnostic
         atomicAdd(&g_cull_stats[2], (unsigned long long)nq);
         atomicAdd(&g_cull_stats[3], (unsigned long long)nloc);
     }
     const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
-    for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
-        const uint32_t i = block_base + queue[q];
-        const float4 p4 = map[i];
-        float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
-        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
-        const Sph s = cart2sph(p.x, p.y, p.z);
-        int row, col;
-        pixel_row_col(g, s.az, s.el, row, col);
-        const uint32_t px = (uint32_t)(row * g.cols + col);
-        const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
-        const int slot = ((row & 15) << 6) | (col & 63);
-        uint32_t t = tags[slot];
-        if (t == kEmptyTag) {
-            const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-            t = (old == kEmptyTag) ? px : old;
+    if (__builtin_expect(nq > (uint32_t)kBmQueue, 0)) {      // queue overflow: a superset is always correct (min is idempotent)
+        for (uint32_t li = threadIdx.x; li < nloc; li += kBlock)
+            exact_insert<B2L_IDENTITY, 16, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
+    } else {
+        for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
+            const uint32_t e = queue[q];
+            const uint32_t li = e >> 20;
+            const int row = (int)((e >> 11) & 511u), col = (int)(e & 2047u);
+            const uint32_t i = block_base + li;
+            if (row == (int)kBmRowUncertain) {
+                const uint32_t up = atomicAdd(&ucount, 1u);
+                if (up < (uint32_t)kBmUQueue) uqueue[up] = (uint16_t)li;
+                else exact_insert<B2L_IDENTITY, 16, 64>(map, i, Tinv, b2l_h, g, vals, tags, imgk);
+                continue;
+            }
+            const uint32_t px = (uint32_t)(row * g.cols + col);
+            const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
+            const int slot = ((row & 15) << 6) | (col & 63);
+            uint32_t t = tags[slot];
+            if (t == kEmptyTag) {
+                const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+                t = (old == kEmptyTag) ? px : old;
+            }
+            if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+            else img_min_u64(imgk + px, v);
         }
-        if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
-        else img_min_u64(imgk + px, v);
+        __syncthreads();
+        const uint32_t nu = min(ucount, (uint32_t)kBmUQueue);
+        for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
+            exact_insert<B2L_IDENTITY, 16, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
     }
     __syncthreads();
     for (int s = threadIdx.x; s < kBmSlots; s += kBlock) {
