@@ -279,7 +279,7 @@ k_map_rimg_lds(const float4* __restrict__ map, uint32_t M, const double* __restr
             const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
             t = (old == kEmptyTag) ? px : old;
         }
-        if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+        if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
         else img_min_u64(imgk + px, v);
     }
     __syncthreads();
@@ -402,7 +402,7 @@ __device__ __forceinline__ void exact_insert(const float4* __restrict__ map, uin
         const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
         t = (old == kEmptyTag) ? px : old;
     }
-    if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+    if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
     else img_min_u64(imgk + px, v);
 }
 
@@ -555,7 +555,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                     const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
                     t = (old == kEmptyTag) ? px : old;
                 }
-                if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+                if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
                 else img_min_u64(imgk + px, v);
             }
             __syncthreads();
@@ -785,7 +785,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
                 const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
                 t = (old == kEmptyTag) ? px : old;
             }
-            if (t == px) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v);
+            if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
             else img_min_u64(imgk + px, v);
         }
         __syncthreads();
