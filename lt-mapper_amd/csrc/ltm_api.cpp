@@ -128,6 +128,7 @@ struct ltm_ctx {
     std::vector<ScanImgEntry> scan_cache;
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
+    int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
 };
 
 namespace {
@@ -499,6 +500,9 @@ void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3])
 // With n_shards > 1 only the voxels of shard `shard` are produced: the Morton key space is cut into n_shards contiguous
 // ranges holding about n/n_shards points each (cut points on a 4096-bin histogram of the key prefix, so they are a pure
 // function of the input), and the outputs of shards 0..n_shards-1 concatenated are exactly the unsharded output.
+//
+// Sort layout: when Morton bits + index bits fit one 64-bit word (always, for clouds the 32-bit index allows and octrees up
+// to depth 10-13) the pair travels packed and the radix sort is keys-only over the Morton bits; otherwise key/index pairs.
 size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf, float4** out, uint32_t shard = 0, uint32_t n_shards = 1)
 {
     *out = nullptr;
@@ -510,16 +514,21 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
     bbox_of(c, pts, n_in, mn, mx);
     OctreeFrame f;
     if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+    const unsigned mbits = 3 * f.depth;
+    unsigned ib = 1;
+    while (ib < 32 && ((size_t)1 << ib) < n_in) ++ib;
+    const bool packed = c->voxel_packed_sort && mbits + ib <= 64;
+    const unsigned kshift = packed ? ib : 0;                       // Morton code = key >> kshift
     size_t n = n_in;
-    DevBuf keys(c, n * 8), idx(c, n * 4);
-    LTM_HIP(morton_keys(pts, n, f, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
+    DevBuf keys(c, n * 8), idx(c, packed ? 8 : n * 4);
+    if (packed) LTM_HIP(morton_keys_packed(pts, n, f, ib, keys.as<uint64_t>(), c->stream));
+    else LTM_HIP(morton_keys(pts, n, f, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
     if (n_shards > 1) {
-        const unsigned bits = 3 * f.depth;
-        const unsigned shift = bits > 12 ? bits - 12 : 0;
+        const unsigned shift = mbits > 12 ? mbits - 12 : 0;
         std::vector<uint32_t> hist(kVoxelKeyBins);
         {
             DevBuf hd(c, kVoxelKeyBins * sizeof(uint32_t));
-            LTM_HIP(key_histogram(keys.as<uint64_t>(), n, shift, hd.as<uint32_t>(), c->stream));
+            LTM_HIP(key_histogram(keys.as<uint64_t>(), n, shift + kshift, hd.as<uint32_t>(), c->stream));
             d2h(c, hist.data(), hd.p, kVoxelKeyBins * sizeof(uint32_t));
         }
         // cut b (1..n_shards-1) = first bin whose preceding count reaches b*n/n_shards
@@ -534,8 +543,9 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
             }
             return kVoxelKeyBins;
         };
-        const uint64_t lo = cut(shard) << shift;
-        const uint64_t hi = (shard + 1 >= n_shards) ? ~0ull : (cut(shard + 1) << shift);
+        auto bound = [&](uint64_t bin) { return bin >= (uint64_t)kVoxelKeyBins ? ~0ull : bin << (shift + kshift); };
+        const uint64_t lo = bound(cut(shard));
+        const uint64_t hi = (shard + 1 >= n_shards) ? ~0ull : bound(cut(shard + 1));
         DevBuf flags(c, n), pos(c, n * 4);
         LTM_HIP(key_range_flags(keys.as<uint64_t>(), n, lo, hi, flags.as<uint8_t>(), c->stream));
         const size_t tb = scan_temp_bytes(n);
@@ -543,21 +553,25 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
         LTM_HIP(exclusive_scan_u8(flags.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
         const size_t nsel = scan_total_u8(c, flags.as<uint8_t>(), pos.as<uint32_t>(), n);
         if (nsel == 0) return 0;
-        DevBuf ck(c, nsel * 8), ci(c, nsel * 4);
-        LTM_HIP(compact_pairs(keys.as<uint64_t>(), idx.as<uint32_t>(), flags.as<uint8_t>(), pos.as<uint32_t>(), n,
-                              ck.as<uint64_t>(), ci.as<uint32_t>(), c->stream));
+        DevBuf ck(c, nsel * 8), ci(c, packed ? 8 : nsel * 4);
+        if (packed) LTM_HIP(compact_keys(keys.as<uint64_t>(), flags.as<uint8_t>(), pos.as<uint32_t>(), n, ck.as<uint64_t>(), c->stream));
+        else LTM_HIP(compact_pairs(keys.as<uint64_t>(), idx.as<uint32_t>(), flags.as<uint8_t>(), pos.as<uint32_t>(), n,
+                                   ck.as<uint64_t>(), ci.as<uint32_t>(), c->stream));
         std::swap(keys.p, ck.p); std::swap(idx.p, ci.p);
         n = nsel;
     }
-    DevBuf keys2(c, n * 8), idx2(c, n * 4);
-    const size_t stb = sort_temp_bytes(n);
-    {
+    DevBuf keys2(c, n * 8), idx2(c, packed ? 8 : n * 4);
+    if (packed) {
+        const size_t stb = sort_keys_temp_bytes(n);
         DevBuf stemp(c, stb);
-        LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, 3 * f.depth,
-                               stemp.p, stb, c->stream));
+        LTM_HIP(sort_keys_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), n, ib, ib + mbits, stemp.p, stb, c->stream));
+    } else {
+        const size_t stb = sort_temp_bytes(n);
+        DevBuf stemp(c, stb);
+        LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, mbits, stemp.p, stb, c->stream));
     }
     DevBuf heads(c, n), pos(c, n * 4);
-    LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
+    LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream, kshift));
     const size_t tb = scan_temp_bytes(n);
     DevBuf temp(c, tb);
     LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
@@ -565,7 +579,8 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
     DevBuf starts(c, nvox * 4);
     LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
     float4* o = reinterpret_cast<float4*>(c->pool.alloc(nvox * sizeof(float4)));
-    LTM_HIP(voxel_centroids(pts, idx2.as<uint32_t>(), starts.as<uint32_t>(), nvox, n, o, c->stream));
+    if (packed) LTM_HIP(voxel_centroids_packed(pts, keys2.as<uint64_t>(), ((uint64_t)1 << ib) - 1, starts.as<uint32_t>(), nvox, n, o, c->stream));
+    else LTM_HIP(voxel_centroids(pts, idx2.as<uint32_t>(), starts.as<uint32_t>(), nvox, n, o, c->stream));
     *out = o;
     return nvox;
 }
@@ -724,6 +739,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (!ok) { (void)hipStreamDestroy(c->stream); delete c; return LTM_E_DEVICE; }
         c->fast_math = (c->selfcheck[0] == 0 && c->selfcheck[1] == 0 && c->selfcheck[2] == 0) ? 1 : 0;
         if (const char* v = getenv("LTM_FAST_MATH")) c->fast_math = c->fast_math && atoi(v);
+        if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
     }
     *out = c;
     return LTM_OK;

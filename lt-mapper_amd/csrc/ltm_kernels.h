@@ -103,7 +103,15 @@ hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_
 size_t sort_temp_bytes(size_t n);
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
                           unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s);
+hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s, unsigned shift = 0);   // compares keys >> shift
+// packed voxel path: (Morton << idx_bits) | index in one word, keys-only sort over the Morton bits
+hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, unsigned idx_bits, uint64_t* keys, hipStream_t s);
+size_t sort_keys_temp_bytes(size_t n);
+hipError_t sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, size_t n, unsigned begin_bit, unsigned end_bit, void* temp,
+                         size_t temp_bytes, hipStream_t s);
+hipError_t voxel_centroids_packed(const float4* pts, const uint64_t* sorted_keys, uint64_t idx_mask, const uint32_t* starts, size_t n_vox,
+                                  size_t n, float4* out, hipStream_t s);
+hipError_t compact_keys(const uint64_t* keys, const uint8_t* flags, const uint32_t* pos, size_t n, uint64_t* keys_out, hipStream_t s);
 // sharded voxel grid: 4096-bin histogram of (key >> shift), range flags, order-preserving compaction of (key, index)
 static constexpr int kVoxelKeyBins = 4096;
 hipError_t key_histogram(const uint64_t* keys, size_t n, unsigned shift, uint32_t* hist, hipStream_t s);

@@ -1268,6 +1268,40 @@ hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* key
     k_morton_keys<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, f, keys, idx);
     return hipGetLastError();
 }
+// packed form: (Morton code << idx_bits) | point index in ONE 64-bit word, so that the sort moves 8 B per element instead of
+// 12 B (keys-only radix sort over the Morton bits; it is stable, so equal codes keep their ascending point indices)
+__global__ void __launch_bounds__(kBlock)
+k_morton_keys_packed(const float4* __restrict__ pts, size_t n, OctreeFrame f, unsigned idx_bits, uint64_t* __restrict__ keys)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p = pts[i];
+    const uint32_t kx = (uint32_t)(((double)p.x - f.minx) / f.res);
+    const uint32_t ky = (uint32_t)(((double)p.y - f.miny) / f.res);
+    const uint32_t kz = (uint32_t)(((double)p.z - f.minz) / f.res);
+    keys[i] = ((((spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz))) << idx_bits) | (uint64_t)i;
+}
+hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, unsigned idx_bits, uint64_t* keys, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_morton_keys_packed<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, f, idx_bits, keys);
+    return hipGetLastError();
+}
+size_t sort_keys_temp_bytes(size_t n)
+{
+    size_t bytes = 0;
+    uint64_t* k = nullptr;
+    (void)rocprim::radix_sort_keys(nullptr, bytes, k, k, n ? n : 1, 0, 64);
+    return bytes + 256;
+}
+hipError_t sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, size_t n, unsigned begin_bit, unsigned end_bit, void* temp,
+                         size_t temp_bytes, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    if (end_bit > 64) end_bit = 64;
+    if (end_bit <= begin_bit) end_bit = begin_bit + 1;
+    return rocprim::radix_sort_keys(temp, temp_bytes, keys_in, keys_out, n, begin_bit, end_bit, s);
+}
 
 size_t sort_temp_bytes(size_t n)
 {
@@ -1331,6 +1365,20 @@ k_compact_pairs(const uint64_t* __restrict__ keys, const uint32_t* __restrict__ 
     keys_out[pos[i]] = keys[i];
     idx_out[pos[i]] = idx[i];
 }
+__global__ void __launch_bounds__(kBlock)
+k_compact_keys(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ flags, const uint32_t* __restrict__ pos, size_t n,
+               uint64_t* __restrict__ keys_out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n || !flags[i]) return;
+    keys_out[pos[i]] = keys[i];
+}
+hipError_t compact_keys(const uint64_t* keys, const uint8_t* flags, const uint32_t* pos, size_t n, uint64_t* keys_out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_compact_keys<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(keys, flags, pos, n, keys_out);
+    return hipGetLastError();
+}
 hipError_t compact_pairs(const uint64_t* keys, const uint32_t* idx, const uint8_t* flags, const uint32_t* pos, size_t n,
                          uint64_t* keys_out, uint32_t* idx_out, hipStream_t s)
 {
@@ -1340,16 +1388,16 @@ hipError_t compact_pairs(const uint64_t* keys, const uint32_t* idx, const uint8_
 }
 
 __global__ void __launch_bounds__(kBlock)
-k_head_flags(const uint64_t* __restrict__ keys, size_t n, uint8_t* __restrict__ heads)
+k_head_flags(const uint64_t* __restrict__ keys, size_t n, unsigned shift, uint8_t* __restrict__ heads)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
-    heads[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+    heads[i] = (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1 : 0;
 }
-hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s)
+hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s, unsigned shift)
 {
     if (!n) return hipSuccess;
-    k_head_flags<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(keys, n, heads);
+    k_head_flags<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(keys, n, shift, heads);
     return hipGetLastError();
 }
 __global__ void __launch_bounds__(kBlock)
@@ -1384,6 +1432,29 @@ k_voxel_centroids(const float4* __restrict__ pts, const uint32_t* __restrict__ s
     }
     const float cnt = (float)(b - a);
     out[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+}
+__global__ void __launch_bounds__(kBlock)
+k_voxel_centroids_packed(const float4* __restrict__ pts, const uint64_t* __restrict__ sorted_keys, uint64_t idx_mask,
+                         const uint32_t* __restrict__ starts, size_t n_vox, size_t n, float4* __restrict__ out)
+{
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vox) return;
+    const uint32_t a = starts[v];
+    const uint32_t b = (v + 1 < n_vox) ? starts[v + 1] : (uint32_t)n;
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+    for (uint32_t j = a; j < b; ++j) {
+        const float4 p = pts[sorted_keys[j] & idx_mask];
+        sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
+    }
+    const float cnt = (float)(b - a);
+    out[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+}
+hipError_t voxel_centroids_packed(const float4* pts, const uint64_t* sorted_keys, uint64_t idx_mask, const uint32_t* starts, size_t n_vox,
+                                  size_t n, float4* out, hipStream_t s)
+{
+    if (!n_vox) return hipSuccess;
+    k_voxel_centroids_packed<<<dim3(grid_for(n_vox)), dim3(kBlock), 0, s>>>(pts, sorted_keys, idx_mask, starts, n_vox, n, out);
+    return hipGetLastError();
 }
 hipError_t voxel_centroids(const float4* pts, const uint32_t* sorted_idx, const uint32_t* starts, size_t n_vox, size_t n,
                            float4* out, hipStream_t s)
