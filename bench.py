@@ -29,6 +29,7 @@ import torch  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
 
+DEFAULT_WORKLOAD = "lot-2x500-os1-64-3res"
 WORKLOADS = {
     # name: (sensor, keyframes per session, 3-res?, scene, kf spacing [m], voxel [m], kNN k, kNN thr)
     "lot-2x500-os1-64-3res": ("os1-64", 500, True, "lot", 1.0, 0.05, 2, 0.01),        # BASELINE configs[1] (default)
@@ -45,7 +46,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--workload", default="lot-2x500-os1-64-3res", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
     ap.add_argument("--cpu-stride", type=int, default=100, help="cpu_baseline: visit every s-th keyframe in per-keyframe loops")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
@@ -145,7 +146,7 @@ def main():
         achieved = vm["bytes"] / (vm["ms"] * 1e-3) / 1e9
         roofline = {"bound": "hbm", "kernel": "k_vote_map_cull" if cls == "vote_map_cull" else "k_map_rimg_blockmin",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(cls), "launches_per_step": vm["launches"] // max(args.steps, 1),
+                    "traffic": measured_traffic(cls, args.workload), "launches_per_step": vm["launches"] // max(args.steps, 1),
                     "avg_launch_ms": round(vm["ms"] / vm["launches"], 4),
                     "algorithmic_bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
                     "algorithmic_definition": "nb*(16*M + 8*R*C) per launch over nb keyframes (SURVEY 8d: map read + range|index image)",
@@ -180,11 +181,11 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(cls):
+def measured_traffic(cls, workload):
     """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
-    inside this process; the file records the command).  None if no measurement exists for this kernel."""
+    inside this process; the file records the command).  None if no measurement exists for this kernel and workload."""
     path = os.path.join(ROOT, "profiles", "r1_final_pmc_hbm_traffic.json")
-    if cls != "vote_map_cull" or not os.path.exists(path):
+    if cls != "vote_map_cull" or workload != DEFAULT_WORKLOAD or not os.path.exists(path):
         return None
     try:
         return round(json.load(open(path))["hbm_bytes_per_launch"], 1)
