@@ -110,8 +110,8 @@ def test_tile_cull_equals_no_tile_cull_on_kitti_scale_street(ltm):
     S = synth.make_session(1, 300, "hdl-64e", device="cuda:0", scene="street", kf_spacing=2.0)
     torch.cuda.synchronize()
     out, dt = {}, {}
-    for tc in (1, 0):
-        ctx = _ctx(ltm, LTM_TILE_CULL=tc)
+    for tc in (1, 0, "exact"):
+        ctx = _ctx(ltm, **(dict(LTM_VOTE_CULL=0) if tc == "exact" else dict(LTM_TILE_CULL=tc)))
         scans, poses, cmap = _load(ctx, S)
         lab = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda")
         ctx.visibility_vote(cmap, scans, poses, 0, poses.n, 2.5, 0.1, 0, lab.data_ptr())      # warm (scan images cached)
@@ -122,4 +122,5 @@ def test_tile_cull_equals_no_tile_cull_on_kitti_scale_street(ltm):
         out[tc] = lab.cpu().numpy()
         ctx.close()
     assert out[1].sum() > 100 and (out[1] == out[0]).all()
-    print(f"tile cull: {dt[1] * 1e3:.1f} ms vs {dt[0] * 1e3:.1f} ms without")
+    assert (out[1] == out["exact"]).all(), "culled vote differs from the exact-image vote on the street scene"
+    print(f"tile cull: {dt[1] * 1e3:.1f} ms vs {dt[0] * 1e3:.1f} ms without, exact-image vote {dt['exact'] * 1e3:.1f} ms")
