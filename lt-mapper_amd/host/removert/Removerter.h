@@ -87,6 +87,7 @@ public:
     void saveStrongNDScans(Session& _sess);
     void saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout);
 
+    void saveKeyframePoses(const Session& _sess);   // <save_pcd_directory>scans_updated_poses.txt: poses matching scans_updated/ (cascade hand-over)
     void run(void);
 };
 

@@ -343,6 +343,23 @@ void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _
     LTM_INFO(" " << scans.size() << " scans saved under " << _save_dir);
 }
 
+// Lifelong hand-over (reference README.md:115-118 leaves it to the user): scans_updated/ holds one file per
+// central KEYFRAME, while the session's pose file has one line per SCAN, so pointing central_sess_scan_dir at scans_updated/ for
+// the next run needs the matching subset of poses.  This writes it next to the scans, in the input format (12 numbers per line,
+// round-trip precision); the next run uses start_idx 0, end_idx n-1, keyframe_gap 1.
+void Removerter::saveKeyframePoses(const Session& _sess)
+{
+    const std::string file = save_pcd_directory_ + "scans_updated_poses.txt";
+    std::ofstream o(file);
+    o.precision(17);
+    for (const Matrix4d& T : _sess.keyframe_poses_) {
+        for (int i = 0; i < 12; ++i) o << (i ? " " : "") << T[i];
+        o << "\n";
+    }
+    if (!o) throw std::runtime_error("cannot write " + file);
+    LTM_INFO(" keyframe poses of the central session saved: " << file);
+}
+
 void Removerter::run(void)                                                         // Removerter.cpp:1653-1678
 {
     using clk = std::chrono::steady_clock;
@@ -366,6 +383,7 @@ void Removerter::run(void)                                                      
     updateScansScanwise();
     const auto t2 = clk::now();
     saveAllTypeOfScans();
+    saveKeyframePoses(central_sess_);
     const auto t3 = clk::now();
     auto s = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
     LTM_INFO(" [timing] step0 (load+map) " << s(t0, t1) << " s, steps 1-3 " << s(t1, t2) << " s (includes map PCD writes), scan writes " << s(t2, t3) << " s");

@@ -196,3 +196,42 @@ def test_ltm_run_file_protocol(tmp_path, orc):
         got = read_ppm(str(outdir / "viz" / f"000_000000_{name}.ppm"))
         bad = (got != want).any(axis=2).mean()
         assert bad <= (0.0 if name == "scan" else 5e-3), f"viz {name}: {bad:.4%} of the pixels differ"   # inverse-pose last bits may move a few map pixels
+
+    # ---- lifelong hand-over through the file protocol.  Run 2: central := scans_updated/ of run 1 with the pose
+    # subset ltm_run wrote next to it, query := session 02 again (the synthetic sessions 01 and 03 do not overlap within 40 keyframes).  The loader re-applies VoxelGrid + pre-clean, as the reference would.
+    n_c = len(c_kf)
+    out2 = tmp_path / "out2"
+    yaml2 = tmp_path / "params2.yaml"
+    yaml2.write_text(yaml.read_text().replace(f'save_pcd_directory: "{outdir}"', f'save_pcd_directory: "{out2}/"')
+                     .replace(f'central_sess_scan_dir: "{dirs[0]}/"', f'central_sess_scan_dir: "{outdir}/scans_updated/"')
+                     .replace(f'central_sess_pose_path: "{tmp_path}/01/poses.txt"', f'central_sess_pose_path: "{outdir}/scans_updated_poses.txt"')
+                     .replace(f"start_idx: {start_idx}", "start_idx: 0").replace(f"end_idx: {end_idx}", f"end_idx: {n_c - 1}")
+                     .replace("gpu_viz_every: 7", "gpu_viz_every: 0"))
+    pose_lines = open(outdir / "scans_updated_poses.txt").read().split("\n")[:-1]
+    assert len(pose_lines) == n_c
+    got_poses = np.array([[float(v) for v in ln.split()] for ln in pose_lines])
+    assert (got_poses == sess[0]["poses"].reshape(-1, 16)[c_kf][:, :12]).all(), "pose subset must round-trip exactly"
+    r = subprocess.run([exe, str(yaml2)], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    upd = [read_pcd(str(outdir / "scans_updated" / sess[0]["names"][k]))[1] for k in c_kf]
+    pts2, off2 = [], [0]
+    for p in upd:
+        q = orc.preclean(voxel_grid(p, 0.05), 2.5)
+        pts2.append(q); off2.append(off2[-1] + len(q))
+    poses2 = sess[0]["poses"].reshape(-1, 16)[c_kf].copy()
+    C2 = dict(scans=np.concatenate(pts2), offsets=np.array(off2, np.uint64), poses=poses2,
+              inv=np.array([np.linalg.inv(p.reshape(4, 4)).reshape(16) for p in poses2]))
+    c2_pos = poses2.reshape(-1, 4, 4)[:, :3, 3]
+    q3_pos = sess[1]["poses"].reshape(-1, 4, 4)[:, :3, 3]
+    q3_kf = [k for k in range(n_kf) if np.sqrt(((c2_pos - q3_pos[k]) ** 2).sum(1)).min() <= 10.0]
+    Q3 = load(sess[1], q3_kf)
+    ref2 = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C2, Q3)
+    for fname in ("updated_map", "pd_map", "nd_map"):
+        want = ref2.cloud(fname)
+        if want is None:
+            assert not (out2 / (fname + ".pcd")).exists()
+            continue
+        close(read_pcd(str(out2 / (fname + ".pcd")))[1], want, "cascade run 2 " + fname)
+    w_pts, w_off = ref2.scanset("scans_updated")
+    for j, k in enumerate(c_kf):
+        close(read_pcd(str(out2 / "scans_updated" / sess[0]["names"][k]))[1], w_pts[int(w_off[j]):int(w_off[j + 1])], f"cascade run 2 scans_updated/{k}")
