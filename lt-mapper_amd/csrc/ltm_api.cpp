@@ -292,12 +292,16 @@ void approx_pose(const double* b2l16, const double* inv16, float* out)
                            (f * g - d * i) / det, (a * i - c3 * g) / det, (c3 * d - a * f) / det,
                            (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
     const double t[3] = {T[3], T[7], T[11]};
+    double c_lo[3];
     for (int r = 0; r < 3; ++r) {
         const double cr = -(inv[3 * r] * t[0] + inv[3 * r + 1] * t[1] + inv[3 * r + 2] * t[2]);
         out[9 + r] = (float)cr;
-        out[12 + r] = (float)(cr - (double)out[9 + r]);
+        c_lo[r] = cr - (double)out[9 + r];
         for (int k = 0; k < 3; ++k) out[3 * r + k] = (float)T[4 * r + k];
     }
+    // A (p - c) = A (p - c_hi) - A c_lo: the second term is a per-keyframe constant, folded into the first FMA of each row
+    for (int r = 0; r < 3; ++r)
+        out[12 + r] = (float)-((double)out[3 * r] * c_lo[0] + (double)out[3 * r + 1] * c_lo[1] + (double)out[3 * r + 2] * c_lo[2]);
     // out[15] doubles as a lower bound of the smallest singular value of A (Gershgorin on A^T A, rounded down): the tile
     // range cull needs |A v| >= smin |v|.  Poses from 6-significant-digit text are rotations up to ~1e-6.
     double gmin = 1e300;

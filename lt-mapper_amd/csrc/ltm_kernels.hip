@@ -308,19 +308,20 @@ static constexpr float kCullEpsPx = 3.0e-3f;
 
 // rb/cb: the pixel if it is certain; multi: within kCullEpsPx of a rounding boundary (candidates r0..r1 x c0..c1, filled by
 // cull_expand); r_lo: lower bound of the exact range (upper bound = r_lo * (1 + 3e-6)); unusual: outside the fast forms' domain
-struct CullCand { int rb, cb, r0, r1, c0, c1; float rowh, colh, r_lo; bool multi, unusual; };
+struct CullCand { int rb, cb, r0, r1, c0, c1; float rowh, colh, r_lo, r; bool multi, unusual; };
 
 // p' = A (p - c): the inverse pose (composed with base->lidar) rewritten around the sensor position c so that the
-// subtraction happens between nearby numbers; c is carried as a float-float pair.  Relative error of p' <= 5e-7
-// (binary32 roundings only), i.e. <= 5e-7 rad of direction error at any range.  16 floats per keyframe.
+// subtraction happens between nearby numbers; c is carried as a float-float pair (c_hi, c_lo) and the tiny constant
+// -A c_lo is precomputed per keyframe (ap[12..14]) and enters through the first FMA of each row.  Relative error of p'
+// <= 5e-7 (binary32 roundings only), i.e. <= 5e-7 rad of direction error at any range.  16 floats per keyframe.
 __device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, float4 p4, bool& ok)
 {
-    const float dx = (p4.x - ap[9]) - ap[12], dy = (p4.y - ap[10]) - ap[13], dz = (p4.z - ap[11]) - ap[14];
+    const float dx = p4.x - ap[9], dy = p4.y - ap[10], dz = p4.z - ap[11];
     ok = ap[15] != 0.0f;
     float3 o;
-    o.x = __builtin_fmaf(ap[2], dz, __builtin_fmaf(ap[1], dy, ap[0] * dx));
-    o.y = __builtin_fmaf(ap[5], dz, __builtin_fmaf(ap[4], dy, ap[3] * dx));
-    o.z = __builtin_fmaf(ap[8], dz, __builtin_fmaf(ap[7], dy, ap[6] * dx));
+    o.x = __builtin_fmaf(ap[2], dz, __builtin_fmaf(ap[1], dy, __builtin_fmaf(ap[0], dx, ap[12])));
+    o.y = __builtin_fmaf(ap[5], dz, __builtin_fmaf(ap[4], dy, __builtin_fmaf(ap[3], dx, ap[13])));
+    o.z = __builtin_fmaf(ap[8], dz, __builtin_fmaf(ap[7], dy, __builtin_fmaf(ap[6], dx, ap[14])));
     return o;
 }
 
@@ -340,13 +341,14 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     // rowh/colh are bounded (|atan| <= pi) unless something upstream made a NaN, and a NaN fails the "<=" below as well.
     const float rfr = __builtin_amdgcn_fractf(cc.rowh), cfr = __builtin_amdgcn_fractf(cc.colh);   // distance above the rounding boundary
     const bool certain = fmaxf(fabsf(rfr - 0.5f), fabsf(cfr - 0.5f)) <= 0.5f - kCullEpsPx;
-    cc.unusual = (p.y == 0.0f) | !(cc.rowh + cc.colh + r < 3.0e4f);   // NaN anywhere, absurd ranges (r >= ~2.8e4 incl. inf)
+    cc.unusual = (p.y == 0.0f) | !(cc.rowh + cc.colh + r < 3.0e4f);   // NaN anywhere (e.g. denormal y with x = 0), absurd ranges (r >= ~2.8e4 incl. inf)
     cc.multi = !certain;
     // clamp(floor(v), 0, n-1) == trunc(med3(v, 0, n-1)): the bounds are integers and the clamped value is non-negative
     cc.rb = (int)__builtin_amdgcn_fmed3f(cc.rowh, 0.0f, g.frows - 1.0f);
     cc.cb = (int)__builtin_amdgcn_fmed3f(cc.colh, 0.0f, g.fcols - 1.0f);
     cc.r0 = cc.r1 = cc.rb; cc.c0 = cc.c1 = cc.cb;
     cc.r_lo = r * (1.0f - 1.5e-6f);
+    cc.r = r;
     return cc;
 }
 
@@ -444,7 +446,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         float d2 = 0.0f, far2 = 0.0f;
 #pragma unroll
         for (int d = 0; d < 3; ++d) {
-            const float c = ap[9 + d] + ap[12 + d];
+            const float c = ap[9 + d];                            // sensor position to ~1e-5 m: the margins below are 1e-2
             const float lo = tb[d] - c, hi = c - tb[3 + d];
             const float e = fmaxf(fmaxf(lo, hi), 0.0f);          // distance to the box along this axis
             const float f = fmaxf(fabsf(lo), fabsf(hi));          // distance to its farthest face
@@ -497,9 +499,10 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
             bool mt[kInFlight];
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
-                const float thr_lo = thr - (1.0e-3f + cc[u].r_lo * 3.0e-6f);
+                // s - r_lo > thr - (1e-3 + 3e-6 r_lo) with r_lo = r (1 - 1.5e-6), i.e. s - r (1 - 4.5e-6) > thr - 1e-3, rounded to the
+                // conservative side (1 - 5e-6) so that one FMA and one compare decide
                 const float s = u2f(s0[u]);
-                bool m = cc[u].unusual | ((s < 9000.0f) & ((s - cc[u].r_lo) > thr_lo));
+                bool m = cc[u].unusual | ((s < 9000.0f) & (__builtin_fmaf(cc[u].r, -(1.0f - 5.0e-6f), s) > thr - 1.0e-3f));
                 if (__builtin_expect(cc[u].multi & !m, 0)) { cull_expand(g, cc[u]); m = cull_matters(cc[u], scank, g.cols, thr); }
                 mt[u] = m & live[u];
             }
