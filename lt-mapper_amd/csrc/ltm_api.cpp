@@ -398,7 +398,9 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
         ProfScope p(c, "vote_scan", (double)npts, (double)npts * 16 + (double)(nb * npx) * 4);
         LTM_HIP(fill_u32(buf, kNoPointBits, nb * npx, c->stream));
         LTM_HIP(hipMemsetAsync(smax, 0, nb * sizeof(uint32_t), c->stream));
-        LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, g, buf, smax, c->stream));
+        uint64_t longest = 0;
+        for (size_t k = kb; k < kb + nb; ++k) longest = std::max<uint64_t>(longest, ss.off[k + 1] - ss.off[k]);
+        LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, longest, g, buf, smax, c->stream));
     }
     c->scan_cache.push_back(ScanImgEntry{ss_handle, g.rows, g.cols, kb, nb, buf, smax, bytes, ++c->scan_cache_stamp});
     *smax_out = smax;
@@ -1228,7 +1230,9 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
         DevBuf flag(c, std::max<size_t>(n, 1)), local(c, std::max<size_t>(n, 1) * 16);
         {
             ProfScope ps(c, "knn_query", (double)n, (double)n * (16.0 + 16.0 * k + 1.0));
-            LTM_HIP(knn_query_scans(s.d, s.off_dev, kf_begin, kf_end, first, n, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.sorted,
+            uint64_t longest = 0;
+            for (size_t k = kf_begin; k < kf_end; ++k) longest = std::max<uint64_t>(longest, s.off[k + 1] - s.off[k]);
+            LTM_HIP(knn_query_scans(s.d, s.off_dev, kf_begin, kf_end, first, n, longest, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.sorted,
                                     index.Mt, index.g, index.table, index.mask, k, thr, index.cell2_lo, flag.as<uint8_t>(), local.as<float4>(), c->stream));
         }
         std::vector<uint64_t> bounds(kf_end - kf_begin + 1);

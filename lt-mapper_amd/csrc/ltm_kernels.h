@@ -26,7 +26,7 @@ hipError_t fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 // scan2RangeImg for keyframes [kb, kb+nb): scan_img[(kf-kb)*npx + px] = min range bits
 // smax_bits (nb entries, zero-initialised by the caller, may be null): per keyframe the float bits of the largest scan range
 hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb,
-                             uint64_t first_pt, uint64_t n_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s);
+                             uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s);
 // bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);
 void set_stats_select(int v);
@@ -132,7 +132,7 @@ struct HashEntry { uint64_t key; uint32_t start, end; };
 hipError_t hash_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, size_t n_pts,
                       HashEntry* table, uint32_t table_mask, hipStream_t s);
 // queries in scan sets: g = pose*(first*p) ; label = coexist ; local = b2l*(inv*g)
-hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
+hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
                            const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
                            const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask,
                            int k, float thr, float cell2_lo, uint8_t* coexist, float4* local_out, hipStream_t s);

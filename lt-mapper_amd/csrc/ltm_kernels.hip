@@ -103,15 +103,12 @@ __global__ void __launch_bounds__(kBlock)
 k_scan_rimg(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t nb,
             uint64_t first_pt, uint64_t n_pts, Geom gg, uint32_t* __restrict__ img)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pts) return;
-    const uint64_t gi = first_pt + i;
-    // keyframe of this point: largest kf in [kb, kb+nb) with offsets[kf] <= gi
-    size_t lo = kb, hi = kb + nb;
-    while (hi - lo > 1) {
-        const size_t mid = (lo + hi) >> 1;
-        if (offsets[mid] <= gi) lo = mid; else hi = mid;
-    }
+    // grid = (chunks of the longest keyframe, keyframes): the keyframe comes from blockIdx.y instead of a binary search over
+    // the offsets (nine dependent loads per point)
+    const size_t lo = kb + blockIdx.y;
+    const uint64_t a = offsets[lo], local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= offsets[lo + 1] - a) return;
+    const uint64_t gi = a + local;
     const RimgGeom g = make_geom(gg);
     const float4 p = scans[gi];
     const Sph s = cart2sph(p.x, p.y, p.z);
@@ -143,9 +140,14 @@ k_image_max(const uint32_t* __restrict__ img, uint32_t npx, uint32_t* __restrict
 }
 
 hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t first_pt,
-                             uint64_t n_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s)
+                             uint64_t n_pts, uint64_t max_kf_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s)
 {
-    if (n_pts) k_scan_rimg<<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb, nb, first_pt, n_pts, g, scan_img);
+    if (n_pts && max_kf_pts)
+        for (size_t k0 = 0; k0 < nb; k0 += 65535) {       // gridDim.y limit
+            const size_t nk = std::min<size_t>(65535, nb - k0);
+            k_scan_rimg<<<dim3(grid_for(max_kf_pts), (unsigned)nk), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb + k0, nk, first_pt, n_pts, g,
+                                                                                        scan_img + k0 * (size_t)(g.rows * g.cols));
+        }
     if (smax_bits && nb) {
         const uint32_t npx = (uint32_t)(g.rows * g.cols);
         k_image_max<<<dim3(std::min<unsigned>(grid_for(npx, kBlock * 8), 64), (unsigned)nb), dim3(kBlock), 0, s>>>(scan_img, npx, smax_bits);
@@ -1650,10 +1652,11 @@ k_knn_query_scans(const float4* __restrict__ scans, const uint64_t* __restrict__
                   const float4* __restrict__ tgt, size_t Mt, KnnGrid g, const HashEntry* __restrict__ table, uint32_t mask,
                   int k, float thr, float cell2_lo, uint8_t* __restrict__ coexist, float4* __restrict__ local_out)
 {
-    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n_pts) return;
-    const uint64_t gi = first_pt + i;
-    const size_t kf = find_kf(offsets, kb, ke, gi);
+    // grid = (chunks of the longest keyframe, keyframes): no per-point search for the keyframe
+    const size_t kf = kb + blockIdx.y;
+    const uint64_t a = offsets[kf], local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= offsets[kf + 1] - a) return;
+    const uint64_t gi = a + local, i = gi - first_pt;
     const float4 p4 = scans[gi];
     float3 p = make_float3(p4.x, p4.y, p4.z);
     // Session.cpp:545 / :618: local2global(scan, pose, kSE3MatExtrinsicPoseBasetoLiDAR)  (sic, quirk Q7)
@@ -1666,17 +1669,20 @@ k_knn_query_scans(const float4* __restrict__ scans, const uint64_t* __restrict__
     coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo) ? 1 : 0;
 }
 hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
-                           const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
+                           uint64_t max_kf_pts, const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
                            const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask,
                            int k, float thr, float cell2_lo, uint8_t* coexist, float4* local_out, hipStream_t s)
 {
-    if (!n_pts) return hipSuccess;
+    if (!n_pts || !max_kf_pts) return hipSuccess;
     if (k < 1 || k > kMaxK) return hipErrorInvalidValue;
     const int kt = (k <= 4 && Mt >= (size_t)k) ? k : 0;     // register-resident specialisations for the usual k (yaml 2, default 3)
     auto launch = [&](auto b2l_tag, auto kt_tag) {
-        k_knn_query_scans<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(
-            scans, offsets_dev, kb, ke, first_pt, n_pts, poses_dev, inv_poses_dev, b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo,
-            coexist, local_out);
+        for (size_t k0 = kb; k0 < ke; k0 += 65535) {      // gridDim.y limit
+            const size_t k1 = std::min(ke, k0 + 65535);
+            k_knn_query_scans<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(grid_for(max_kf_pts), (unsigned)(k1 - k0)), dim3(kBlock), 0, s>>>(
+                scans, offsets_dev, k0, k1, first_pt, n_pts, poses_dev, inv_poses_dev, b2l, sorted_target, Mt, g, table, table_mask, k, thr, cell2_lo,
+                coexist, local_out);
+        }
     };
     auto by_kt = [&](auto b2l_tag) {
         switch (kt) {
