@@ -37,7 +37,7 @@ class LazyScans:
 
     def full(self):
         if self._full is None:
-            self._full = self.sops._allgather_scanset(self.local)
+            self._full = self.sops._allgather_scanset(self.local, self.n)
         return self._full
 
     # so that code written for plain scan sets (tests, scan_outputs) keeps working
@@ -75,10 +75,21 @@ class ShardedOps:
         assert (scans.kb, scans.ke, scans.n) == (kb, ke, self.ops.n_keyframes(poses)), "scan shard and pose shard disagree"
         return kb, ke
 
-    def _allgather_scanset(self, local):
+    def _allgather_scanset(self, local, n_total):
         pts, off = self.ops.scanset_to_tensors(local)
-        counts = [None] * self.world
-        self.dist.all_gather_object(counts, [int(x) for x in off], group=self.group)
+        # per-keyframe offsets of every rank as one padded int64 all-gather (all_gather_object would pickle through the host)
+        n_local = len(off) - 1
+        n_max = max(shard_range(n_total, r, self.world)[1] - shard_range(n_total, r, self.world)[0] for r in range(self.world))
+        assert n_local <= n_max, "scan shard larger than any keyframe block"
+        mine = torch.full((n_max + 2,), -1, dtype=torch.int64, device=pts.device)
+        mine[0] = n_local
+        mine[1: n_local + 2] = torch.as_tensor([int(x) for x in off], dtype=torch.int64)
+        gathered = [torch.empty_like(mine) for _ in range(self.world)]
+        self.dist.all_gather(gathered, mine, group=self.group)
+        counts = []
+        for t in gathered:
+            h = t.cpu().tolist()
+            counts.append(h[1: int(h[0]) + 2])
         sizes = [c[-1] for c in counts]
         cap = max(max(sizes), 1)
         pad = torch.zeros((cap, 4), dtype=torch.float32, device=pts.device)
