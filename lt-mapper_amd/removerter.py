@@ -29,6 +29,7 @@ class Params:
     # new optional keys (prefix gpu_): off = exactly the shipped behaviour
     gpu_use_self_removert: bool = False      # enable the selfRemovert() call that is commented out at Removerter.cpp:1582,1586
     gpu_skip_hd_knn: bool = False            # skip the visualisation-only HD kNN (Removerter.cpp:1590-1601)
+    gather_scan_outputs: bool = False        # multi-GPU: also assemble the five per-keyframe outputs on every rank (default: rank-local)
 
 
 class HipOps:
@@ -319,11 +320,14 @@ class Removerter:
         self.parseLDScansViaProjection()
         self.updateScansScanwise()
         C, Q = self.central_sess_, self.query_sess_
-        # the five per-keyframe outputs are assembled on every rank (no-op on one GPU): this is the "all-gather to assemble the
-        # final maps" of the north star and is part of the timed step
-        for name in ("keyframe_scans_updated_", "keyframe_scans_updated_strong_", "keyframe_scans_pd_", "keyframe_scans_strong_pd_",
-                     "keyframe_scans_strong_nd_"):
-            setattr(C, name, self.ops.materialize(getattr(C, name)))
+        # Multi-GPU: every map is complete on every rank at this point (their inputs were all-gathered where a merge needed all
+        # keyframes -- the "all-gather to assemble the final maps" of the north star).  The five per-keyframe outputs are one file
+        # per keyframe (Removerter.cpp:1637-1650), so each rank keeps -- and writes -- those of its own keyframes; assembling them
+        # everywhere as well is optional (and lazy: LazyScans.download() gathers on demand).  No-op on one GPU.
+        if self.P.gather_scan_outputs:
+            for name in ("keyframe_scans_updated_", "keyframe_scans_updated_strong_", "keyframe_scans_pd_", "keyframe_scans_strong_pd_",
+                         "keyframe_scans_strong_nd_"):
+                setattr(C, name, self.ops.materialize(getattr(C, name)))
         self.outputs.update(central_map_static=C.map_global_curr_static_, central_map_dynamic=C.map_global_curr_dynamic_,
                             query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
 
