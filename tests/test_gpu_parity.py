@@ -204,6 +204,27 @@ def test_reproject_matches_oracle(gpu_ctx, orc, small_pair):
     assert gp.shape[0] == 1 and gp[0, 3] == 2.0
 
 
+@pytest.mark.parametrize("vfov,hfov", [(30.5, 120.25), (26.9, 360.0), (90.0, 180.0)])
+def test_vote_and_reproject_with_other_fovs_match_oracle(ltm, orc, small_pair, vfov, hfov):
+    """most of the map falls outside a narrow FOV and is clamped into the edge rows / columns (utility.cpp:122-123, quirk Q2):
+    the culled vote, the exact-image vote and the reprojection must still agree with the oracle bit for bit"""
+    C, Q = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), 0.05)
+    ctx = ltm.Context(vfov=vfov, hfov=hfov, device=0)
+    g_map = ctx.upload(cmap)
+    for mode, src in ((0, C), (1, Q)):
+        g_scans, g_poses = ctx.upload_scans(src["scans"], src["offsets"]), ctx.poses(src["poses"], src["inv"])
+        for alpha in (2.5, 1.425):
+            want = orc.vote_labels(cmap, src["scans"], src["offsets"], src["inv"], I4, vfov, hfov, alpha, 0.1, mode)
+            _, _, got = ctx.visibility_partition(g_map, g_scans, g_poses, alpha, 0.1, mode, want_labels=True)
+            assert (got == want).all(), f"fov ({vfov},{hfov}) alpha {alpha} mode {mode}: {(got != want).sum()} labels differ"
+    g_pts, g_off = ctx.reproject(g_map, ctx.poses(C["poses"], C["inv"]), 3.0).download()
+    o_pts, o_off = orc.reproject(cmap, C["inv"], I4, vfov, hfov, 3.0)
+    assert (g_off == o_off).all()
+    assert_clouds_equal(g_pts, o_pts, f"reprojected scans, fov ({vfov},{hfov})")
+    ctx.close()
+
+
 @pytest.mark.parametrize("k,thr", [(2, 0.01), (3, 0.1), (1, 0.05), (4, 0.02), (6, 0.05)])   # k <= 4: register specialisations, 6: generic path
 def test_knn_partition_matches_oracle(gpu_ctx, orc, small_pair, k, thr):
     C, Q = small_pair
