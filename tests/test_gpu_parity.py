@@ -204,6 +204,32 @@ def test_reproject_matches_oracle(gpu_ctx, orc, small_pair):
     assert gp.shape[0] == 1 and gp[0, 3] == 2.0
 
 
+def test_survivor_queue_overflow_paths(gpu_ctx, orc, small_pair):
+    """both projection kernels fall back to the exact path for a whole tile when their LDS survivor queue (2048 of 4096 points)
+    overflows: (a) a vote whose scans lie far behind the map, so every map point 'matters'; (b) a reprojection of a sparse
+    shell of points that all own their pixel, so every point survives the block-local arg-min filter"""
+    C, _ = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4), 0.05)
+    far = C["scans"].copy()
+    far[:, :3] *= 1.6                                             # the scans now see 60 % farther than the map surface
+    labels_o = orc.vote_labels(cmap, far, C["offsets"], C["inv"], I4, VFOV, HFOV, 2.5, 0.1, 0)
+    assert labels_o.mean() > 0.05
+    _, _, labels_g = gpu_ctx.visibility_partition(gpu_ctx.upload(cmap), gpu_ctx.upload_scans(far, C["offsets"]), gpu_ctx.poses(C["poses"], C["inv"]),
+                                                  2.5, 0.1, 0, want_labels=True)
+    assert (labels_g == labels_o).all(), f"{(labels_g != labels_o).sum()} labels differ"
+    surv, pts = gpu_ctx.cull_stats()
+    rng = np.random.default_rng(5)
+    n = 40000
+    d = rng.normal(size=(n, 3)); d /= np.linalg.norm(d, axis=1, keepdims=True)
+    d[:, 2] *= 0.3
+    shell = np.concatenate([d * rng.uniform(20, 60, (n, 1)), rng.uniform(0, 255, (n, 1))], axis=1).astype(np.float32)
+    poses = np.tile(I4.reshape(1, 16), (3, 1))
+    g_pts, g_off = gpu_ctx.reproject(gpu_ctx.upload(shell), gpu_ctx.poses(poses, poses), 3.0).download()
+    o_pts, o_off = orc.reproject(shell, poses, I4, VFOV, HFOV, 3.0)
+    assert (g_off == o_off).all() and int(o_off[1]) > 0.8 * n * 0.5
+    assert_clouds_equal(g_pts, o_pts, "reprojection of a sparse shell")
+
+
 @pytest.mark.parametrize("vfov,hfov", [(30.5, 120.25), (26.9, 360.0), (90.0, 180.0)])
 def test_vote_and_reproject_with_other_fovs_match_oracle(ltm, orc, small_pair, vfov, hfov):
     """most of the map falls outside a narrow FOV and is clamped into the edge rows / columns (utility.cpp:122-123, quirk Q2):
