@@ -33,3 +33,28 @@ def test_cli_usage_and_loud_failure_without_gpu(tmp_path):
         y.write_text(f"removert:\n  save_pcd_directory: \"{tmp_path}/out/\"\n")
         r = subprocess.run([exe, str(y)], capture_output=True, text=True, timeout=60)
         assert r.returncode == 1 and "no CPU fallback" in r.stderr, r.stderr
+
+
+def test_cascade_yaml_hand_over(tmp_path):
+    """tools/cascade_yaml.py: the YAML of run j+1 points the central session at scans_updated/ + the pose subset of run j"""
+    from tools.cascade_yaml import next_yaml
+    save = tmp_path / "out1"
+    save.mkdir()
+    (save / "scans_updated_poses.txt").write_text("1 0 0 0 0 1 0 0 0 0 1 0\n" * 7)
+    y1 = f"""removert:
+  save_pcd_directory: "{save}"   # no trailing slash
+  central_sess_scan_dir: "/data/01/Scans/"
+  central_sess_pose_path: "/data/01/poses.txt"
+  query_sess_scan_dir: "/data/02/Scans/"
+  query_sess_pose_path: "/data/02/poses.txt"
+  start_idx: 11
+  end_idx: 39
+  keyframe_gap: 5
+  num_nn_points_within: 2
+"""
+    y2 = next_yaml(y1, "/data/03/Scans/", "/data/03/poses.txt", str(tmp_path / "out2") + "/")
+    assert f'central_sess_scan_dir: "{save}/scans_updated/"' in y2
+    assert f'central_sess_pose_path: "{save}/scans_updated_poses.txt"' in y2
+    assert 'query_sess_scan_dir: "/data/03/Scans/"' in y2 and 'query_sess_pose_path: "/data/03/poses.txt"' in y2
+    assert "start_idx: 0" in y2 and "end_idx: 6" in y2 and "keyframe_gap: 1" in y2 and "use_keyframe_gap: true" in y2
+    assert "num_nn_points_within: 2" in y2 and f'save_pcd_directory: "{tmp_path}/out2/"' in y2
