@@ -74,6 +74,9 @@ int ltm_cloud_download(ltm_ctx*, ltm_cloud, void* dst, size_t cap_pts, size_t st
 int ltm_cloud_device_ptr(ltm_ctx*, ltm_cloud, const void** dev_xyzi);                 /* borrowed, valid until free */
 int ltm_cloud_clone(ltm_ctx*, ltm_cloud, ltm_cloud* out);                              /* `*a = *b` deep copies */
 int ltm_cloud_concat(ltm_ctx*, const ltm_cloud* in, size_t n, ltm_cloud* out);         /* `*a += *b` (order kept) */
+/* pcl::ExtractIndices as used by parsePointcloudSubsetUsingPtIdx (Removerter.cpp:933-946): out[j] = in[idx[j]], order kept;
+ * an index outside [0, n) is LTM_E_INVALID (undefined behaviour in the reference) */
+int ltm_cloud_select(ltm_ctx*, ltm_cloud in, const int32_t* idx_host, size_t n_idx, ltm_cloud* out);
 int ltm_cloud_free(ltm_ctx*, ltm_cloud);
 
 /* ---------------------------------------------------------------- scan sets ---- */
@@ -82,6 +85,7 @@ int ltm_scanset_upload(ltm_ctx*, const void* pts, size_t stride_bytes, const uin
 int ltm_scanset_from_device(ltm_ctx*, const void* dev_xyzi, const uint64_t* host_offsets, size_t n_kf, ltm_scanset* out);
 int ltm_scanset_info(ltm_ctx*, ltm_scanset, size_t* n_kf, size_t* n_points);
 int ltm_scanset_offsets(ltm_ctx*, ltm_scanset, uint64_t* offsets /* n_kf+1 */);
+int ltm_scanset_keyframe(ltm_ctx*, ltm_scanset, size_t kf, ltm_cloud* out);            /* one keyframe's scan as a cloud (D2D copy) */
 int ltm_scanset_download(ltm_ctx*, ltm_scanset, void* dst, size_t cap_pts, size_t stride_bytes);
 int ltm_scanset_device_ptr(ltm_ctx*, ltm_scanset, const void** dev_xyzi);
 int ltm_scanset_as_cloud(ltm_ctx*, ltm_scanset, ltm_cloud* out);                       /* flat copy of all points */

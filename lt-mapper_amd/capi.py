@@ -47,6 +47,8 @@ SIGNATURES = {
     "ltm_cloud_device_ptr": (_i, [_vp, _u64, C.POINTER(_vp)]),
     "ltm_cloud_clone": (_i, [_vp, _u64, _pu64]),
     "ltm_cloud_concat": (_i, [_vp, _pu64, _sz, _pu64]),
+    "ltm_cloud_select": (_i, [_vp, _u64, _vp, _sz, _pu64]),
+    "ltm_scanset_keyframe": (_i, [_vp, _u64, _sz, _pu64]),
     "ltm_cloud_free": (_i, [_vp, _u64]),
     "ltm_scanset_upload": (_i, [_vp, _vp, _sz, _pu64, _sz, _pu64]),
     "ltm_scanset_from_device": (_i, [_vp, _vp, _pu64, _sz, _pu64]),
@@ -159,6 +161,18 @@ class Context:
     def cloud_from_device(self, dev_ptr, n):
         out = _u64()
         self._ck(self.lib.ltm_cloud_from_device(self.h, dev_ptr, n, C.byref(out)))
+        return Cloud(self, out.value)
+
+    def select(self, cloud, idx):
+        """pcl::ExtractIndices (parsePointcloudSubsetUsingPtIdx, Removerter.cpp:933-946): out[j] = cloud[idx[j]]"""
+        a = np.ascontiguousarray(idx, dtype=np.int32)
+        out = _u64()
+        self._ck(self.lib.ltm_cloud_select(self.h, cloud.h, a.ctypes.data, a.size, C.byref(out)))
+        return Cloud(self, out.value)
+
+    def scan_of_keyframe(self, scans, kf):
+        out = _u64()
+        self._ck(self.lib.ltm_scanset_keyframe(self.h, scans.h, kf, C.byref(out)))
         return Cloud(self, out.value)
 
     def concat(self, clouds):

@@ -844,6 +844,36 @@ int ltm_cloud_concat(ltm_ctx* c, const ltm_cloud* in, size_t n, ltm_cloud* out)
         *out = h;
     });
 }
+int ltm_cloud_select(ltm_ctx* c, ltm_cloud hin, const int32_t* idx_host, size_t n_idx, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out && (idx_host || n_idx == 0), "null argument");
+        const Cloud in = get_cloud(c, hin);
+        for (size_t j = 0; j < n_idx; ++j) LTM_REQUIRE(idx_host[j] >= 0 && (size_t)idx_host[j] < in.n, "point index out of range");
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, n_idx, &d);
+        if (n_idx) {
+            DevBuf idx(c, n_idx * sizeof(uint32_t));
+            h2d(c, idx.p, idx_host, n_idx * sizeof(uint32_t));     // non-negative int32 == uint32
+            LTM_HIP(gather_points(in.d, idx.as<uint32_t>(), n_idx, d, c->stream));
+            sync(c);
+        }
+        *out = h;
+    });
+}
+int ltm_scanset_keyframe(ltm_ctx* c, ltm_scanset hs, size_t kf, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const ScanSet& s = get_ss(c, hs);
+        LTM_REQUIRE(kf < s.nkf(), "keyframe out of range");
+        const size_t a = s.off[kf], n = s.off[kf + 1] - a;
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, n, &d);
+        if (n) d2d(c, d, s.d + a, n * 16);
+        *out = h;
+    });
+}
 int ltm_cloud_free(ltm_ctx* c, ltm_cloud h)
 {
     return guarded(c, [&] { Cloud& cl = get_cloud(c, h); c->pool.free(cl.d); c->clouds.erase(h); });

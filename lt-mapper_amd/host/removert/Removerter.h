@@ -87,6 +87,22 @@ public:
     void saveStrongNDScans(Session& _sess);
     void saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout);
 
+    // ---- the reference's fine-grained methods, kept as thin wrappers over the C ABI (Removerter.h:126-201).  run() does not use
+    // them: the batch calls above replace their per-scan loops; they exist so that code written against the class still links.
+    // A range image stands in for the cv::Mat pair of map2RangeImg (range CV_32FC1, point index CV_32SC1).
+    struct RangeImage { int rows = 0, cols = 0; std::vector<float> range; std::vector<int32_t> ptidx; };
+    RangeImage scan2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size);   // Removerter.cpp:109-156
+    std::vector<int> calcDescrepancyAndParseDynamicPointIdxForEachScan(std::pair<int, int> _rimg_shape);                           // :542-593 (central on itself)
+    std::vector<int> calcDescrepancyAndParseDynamicPointIdxForEachScan(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape);
+    std::vector<int> calcDescrepancyAndParseDynamicPointIdxForEachScanForND(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape);   // :485-540
+    std::vector<int> calcDescrepancyAndParseDynamicPointIdxForEachScanForPD(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape);   // :429-482
+    std::vector<int> getStaticIdxFromDynamicIdx(const std::vector<int>& _dynamic_point_indexes, int _num_all_points);              // :675-687
+    void parsePointcloudSubsetUsingPtIdx(const CloudPtr& _ptcloud_orig, std::vector<int>& _point_indexes, CloudPtr& _ptcloud_to_save);   // :933-946
+
+    // Step 0, then: the fine-grained wrappers must reproduce partitionCurrentMap() (same static / dynamic clouds, byte for byte) and
+    // scan2RangeImg must agree with the range of every scan point.  Used by `ltm_run <yaml> --check-wrappers` (tests/test_gpu_cli.py).
+    bool checkFineGrainedWrappers();
+
     void saveKeyframePoses(const Session& _sess);   // <save_pcd_directory>scans_updated_poses.txt: poses matching scans_updated/ (cascade hand-over)
     void run(void);
 };

@@ -2,7 +2,9 @@
 #include "removert/Removerter.h"
 
 #include <chrono>
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -341,6 +343,123 @@ void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _
         if (!savePCDFileBinary(file_name, scans[idx_scan], octree_layout, &err)) throw std::runtime_error(err);
     }, (unsigned)std::max(1, kNumOmpCores));
     LTM_INFO(" " << scans.size() << " scans saved under " << _save_dir);
+}
+
+// ------------------------------------------------------------------ fine-grained reference methods (thin wrappers)
+// the resolution factor whose image shape is `_rimg_shape` (resetRimgSize inverted; the shapes come from it in the first place)
+static float alphaOfShape(float vfov, float hfov, std::pair<int, int> shape)
+{
+    const float alpha = (float)shape.first / vfov;
+    int r = 0, c = 0;
+    ltm_rimg_size(vfov, hfov, alpha, &r, &c);
+    if (r != shape.first || c != shape.second) throw std::runtime_error("range image shape is not a resolution of this field of view");
+    return alpha;
+}
+
+Removerter::RangeImage Removerter::scan2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size)
+{
+    if (_fov.first != kVFOV || _fov.second != kHFOV) throw std::runtime_error("scan2RangeImg: the field of view is fixed per context (sequence_vfov / sequence_hfov)");
+    RangeImage img;
+    img.rows = _rimg_size.first; img.cols = _rimg_size.second;
+    img.range.resize((size_t)img.rows * img.cols);
+    ltmCheck(_scan->ctx, ltm_debug_range_image(_scan->ctx, _scan->h, nullptr, nullptr, alphaOfShape(kVFOV, kHFOV, _rimg_size), img.range.data(), nullptr),
+             "ltm_debug_range_image");
+    return img;
+}
+
+static std::vector<int> votedIndexes(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float alpha, int mode)
+{
+    std::vector<uint8_t> labels(map->size());
+    ltmCheck(tgt.dev_->ctx, ltm_visibility_partition(tgt.dev_->ctx, map->h, scans->h, src.poses_h_, alpha, 0.1f, mode, nullptr, nullptr, labels.data()),
+             "ltm_visibility_partition");
+    std::vector<int> idx;                       // ascending and unique, like the std::set round trip of Removerter.cpp:589-590
+    for (size_t i = 0; i < labels.size(); ++i) if (labels[i]) idx.push_back((int)i);
+    return idx;
+}
+std::vector<int> Removerter::calcDescrepancyAndParseDynamicPointIdxForEachScan(std::pair<int, int> _rimg_shape)
+{
+    return calcDescrepancyAndParseDynamicPointIdxForEachScan(central_sess_, central_sess_, _rimg_shape);
+}
+std::vector<int> Removerter::calcDescrepancyAndParseDynamicPointIdxForEachScan(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape)
+{
+    return votedIndexes(_target_sess, _target_sess.map_global_curr_, _source_sess.keyframe_scans_, _source_sess, alphaOfShape(kVFOV, kHFOV, _rimg_shape), 0);
+}
+std::vector<int> Removerter::calcDescrepancyAndParseDynamicPointIdxForEachScanForND(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape)
+{
+    return votedIndexes(_target_sess, _target_sess.map_global_nd_, _source_sess.keyframe_scans_static_projected_, _source_sess, alphaOfShape(kVFOV, kHFOV, _rimg_shape), 1);
+}
+std::vector<int> Removerter::calcDescrepancyAndParseDynamicPointIdxForEachScanForPD(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape)
+{
+    return votedIndexes(_target_sess, _target_sess.map_global_pd_, _source_sess.keyframe_scans_static_projected_, _source_sess, alphaOfShape(kVFOV, kHFOV, _rimg_shape), 0);
+}
+
+// complement of the dynamic indexes in linspace<int>(0, N, N) (utility.h:158-167), quirk Q5 included: integer step N/(N-1), i.e.
+// {0, 2} for N == 2 and a division by zero for N == 1 (reported as an exception here)
+std::vector<int> Removerter::getStaticIdxFromDynamicIdx(const std::vector<int>& _dynamic_point_indexes, int _num_all_points)
+{
+    if (_num_all_points == 1) throw std::runtime_error("getStaticIdxFromDynamicIdx: linspace<int>(0, 1, 1) divides by zero in the reference");
+    std::vector<char> dyn((size_t)std::max(_num_all_points, 0) + 3, 0);
+    for (int i : _dynamic_point_indexes) if (i >= 0 && (size_t)i < dyn.size()) dyn[(size_t)i] = 1;
+    const int step = _num_all_points == 2 ? 2 : 1;
+    std::vector<int> out;
+    for (int k = 0, v = 0; k < _num_all_points; ++k, v += step) if (!dyn[(size_t)v]) out.push_back(v);
+    return out;
+}
+
+void Removerter::parsePointcloudSubsetUsingPtIdx(const CloudPtr& _ptcloud_orig, std::vector<int>& _point_indexes, CloudPtr& _ptcloud_to_save)
+{
+    ltm_cloud h = 0;
+    static_assert(sizeof(int) == sizeof(int32_t), "int32 indices");
+    ltmCheck(_ptcloud_orig->ctx, ltm_cloud_select(_ptcloud_orig->ctx, _ptcloud_orig->h, reinterpret_cast<const int32_t*>(_point_indexes.data()),
+                                                   _point_indexes.size(), &h), "ltm_cloud_select");
+    _ptcloud_to_save = std::make_shared<CloudH>(_ptcloud_orig->ctx, h);
+}
+
+bool Removerter::checkFineGrainedWrappers()
+{
+    loadSessionInfo();
+    parseKeyframes();
+    loadKeyframes();
+    precleaningKeyframes(2.5);
+    makeGlobalMap();
+    const float alpha = 2.5f;
+    const std::pair<int, int> shape = resetRimgSize(kFOV, alpha);
+    bool ok = true;
+    auto expect = [&](bool cond, const char* what) { if (!cond) { std::fprintf(stderr, "check-wrappers: %s FAILED\n", what); ok = false; } };
+    // 1. index form of the vote == the batch partition
+    Session& C = central_sess_;
+    std::vector<int> dyn = calcDescrepancyAndParseDynamicPointIdxForEachScan(shape);
+    std::vector<int> sta = getStaticIdxFromDynamicIdx(dyn, (int)C.map_global_curr_->size());
+    CloudPtr dyn_pts, sta_pts;
+    parsePointcloudSubsetUsingPtIdx(C.map_global_curr_, dyn, dyn_pts);
+    parsePointcloudSubsetUsingPtIdx(C.map_global_curr_, sta, sta_pts);
+    auto [static_tt, dynamic_tt] = partitionCurrentMap(C, C, alpha);
+    auto same = [](const CloudPtr& a, const CloudPtr& b) {
+        const Cloud x = a->download(), y = b->download();
+        return x.size() == y.size() && (x.empty() || std::memcmp(x.data(), y.data(), x.size() * sizeof(PointType)) == 0);
+    };
+    expect(!dyn.empty() && dyn.size() + sta.size() == C.map_global_curr_->size(), "index sets partition the map");
+    expect(same(dyn_pts, dynamic_tt), "dynamic subset == partitionCurrentMap().second");
+    expect(same(sta_pts, static_tt), "static subset == partitionCurrentMap().first");
+    // 2. scan2RangeImg: every pixel is either empty (10000) or the range of some scan point, and the nearest point of the scan is in it
+    ltm_cloud h = 0;
+    ltmCheck(dev_->ctx, ltm_scanset_keyframe(dev_->ctx, C.keyframe_scans_->h, 0, &h), "ltm_scanset_keyframe");
+    CloudPtr scan0 = C.wrap(h);
+    const RangeImage img = scan2RangeImg(scan0, kFOV, shape);
+    const Cloud pts = scan0->download();
+    float rmin = 1e30f, imin = 1e30f;
+    for (const PointType& p : pts) rmin = std::min(rmin, std::sqrt(p.x * p.x + p.y * p.y + p.z * p.z));
+    size_t filled = 0;
+    for (float v : img.range) { if (v < kFlagNoPOINT) { ++filled; imin = std::min(imin, v); } }
+    expect(img.rows == shape.first && img.cols == shape.second && filled > 0 && filled <= pts.size(), "scan2RangeImg fills at most one pixel per point");
+    expect(std::fabs(imin - rmin) <= 1e-4f * rmin, "the nearest scan point is in the range image");
+    // 3. quirk Q5
+    expect((getStaticIdxFromDynamicIdx({}, 2) == std::vector<int>{0, 2}), "linspace<int>(0,2,2) == {0,2}");
+    bool threw = false;
+    try { getStaticIdxFromDynamicIdx({}, 1); } catch (const std::exception&) { threw = true; }
+    expect(threw, "N == 1 is reported");
+    std::printf("check-wrappers: %s (%zu dynamic of %zu map points)\n", ok ? "OK" : "FAILED", dyn.size(), C.map_global_curr_->size());
+    return ok;
 }
 
 // Lifelong hand-over (reference README.md:115-118 leaves it to the user): scans_updated/ holds one file per

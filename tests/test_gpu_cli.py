@@ -197,6 +197,11 @@ def test_ltm_run_file_protocol(tmp_path, orc):
         bad = (got != want).any(axis=2).mean()
         assert bad <= (0.0 if name == "scan" else 5e-3), f"viz {name}: {bad:.4%} of the pixels differ"   # inverse-pose last bits may move a few map pixels
 
+    # ---- the reference's fine-grained methods (calcDescrepancyAndParseDynamicPointIdxForEachScan, getStaticIdxFromDynamicIdx,
+    # parsePointcloudSubsetUsingPtIdx, scan2RangeImg) kept as thin wrappers must reproduce the batch partition
+    r = subprocess.run([exe, str(yaml), "--check-wrappers"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "check-wrappers: OK" in r.stdout, r.stdout[-1500:] + r.stderr[-1500:]
+
     # ---- lifelong hand-over through the file protocol.  Run 2: central := scans_updated/ of run 1 with the pose
     # subset ltm_run wrote next to it, query := session 02 again (the synthetic sessions 01 and 03 do not overlap within 40 keyframes).  The loader re-applies VoxelGrid + pre-clean, as the reference would.
     n_c = len(c_kf)

@@ -178,6 +178,25 @@ def test_viz_images_match_oracle_colormap(gpu_ctx, orc, small_pair, mode):
     assert len(np.unique(got["map"].reshape(-1, 3), axis=0)) > 20        # a real picture, not a constant
 
 
+def test_cloud_select_and_scan_of_keyframe(gpu_ctx, small_pair):
+    """pcl::ExtractIndices stand-in (parsePointcloudSubsetUsingPtIdx) and the per-keyframe slice of a scan set"""
+    C, _ = small_pair
+    pts = C["scans"][:5000]
+    g = gpu_ctx.upload(pts)
+    rng = np.random.default_rng(3)
+    for idx in (np.arange(0, 5000, 7), rng.integers(0, 5000, 999), np.array([], np.int64), np.array([4999, 0, 0])):
+        np.testing.assert_array_equal(gpu_ctx.select(g, idx).download(), pts[idx])
+    for bad in ([5000], [-1]):
+        with pytest.raises(Exception):
+            gpu_ctx.select(g, bad)
+    g_scans = gpu_ctx.upload_scans(C["scans"], C["offsets"])
+    for kf in (0, 3):
+        a, b = int(C["offsets"][kf]), int(C["offsets"][kf + 1])
+        np.testing.assert_array_equal(gpu_ctx.scan_of_keyframe(g_scans, kf).download(), C["scans"][a:b])
+    with pytest.raises(Exception):
+        gpu_ctx.scan_of_keyframe(g_scans, len(C["offsets"]) - 1)
+
+
 def test_merge_and_preclean(gpu_ctx, orc, small_pair):
     C, _ = small_pair
     g_scans = gpu_ctx.upload_scans(C["scans"], C["offsets"])
