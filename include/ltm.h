@@ -74,6 +74,10 @@ int ltm_cloud_download(ltm_ctx*, ltm_cloud, void* dst, size_t cap_pts, size_t st
 int ltm_cloud_device_ptr(ltm_ctx*, ltm_cloud, const void** dev_xyzi);                 /* borrowed, valid until free */
 int ltm_cloud_clone(ltm_ctx*, ltm_cloud, ltm_cloud* out);                              /* `*a = *b` deep copies */
 int ltm_cloud_concat(ltm_ctx*, const ltm_cloud* in, size_t n, ltm_cloud* out);         /* `*a += *b` (order kept) */
+/* pcl::transformPointCloud(cloud, out, Matrix4d) applied once or twice (row-major 4x4, NULL = skip), the float result of the first
+ * being the input of the second: local2global = (T1 = lidar->base, T2 = pose), global2local / transformGlobalMapToLocal =
+ * (T1 = inverse pose, T2 = base->lidar)  (utility.cpp:64-72, 160-168, 194-202) */
+int ltm_cloud_transform(ltm_ctx*, ltm_cloud in, const double* T1, const double* T2, ltm_cloud* out);
 /* pcl::ExtractIndices as used by parsePointcloudSubsetUsingPtIdx (Removerter.cpp:933-946): out[j] = in[idx[j]], order kept;
  * an index outside [0, n) is LTM_E_INVALID (undefined behaviour in the reference) */
 int ltm_cloud_select(ltm_ctx*, ltm_cloud in, const int32_t* idx_host, size_t n_idx, ltm_cloud* out);

@@ -47,6 +47,7 @@ SIGNATURES = {
     "ltm_cloud_device_ptr": (_i, [_vp, _u64, C.POINTER(_vp)]),
     "ltm_cloud_clone": (_i, [_vp, _u64, _pu64]),
     "ltm_cloud_concat": (_i, [_vp, _pu64, _sz, _pu64]),
+    "ltm_cloud_transform": (_i, [_vp, _u64, _vp, _vp, _pu64]),
     "ltm_cloud_select": (_i, [_vp, _u64, _vp, _sz, _pu64]),
     "ltm_scanset_keyframe": (_i, [_vp, _u64, _sz, _pu64]),
     "ltm_cloud_free": (_i, [_vp, _u64]),
@@ -161,6 +162,14 @@ class Context:
     def cloud_from_device(self, dev_ptr, n):
         out = _u64()
         self._ck(self.lib.ltm_cloud_from_device(self.h, dev_ptr, n, C.byref(out)))
+        return Cloud(self, out.value)
+
+    def transform(self, cloud, T1=None, T2=None):
+        """pcl::transformPointCloud once or twice (row-major 4x4 doubles)"""
+        t1 = None if T1 is None else np.ascontiguousarray(T1, dtype=np.float64).reshape(16)
+        t2 = None if T2 is None else np.ascontiguousarray(T2, dtype=np.float64).reshape(16)
+        out = _u64()
+        self._ck(self.lib.ltm_cloud_transform(self.h, cloud.h, None if t1 is None else t1.ctypes.data, None if t2 is None else t2.ctypes.data, C.byref(out)))
         return Cloud(self, out.value)
 
     def select(self, cloud, idx):

@@ -844,6 +844,21 @@ int ltm_cloud_concat(ltm_ctx* c, const ltm_cloud* in, size_t n, ltm_cloud* out)
         *out = h;
     });
 }
+int ltm_cloud_transform(ltm_ctx* c, ltm_cloud hin, const double* T1, const double* T2, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const Cloud in = get_cloud(c, hin);
+        float4* d;
+        const ltm_cloud h = alloc_cloud(c, in.n, &d);
+        HostMat34 a, b;
+        if (T1) a = to34(T1);
+        if (T2) b = to34(T2);
+        if (!T1 && !T2) d2d(c, d, in.d, in.n * 16);
+        else LTM_HIP(transform_cloud(in.d, in.n, T1 ? &a : nullptr, T2 ? &b : nullptr, d, c->stream));
+        *out = h;
+    });
+}
 int ltm_cloud_select(ltm_ctx* c, ltm_cloud hin, const int32_t* idx_host, size_t n_idx, ltm_cloud* out)
 {
     return guarded(c, [&] {

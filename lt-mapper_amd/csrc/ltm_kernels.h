@@ -82,6 +82,7 @@ hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, siz
 
 // ---- transforms ----
 // out[i] = xform(second, xform(first, in[i])) with per-keyframe `second` (merge: first=L2B, second=pose[kf])
+hipError_t transform_cloud(const float4* in, size_t n, const HostMat34* t1, const HostMat34* t2, float4* out, hipStream_t s);   // one or two rigid transforms of a cloud
 hipError_t transform_scans(const float4* in, const uint64_t* offsets_dev, size_t n_kf, uint64_t n_pts,
                            HostMat34 first, int first_identity, const double* per_kf_dev, float4* out, hipStream_t s);
 // out[k] = a[k] ++ b[k] ++ c[k] per keyframe; c (and oc) may alias b with an all-zero-length offsets array

@@ -1060,6 +1060,27 @@ hipError_t transform_scans(const float4* in, const uint64_t* offsets_dev, size_t
     return hipGetLastError();
 }
 
+// pcl::transformPointCloud<PointT, double> applied once or twice to a whole cloud (utility.cpp:64-72, 160-168, 194-202): the float
+// result of the first transform is the input of the second; intensity is copied
+__global__ void __launch_bounds__(kBlock)
+k_transform_cloud(const float4* __restrict__ in, size_t n, int has1, HostMat34 t1, int has2, HostMat34 t2, float4* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float4 p4 = in[i];
+    float3 p = make_float3(p4.x, p4.y, p4.z);
+    if (has1) p = xform(to_dev(t1), p);
+    if (has2) p = xform(to_dev(t2), p);
+    out[i] = make_float4(p.x, p.y, p.z, p4.w);
+}
+hipError_t transform_cloud(const float4* in, size_t n, const HostMat34* t1, const HostMat34* t2, float4* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    HostMat34 z{};
+    k_transform_cloud<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(in, n, t1 != nullptr, t1 ? *t1 : z, t2 != nullptr, t2 ? *t2 : z, out);
+    return hipGetLastError();
+}
+
 // per-keyframe concatenation a[k] ++ b[k] ++ c[k] (Session.cpp:365-371) as one gather: out_off = offsets of the result
 __global__ void __launch_bounds__(kBlock)
 k_zip_concat(const float4* __restrict__ a, const uint64_t* __restrict__ oa, const float4* __restrict__ b, const uint64_t* __restrict__ ob,

@@ -90,7 +90,7 @@ public:
     // ---- the reference's fine-grained methods, kept as thin wrappers over the C ABI (Removerter.h:126-201).  run() does not use
     // them: the batch calls above replace their per-scan loops; they exist so that code written against the class still links.
     // A range image stands in for the cv::Mat pair of map2RangeImg (range CV_32FC1, point index CV_32SC1).
-    struct RangeImage { int rows = 0, cols = 0; std::vector<float> range; std::vector<int32_t> ptidx; };
+    using RangeImage = ltremovert::RangeImage;
     RangeImage scan2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size);   // Removerter.cpp:109-156
     std::vector<int> calcDescrepancyAndParseDynamicPointIdxForEachScan(std::pair<int, int> _rimg_shape);                           // :542-593 (central on itself)
     std::vector<int> calcDescrepancyAndParseDynamicPointIdxForEachScan(const Session& _target_sess, const Session& _source_sess, std::pair<int, int> _rimg_shape);

@@ -3,7 +3,9 @@
 // pcl::PointCloud::Ptr, and the kd-tree / ICP members are gone (the kNN stage is one C-ABI call).
 #pragma once
 #include <memory>
+#include <set>
 #include <string>
+#include <utility>
 #include <vector>
 
 #include "removert/RosParamServer.h"
@@ -27,6 +29,27 @@ struct CloudH { ltm_ctx* ctx = nullptr; ltm_cloud h = 0; CloudH() = default; Clo
 struct ScansH { ltm_ctx* ctx = nullptr; ltm_scanset h = 0; ScansH() = default; ScansH(ltm_ctx* c, ltm_scanset v) : ctx(c), h(v) {} ~ScansH(); size_t numKeyframes() const; std::vector<Cloud> download() const; };
 using CloudPtr = std::shared_ptr<CloudH>;
 using ScansPtr = std::shared_ptr<ScansH>;
+
+// ---- free functions of ltremovert/include/removert/utility.h:128-167 on device clouds (thin wrappers over the C ABI; the batch
+// stages of Session / Removerter do not go through them).  Matrices are row-major 4x4 doubles (Matrix4d).
+struct RangeImage { int rows = 0, cols = 0; std::vector<float> range; std::vector<int32_t> ptidx; };   // the cv::Mat pair of map2RangeImg
+RangeImage map2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size);        // utility.cpp:92-142
+CloudPtr parseProjectedPoints(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size); // :74-89
+void transformGlobalMapToLocal(const CloudPtr& _map_global, const Matrix4d& _base_pose_inverse, const Matrix4d& _base2lidar, CloudPtr& _map_local);   // :64-72
+CloudPtr local2global(const CloudPtr& _scan_local, const Matrix4d& _scan_pose, const Matrix4d& _base2lidar);                      // :160-168 (argument name as in the reference, quirk Q7)
+CloudPtr global2local(const CloudPtr& _scan_global, const Matrix4d& _scan_pose_inverse, const Matrix4d& _base2lidar);             // :194-202
+CloudPtr mergeScansWithinGlobalCoordUtil(const std::vector<CloudPtr>& _scans, const std::vector<Matrix4d>& _scans_poses, const Matrix4d& _lidar2base);   // :170-192
+void octreeDownsampling(const CloudPtr& _src, CloudPtr& _to_save, const float _kDownsampleVoxelSize = 0.05f);                      // :204-219
+std::set<int> convertIntVecToSet(const std::vector<int>& v);                                                                       // :238-245
+template <typename T> std::vector<T> linspace(T a, T b, size_t N)                                                                  // utility.h:158-167, quirk Q5 kept
+{
+    std::vector<T> xs(N);
+    if (N == 0) return xs;
+    const T h = (b - a) / static_cast<T>(N - 1);      // integer T: truncating division; N == 1 divides by zero as in the reference
+    T val = a;
+    for (size_t i = 0; i < N; ++i, val += h) xs[i] = val;
+    return xs;
+}
 
 class Session : public RosParamServer
 {

@@ -453,7 +453,33 @@ bool Removerter::checkFineGrainedWrappers()
     for (float v : img.range) { if (v < kFlagNoPOINT) { ++filled; imin = std::min(imin, v); } }
     expect(img.rows == shape.first && img.cols == shape.second && filled > 0 && filled <= pts.size(), "scan2RangeImg fills at most one pixel per point");
     expect(std::fabs(imin - rmin) <= 1e-4f * rmin, "the nearest scan point is in the range image");
-    // 3. quirk Q5
+    // 3. free functions of utility.h: one keyframe through transformGlobalMapToLocal + parseProjectedPoints == that keyframe of the
+    //    batch reprojection; two scans through local2global / mergeScansWithinGlobalCoordUtil == the head of the batch merge
+    {
+        CloudPtr local;
+        transformGlobalMapToLocal(C.map_global_curr_, C.keyframe_inverse_poses_.at(0), kSE3MatExtrinsicPoseBasetoLiDAR, local);
+        const CloudPtr projected = ltremovert::parseProjectedPoints(local, kFOV, resetRimgSize(kFOV, C.kReprojectionAlpha));
+        ScansPtr batch;
+        C.parseScansViaProjection(C.map_global_curr_, batch);
+        ltm_cloud hk = 0;
+        ltmCheck(dev_->ctx, ltm_scanset_keyframe(dev_->ctx, batch->h, 0, &hk), "ltm_scanset_keyframe");
+        expect(projected->size() > 0 && same(projected, C.wrap(hk)), "transformGlobalMapToLocal + parseProjectedPoints == parseScansViaProjection[0]");
+        std::vector<CloudPtr> two;
+        for (size_t k = 0; k < 2; ++k) { ltm_cloud hs = 0; ltmCheck(dev_->ctx, ltm_scanset_keyframe(dev_->ctx, C.keyframe_scans_->h, k, &hs), "ltm_scanset_keyframe"); two.push_back(C.wrap(hs)); }
+        const CloudPtr merged2 = mergeScansWithinGlobalCoordUtil(two, {C.keyframe_poses_.at(0), C.keyframe_poses_.at(1)}, kSE3MatExtrinsicLiDARtoPoseBase);
+        ltm_cloud hall = 0;
+        ltmCheck(dev_->ctx, ltm_merge_to_global(dev_->ctx, C.keyframe_scans_->h, C.poses_h_, &hall), "ltm_merge_to_global");
+        const Cloud all = C.wrap(hall)->download(), head = merged2->download();
+        expect(head.size() == two[0]->size() + two[1]->size() && head.size() <= all.size() &&
+               std::memcmp(head.data(), all.data(), head.size() * sizeof(PointType)) == 0, "mergeScansWithinGlobalCoordUtil == head of mergeScansWithinGlobalCoord");
+        expect(same(local2global(two[0], C.keyframe_poses_.at(0), kSE3MatExtrinsicLiDARtoPoseBase), mergeScansWithinGlobalCoordUtil({two[0]}, {C.keyframe_poses_.at(0)}, kSE3MatExtrinsicLiDARtoPoseBase)),
+               "local2global == a one-scan merge");
+        CloudPtr down;
+        ltremovert::octreeDownsampling(merged2, down, 0.4f);
+        expect(same(down, C.octreeDownsampling(merged2, 0.4f)), "free octreeDownsampling == Session::octreeDownsampling");
+        expect((linspace<int>(0, 5, 5) == std::vector<int>{0, 1, 2, 3, 4}) && (linspace<int>(0, 2, 2) == std::vector<int>{0, 2}), "linspace<int>");
+    }
+    // 4. quirk Q5
     expect((getStaticIdxFromDynamicIdx({}, 2) == std::vector<int>{0, 2}), "linspace<int>(0,2,2) == {0,2}");
     bool threw = false;
     try { getStaticIdxFromDynamicIdx({}, 1); } catch (const std::exception&) { threw = true; }

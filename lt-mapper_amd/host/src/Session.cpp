@@ -43,6 +43,65 @@ std::vector<Cloud> ScansH::download() const
     return out;
 }
 
+// ------------------------------------------------------------------ utility.h free functions on device clouds
+static float alphaOfShape(ltm_ctx* ctx, const std::pair<float, float>& fov, const std::pair<int, int>& shape)
+{
+    (void)ctx;
+    const float alpha = (float)shape.first / fov.first;
+    int r = 0, c = 0;
+    ltm_rimg_size(fov.first, fov.second, alpha, &r, &c);
+    if (r != shape.first || c != shape.second) throw std::runtime_error("range image shape is not a resolution of this field of view");
+    return alpha;
+}
+RangeImage map2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size)
+{
+    RangeImage img;
+    img.rows = _rimg_size.first; img.cols = _rimg_size.second;
+    img.range.resize((size_t)img.rows * img.cols);
+    img.ptidx.resize(img.range.size());
+    ltmCheck(_scan->ctx, ltm_debug_range_image(_scan->ctx, _scan->h, nullptr, nullptr, alphaOfShape(_scan->ctx, _fov, _rimg_size), img.range.data(), img.ptidx.data()),
+             "ltm_debug_range_image");
+    return img;
+}
+CloudPtr parseProjectedPoints(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size)
+{
+    const RangeImage img = map2RangeImg(_scan, _fov, _rimg_size);
+    std::vector<int32_t> idx;                              // row-major, `ptidx != 0` (utility.cpp:82: point 0 doubles as "empty", quirk Q3)
+    for (int32_t v : img.ptidx) if (v != 0) idx.push_back(v);
+    ltm_cloud h = 0;
+    ltmCheck(_scan->ctx, ltm_cloud_select(_scan->ctx, _scan->h, idx.data(), idx.size(), &h), "ltm_cloud_select");
+    return std::make_shared<CloudH>(_scan->ctx, h);
+}
+static CloudPtr transformed(const CloudPtr& in, const Matrix4d& first, const Matrix4d& second)
+{
+    ltm_cloud h = 0;
+    ltmCheck(in->ctx, ltm_cloud_transform(in->ctx, in->h, first.data(), second.data(), &h), "ltm_cloud_transform");
+    return std::make_shared<CloudH>(in->ctx, h);
+}
+void transformGlobalMapToLocal(const CloudPtr& _map_global, const Matrix4d& _base_pose_inverse, const Matrix4d& _base2lidar, CloudPtr& _map_local)
+{
+    _map_local = transformed(_map_global, _base_pose_inverse, _base2lidar);
+}
+CloudPtr local2global(const CloudPtr& _scan_local, const Matrix4d& _scan_pose, const Matrix4d& _base2lidar) { return transformed(_scan_local, _base2lidar, _scan_pose); }
+CloudPtr global2local(const CloudPtr& _scan_global, const Matrix4d& _scan_pose_inverse, const Matrix4d& _base2lidar) { return transformed(_scan_global, _scan_pose_inverse, _base2lidar); }
+CloudPtr mergeScansWithinGlobalCoordUtil(const std::vector<CloudPtr>& _scans, const std::vector<Matrix4d>& _scans_poses, const Matrix4d& _lidar2base)
+{
+    if (_scans.empty()) throw std::runtime_error("mergeScansWithinGlobalCoordUtil: no scans");
+    std::vector<CloudPtr> parts;
+    std::vector<ltm_cloud> hs;
+    for (size_t i = 0; i < _scans.size(); ++i) { parts.push_back(transformed(_scans[i], _lidar2base, _scans_poses.at(i))); hs.push_back(parts.back()->h); }
+    ltm_cloud h = 0;
+    ltmCheck(_scans[0]->ctx, ltm_cloud_concat(_scans[0]->ctx, hs.data(), hs.size(), &h), "ltm_cloud_concat");
+    return std::make_shared<CloudH>(_scans[0]->ctx, h);
+}
+void octreeDownsampling(const CloudPtr& _src, CloudPtr& _to_save, const float _kDownsampleVoxelSize)
+{
+    ltm_cloud h = 0;
+    ltmCheck(_src->ctx, ltm_voxel_centroid(_src->ctx, _src->h, _kDownsampleVoxelSize, &h), "ltm_voxel_centroid");
+    _to_save = std::make_shared<CloudH>(_src->ctx, h);
+}
+std::set<int> convertIntVecToSet(const std::vector<int>& v) { return std::set<int>(v.begin(), v.end()); }
+
 Session::Session(std::shared_ptr<Device> dev) : dev_(std::move(dev)) { kDownsampleVoxelSize = RosParamServer::kDownsampleVoxelSize; }
 
 void Session::loadSessionInfo(std::string _sess_type, std::string _scan_dir, std::string _pose_path)

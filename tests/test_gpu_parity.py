@@ -178,6 +178,20 @@ def test_viz_images_match_oracle_colormap(gpu_ctx, orc, small_pair, mode):
     assert len(np.unique(got["map"].reshape(-1, 3), axis=0)) > 20        # a real picture, not a constant
 
 
+def test_cloud_transform_matches_pcl_semantics(gpu_ctx, orc, small_pair):
+    """ltm_cloud_transform = pcl::transformPointCloud<double> once or twice (local2global / global2local / transformGlobalMapToLocal)"""
+    C, _ = small_pair
+    pts = C["scans"][:20000]
+    g = gpu_ctx.upload(pts)
+    l2b = np.eye(4); l2b[:3, :3] = [[0.0, -1.0, 0.0], [1.0, 0.0, 0.0], [0.0, 0.0, 1.0]]; l2b[:3, 3] = [0.3, -0.1, 0.25]
+    pose, inv = C["poses"][2].reshape(4, 4), C["inv"][2].reshape(4, 4)
+    assert_clouds_equal(gpu_ctx.transform(g, l2b, pose).download(), orc.transform(pose, orc.transform(l2b, pts)), "local2global")
+    assert_clouds_equal(gpu_ctx.transform(g, inv, np.linalg.inv(l2b)).download(), orc.transform(np.linalg.inv(l2b), orc.transform(inv, pts)), "global2local")
+    assert_clouds_equal(gpu_ctx.transform(g, pose).download(), orc.transform(pose, pts), "single transform")
+    assert_clouds_equal(gpu_ctx.transform(g, None, pose).download(), orc.transform(pose, pts), "second only")
+    assert_clouds_equal(gpu_ctx.transform(g).download(), pts, "no transform = copy")
+
+
 def test_cloud_select_and_scan_of_keyframe(gpu_ctx, small_pair):
     """pcl::ExtractIndices stand-in (parsePointcloudSubsetUsingPtIdx) and the per-keyframe slice of a scan set"""
     C, _ = small_pair
