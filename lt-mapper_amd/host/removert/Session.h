@@ -104,6 +104,12 @@ public:
     void updateScansScanwise();                                                                    // :362-380
     void extractLowDynPointsViaKnnDiff(const CloudPtr& _target_map);                               // :393-427
     void extractHighDynPointsViaKnnDiff(const CloudPtr& _target_map);                              // :487-504
+    // per-scan forms (Session.cpp:537-607, 610-642), thin wrappers: same rule on one keyframe against the target map of the last
+    // extract*ViaKnnDiff call (the reference keeps that map's kd-tree as a member); {coexist, diff} resp. {static, dynamic}
+    std::pair<CloudPtr, CloudPtr> partitionLowDynamicPointsOfScanByKnn(int _scan_idx);
+    std::pair<CloudPtr, CloudPtr> partitionHighDynamicPointsOfScanByKnn(int _scan_idx);
+    void allocateMemory() {}                                                                       // :62-78: nothing to pre-allocate here
+    CloudPtr knn_target_map_;
     void constructGlobalNDMap();                                                                   // :430-435
     void removeWeakNDMapPointsHavingStrongNDInNear();                                              // :452-484
     void constructGlobalPDMap();                                                                   // :437-445

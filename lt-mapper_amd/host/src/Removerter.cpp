@@ -479,7 +479,17 @@ bool Removerter::checkFineGrainedWrappers()
         expect(same(down, C.octreeDownsampling(merged2, 0.4f)), "free octreeDownsampling == Session::octreeDownsampling");
         expect((linspace<int>(0, 5, 5) == std::vector<int>{0, 1, 2, 3, 4}) && (linspace<int>(0, 2, 2) == std::vector<int>{0, 2}), "linspace<int>");
     }
-    // 4. quirk Q5
+    // 4. per-scan kNN forms == that keyframe of the batch stage
+    {
+        C.parseStaticScansViaProjection();
+        C.extractLowDynPointsViaKnnDiff(query_sess_.map_global_curr_);
+        const auto [co1, di1] = C.partitionLowDynamicPointsOfScanByKnn(1);
+        ltm_cloud ha = 0, hb = 0;
+        ltmCheck(dev_->ctx, ltm_scanset_keyframe(dev_->ctx, C.scans_knn_coexist_->h, 1, &ha), "ltm_scanset_keyframe");
+        ltmCheck(dev_->ctx, ltm_scanset_keyframe(dev_->ctx, C.scans_knn_diff_->h, 1, &hb), "ltm_scanset_keyframe");
+        expect(co1->size() + di1->size() > 0 && same(co1, C.wrap(ha)) && same(di1, C.wrap(hb)), "partitionLowDynamicPointsOfScanByKnn(1) == extractLowDynPointsViaKnnDiff()[1]");
+    }
+    // 5. quirk Q5
     expect((getStaticIdxFromDynamicIdx({}, 2) == std::vector<int>{0, 2}), "linspace<int>(0,2,2) == {0,2}");
     bool threw = false;
     try { getStaticIdxFromDynamicIdx({}, 1); } catch (const std::exception&) { threw = true; }

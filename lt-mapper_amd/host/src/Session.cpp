@@ -281,8 +281,24 @@ void Session::updateScansScanwise()
     keyframe_scans_updated_ = wrap_scans(voxelised);
 }
 
+static std::pair<CloudPtr, CloudPtr> knnOneScan(const Session& s, const CloudPtr& target, const ScansPtr& scans, int idx)
+{
+    if (!target) throw std::runtime_error("no kNN target map yet: call extract*ViaKnnDiff first");
+    ltm_scanset co = 0, di = 0;
+    ltmCheck(s.dev_->ctx, ltm_knn_partition(s.dev_->ctx, target->h, scans->h, s.poses_h_, (size_t)idx, (size_t)idx + 1, s.kNumKnnPointsToCompare,
+                                            s.kScanKnnAndMapKnnAvgDiffThreshold, &co, &di), "ltm_knn_partition");
+    const ScansH a(s.dev_->ctx, co), b(s.dev_->ctx, di);          // freed on return
+    ltm_cloud ca = 0, cb = 0;
+    ltmCheck(s.dev_->ctx, ltm_scanset_keyframe(s.dev_->ctx, co, 0, &ca), "ltm_scanset_keyframe");
+    ltmCheck(s.dev_->ctx, ltm_scanset_keyframe(s.dev_->ctx, di, 0, &cb), "ltm_scanset_keyframe");
+    return {s.wrap(ca), s.wrap(cb)};
+}
+std::pair<CloudPtr, CloudPtr> Session::partitionLowDynamicPointsOfScanByKnn(int _scan_idx) { return knnOneScan(*this, knn_target_map_, keyframe_scans_static_projected_, _scan_idx); }
+std::pair<CloudPtr, CloudPtr> Session::partitionHighDynamicPointsOfScanByKnn(int _scan_idx) { return knnOneScan(*this, knn_target_map_, keyframe_scans_, _scan_idx); }
+
 void Session::extractLowDynPointsViaKnnDiff(const CloudPtr& _target_map)
 {
+    knn_target_map_ = _target_map;
     // Session.cpp:395-402 build a 0.4 m octree for an ICP that is disabled (useICPrefinement{false}); no observable effect, not run
     ltm_scanset co = 0, di = 0;
     ltmCheck(dev_->ctx, ltm_knn_partition(dev_->ctx, _target_map->h, keyframe_scans_static_projected_->h, poses_h_, 0, keyframe_poses_.size(),
@@ -292,6 +308,7 @@ void Session::extractLowDynPointsViaKnnDiff(const CloudPtr& _target_map)
 
 void Session::extractHighDynPointsViaKnnDiff(const CloudPtr& _target_map)
 {
+    knn_target_map_ = _target_map;
     ltm_scanset di = 0;
     ltmCheck(dev_->ctx, ltm_knn_partition(dev_->ctx, _target_map->h, keyframe_scans_->h, poses_h_, 0, keyframe_poses_.size(),
                                           kNumKnnPointsToCompare, kScanKnnAndMapKnnAvgDiffThreshold, nullptr, &di), "ltm_knn_partition");
