@@ -1,33 +1,43 @@
 #!/usr/bin/env python3
 """bench.py -- keyframe-pairs/sec of the LT-removert / LT-map hot path (BASELINE.json metric) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W          (N>1: launched one rank per GPU by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+N > 1 without a torch.distributed environment re-launches itself as
+`python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ...` (one rank per GPU over RCCL); when
+the driver already launched it that way the environment is used as it is.
 
 A *step* is one full pass of the hot path over one synthetic session pair that is already resident in HBM:
 makeGlobalMap + Removerter::run() Steps 1-3 (Removerter.cpp:1653-1678) = remove/revert visibility votes, static
 reprojection, inter-session kNN change detection, ND/PD filtering, LT-map composition and the final reprojections.
 Default workload = BASELINE.json configs[1]: "ParkingLot 01 vs 02, 500 keyframes each, 3-res removert, 1xMI355X"
-restated on the synthetic `lot` scene (tools/synth.py; no dataset is reachable offline).
+restated on the synthetic `lot` scene (tools/synth.py; no dataset is reachable offline).  `lot-cascade-6x500` is
+configs[2]: five chained pair runs 01 -> 02..06 (lt-mapper_amd/cascade.py), 2500 keyframe pairs per step.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline     -- the dominant kernel (k_map_rimg, class "vote_map"): algorithmic bytes per launch / average launch
-                  duration measured with HIP events on the context's stream, against the 8 TB/s HBM peak
+  roofline     -- the dominant kernel (k_vote_map_cull): algorithmic bytes per launch (map tiles actually read + images
+                  written) / average launch duration measured with HIP events on the context's stream, against the 8 TB/s
+                  HBM peak; `valu_issue_frac` = VALU lane-instructions issued per second against the vector pipes' peak (what
+                  really bounds this kernel); `traffic` = PMC-measured HBM bytes per launch (profiles/, only if it was
+                  collected for exactly this kernel source);
+  rooflines    -- the same figure for every kernel class of the step;
   cpu_baseline -- the CPU oracle (a port of the reference; the reference itself cannot be built here) timed on this
-                  box on a bounded keyframe sample of the same workload, single thread
+                  box on a bounded keyframe sample of the same workload: single thread (the north-star denominator) and
+                  all cores; the committed full, unsampled runs are quoted next to it.
 """
 import argparse
+import hashlib
 import json
 import os
+import socket
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-import numpy as np  # noqa: E402
-import torch  # noqa: E402
-
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+N_CU, SIMD_PER_CU, LANES_PER_SIMD = 256, 4, 16
 
 DEFAULT_WORKLOAD = "lot-2x500-os1-64-3res"
 WORKLOADS = {
@@ -35,9 +45,22 @@ WORKLOADS = {
     "lot-2x500-os1-64-3res": ("os1-64", 500, True, "lot", 1.0, 0.05, 2, 0.01),        # BASELINE configs[1] (default)
     "lot-2x50-os1-64-1res": ("os1-64", 50, False, "lot", 1.0, 0.05, 2, 0.01),         # configs[0] shape (plumbing case)
     "lot-2x100-small-3res": ("small", 100, True, "lot", 1.0, 0.05, 2, 0.01),          # quick check
+    "lot-cascade-6x500": ("os1-64", 500, True, "lot", 1.0, 0.05, 2, 0.01),            # configs[2]: sessions 01 -> 02..06 chained
+    "lot-cascade-4x50-small": ("small", 50, True, "lot", 1.0, 0.05, 2, 0.01),         # quick check of the cascade workload
     "street-2x2000-hdl64e-1res": ("hdl-64e", 2000, False, "street", 1.0, 0.05, 2, 0.01),   # configs[3], KITTI-scale
     "street-2x2000-hdl64e-3res": ("hdl-64e", 2000, True, "street", 1.0, 0.05, 2, 0.01),
     "street-2x200-mls-knn": ("mls", 200, False, "street", 2.0, 0.1, 2, 0.04),         # configs[4], dense MLS kNN stress
+}
+CASCADE_SESSIONS = {"lot-cascade-6x500": 6, "lot-cascade-4x50-small": 4}
+
+# kernel class (ltm_profile_read) -> kernels behind it; bytes are the algorithmic bytes of DESIGN.md section 4
+CLASS_KERNELS = {
+    "vote_map_cull": "k_vote_map_cull", "vote_map_exact": "k_map_rimg_blockmin", "reproject_map": "k_map_rimg_blockmin",
+    "vote_scan": "k_scan_rimg + k_image_max", "vote_compare": "k_compare_flag", "vote_fill": "k_fill_u64",
+    "partition": "rocprim scan + k_partition_scatter", "voxel": "bbox + Morton keys + rocprim radix sort + k_voxel_centroids",
+    "voxel_scanset": "per-keyframe bbox + composite keys + rocprim radix sort + k_voxel_centroids",
+    "knn_build": "k_cell_keys + rocprim radix sort + k_hash_build", "knn_query": "k_knn_query_scans / k_knn_query_cloud",
+    "reproject_gather": "rocprim scan + k_reproject_gather", "merge": "k_transform_scans",
 }
 
 
@@ -47,20 +70,38 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-stride", type=int, default=100, help="cpu_baseline: visit every s-th keyframe in per-keyframe loops")
+    ap.add_argument("--cpu-stride", type=int, default=50, help="cpu_baseline, single thread: visit every s-th keyframe in per-keyframe loops")
+    ap.add_argument("--cpu-stride-allcore", type=int, default=10, help="cpu_baseline, all cores: keyframe stride")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--verbose", action="store_true")
     return ap.parse_args()
 
 
+def relaunch_under_torchrun(n):
+    """`python bench.py --gpus N` without a launcher: become `python -m torch.distributed.run ... bench.py <same args>`"""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    os.execvpe(cmd[0], cmd, env)
+
+
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        relaunch_under_torchrun(args.gpus)
+    import numpy as np
+    import torch
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
     assert torch.cuda.is_available(), "bench.py needs a GPU: there is no CPU fallback for the measured path"
     torch.cuda.set_device(local_rank)
     dist = None
@@ -71,14 +112,16 @@ def main():
 
     import ltmapper_amd  # noqa: F401
     from ltmapper_amd import capi
+    from ltmapper_amd.cascade import run_cascade
     from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
     from tools import synth
 
     sensor, n_kf, three_res, scene, spacing, voxel, knn_k, knn_thr = WORKLOADS[args.workload]
+    n_sessions = CASCADE_SESSIONS.get(args.workload, 2)
     dev = f"cuda:{local_rank}"
     t0 = time.perf_counter()
-    # synthetic sessions 01 / 02, generated on the GPU, already in HBM when the timed region starts
-    sess_t = [synth.make_session(s, n_kf, sensor, device=dev, scene=scene, kf_spacing=spacing) for s in (1, 2)]
+    # synthetic sessions 01, 02, ..., generated on the GPU, already in HBM when the timed region starts
+    sess_t = [synth.make_session(s, n_kf, sensor, device=dev, scene=scene, kf_spacing=spacing) for s in range(1, n_sessions + 1)]
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
 
@@ -86,13 +129,9 @@ def main():
     P = Params(gpu_use_self_removert=three_res, remove_resolution_list=[2.5, 2.0, 1.5] if three_res else [2.5],
                num_nn_points_within=knn_k, dist_nn_points_within=knn_thr, downsample_voxel_size=voxel)
 
-    def fresh_sessions():
-        out = []
-        for name, S in zip(("Central", "Query"), sess_t):
-            scans = ctx.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64))
-            scans = ctx.preclean(scans, 2.5)                      # precleaningKeyframes(2.5), Removerter.cpp:1660
-            out.append(Session(name, scans, ctx.poses(S["poses"], S["inv"])))
-        return out
+    def load(S):
+        scans = ctx.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64))
+        return ctx.preclean(scans, 2.5), ctx.poses(S["poses"], S["inv"])     # precleaningKeyframes(2.5), Removerter.cpp:1660
 
     if world > 1:
         from ltmapper_amd.dist import ShardedOps
@@ -100,12 +139,15 @@ def main():
     else:
         ops = HipOps(ctx)
 
-    sessions = fresh_sessions()   # loading + pre-clean are Step 0 plumbing, outside the timed region
+    loaded = [load(S) for S in sess_t]   # loading + pre-clean are Step 0 plumbing, outside the timed region
 
     def one_step():
         ctx.clear_caches()   # no derived data (scan range images) survives from a previous step: every step is a fresh run
-        C, Q = sessions
-        rm = Removerter(ops, P, Session("Central", C.keyframe_scans_, C.keyframe_poses), Session("Query", Q.keyframe_scans_, Q.keyframe_poses))
+        if n_sessions > 2:
+            runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:])
+            return runs[-1]
+        (cs, cp), (qs, qp) = loaded
+        rm = Removerter(ops, P, Session("Central", cs, cp), Session("Query", qs, qp))
         rm.run()
         return rm
 
@@ -134,9 +176,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    pairs_per_step = n_kf                      # min(N_c, N_q) keyframe pairs per session pair
+    pairs_per_step = n_kf * (n_sessions - 1)   # min(N_c, N_q) keyframe pairs per session pair, one pair run per query session
     value = pairs_per_step * args.steps / elapsed
     ms_per_step = 1e3 * elapsed / args.steps
+
+    clock_hz = 1e3 * float(getattr(torch.cuda.get_device_properties(local_rank), "clock_rate", 2.4e6))
+    valu_peak = N_CU * SIMD_PER_CU * LANES_PER_SIMD * clock_hz      # VALU lane-instructions per second
+    pmc = load_pmc(args.workload)
+
+    def class_roofline(cls, v):
+        if not v["launches"] or v["ms"] <= 0:
+            return None
+        achieved = v["bytes"] / (v["ms"] * 1e-3) / 1e9
+        return {"class": cls, "kernels": CLASS_KERNELS.get(cls, cls), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(v["ms"] / args.steps, 3),
+                "launches_per_step": round(v["launches"] / max(args.steps, 1), 2),
+                "algorithmic_bytes_per_step": round(v["bytes"] / args.steps, 1), "units_per_step": round(v["units"] / args.steps, 1)}
 
     # dominant kernel: k_vote_map_cull (profile class "vote_map_cull"; falls back to the exact kernel if culling is disabled)
     cls = "vote_map_cull" if prof.get("vote_map_cull", {}).get("launches") else "vote_map_exact"
@@ -144,17 +199,27 @@ def main():
     roofline = None
     if vm["launches"]:
         achieved = vm["bytes"] / (vm["ms"] * 1e-3) / 1e9
+        pps = vm["units"] / (vm["ms"] * 1e-3)
+        vpp = pmc.get("valu_insts_per_point") if cls == "vote_map_cull" else None
         roofline = {"bound": "hbm", "kernel": "k_vote_map_cull" if cls == "vote_map_cull" else "k_map_rimg_blockmin",
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": measured_traffic(cls, args.workload), "launches_per_step": vm["launches"] // max(args.steps, 1),
+                    "traffic": pmc.get("hbm_bytes_per_launch") if cls == "vote_map_cull" else None,
+                    "traffic_source": pmc.get("source"),
+                    "launches_per_step": vm["launches"] // max(args.steps, 1),
                     "avg_launch_ms": round(vm["ms"] / vm["launches"], 4),
                     "algorithmic_bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
-                    "algorithmic_definition": "nb*(16*M + 8*R*C) per launch over nb keyframes (SURVEY 8d: map read + range|index image)",
-                    "point_projections_per_s": round(vm["units"] / (vm["ms"] * 1e-3), 1)}
+                    "algorithmic_definition": "16 B x (points of the map tiles the launch reads: whole-tile-culled tiles excluded) + 8 B x R x C per keyframe image "
+                                              "(SURVEY 8d: map read + range|index image)",
+                    "point_projections_per_s": round(pps, 1),
+                    "valu_insts_per_point": vpp,
+                    "valu_issue_frac": round(vpp * pps / valu_peak, 4) if vpp else None,
+                    "valu_peak_lane_insts_per_s": valu_peak,
+                    "real_bound": "VALU issue (see valu_issue_frac): the map stays in L2 / Infinity Cache, measured HBM traffic is several times below the algorithmic bytes"}
+    rooflines = [r for r in (class_roofline(k, v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])) if r]
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args.cpu_stride, args.verbose, knn_k, knn_thr, voxel)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline and n_sessions == 2:
+        cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k, knn_thr, voxel)
 
     if rank == 0:
         M_c = len(last.outputs["OriginalNoisyCentralMapGlobal"])
@@ -164,13 +229,14 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
             "dtype": "f32 (+f64 rigid transforms, u64 range|index atomics)", "data": "synthetic (tools/synth.py synth-v1, seed 20250224)",
-            "config": {"workload": args.workload, "sessions": f"{scene} 01 vs 02", "keyframes_per_session": n_kf, "sensor": sensor,
+            "config": {"workload": args.workload, "sessions": f"{scene} 01 vs 02" if n_sessions == 2 else f"{scene} cascade 01 -> 02..{n_sessions:02d} ({n_sessions - 1} chained pair runs)",
+                       "keyframes_per_session": n_kf, "keyframe_pairs_per_step": pairs_per_step, "sensor": sensor,
                        "remove_resolution_list": P.remove_resolution_list if three_res else [2.5], "self_removert": three_res,
-                       "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points": [M_c, M_q],
+                       "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points_last_pair": [M_c, M_q],
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
                        "parallelism": f"keyframe-sharded x{world} (label all-reduce + scan all-gather)" if world > 1 else "single GPU",
-                       "step": "makeGlobalMap + Removerter::run Steps 1-3, inputs resident in HBM"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline,
+                       "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
@@ -181,22 +247,36 @@ def main():
         dist.destroy_process_group()
 
 
-def measured_traffic(cls, workload):
-    """HBM bytes per launch of the dominant kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
-    inside this process; the file records the command).  None if no measurement exists for this kernel and workload."""
-    path = os.path.join(ROOT, "profiles", "r1_final_pmc_hbm_traffic.json")
-    if cls != "vote_map_cull" or workload != DEFAULT_WORKLOAD or not os.path.exists(path):
-        return None
+def kernels_sha():
+    h = hashlib.sha256()
+    for f in ("ltm_kernels.hip", "ltm_device_math.h", "ltm_kernels.h"):
+        h.update(open(os.path.join(ROOT, "lt-mapper_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def load_pmc(workload):
+    """PMC figures of the dominant kernel (rocprofv3 cannot run inside this process): profiles/pmc_latest.json is regenerated by
+    tools/collect_profiles.sh, which stamps it with the commit and a hash of the kernel sources; it is used only if that hash
+    equals the sources this run was built from and the workload matches -- otherwise traffic / VALU counts are null, never stale."""
+    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
     try:
-        return round(json.load(open(path))["hbm_bytes_per_launch"], 1)
+        d = json.load(open(path))
     except Exception:
-        return None
+        return {}
+    if d.get("workload") != workload or d.get("kernels_sha") != kernels_sha():
+        return {"source": f"profiles/pmc_latest.json ignored: collected for workload {d.get('workload')} / kernel sources {d.get('kernels_sha')}, "
+                          f"this run is {workload} / {kernels_sha()}"}
+    return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "valu_insts_per_point": d.get("valu_insts_per_point"),
+            "source": f"profiles/pmc_latest.json (commit {d.get('commit')}, kernel sources {d.get('kernels_sha')}): separate rocprofv3 --pmc passes, "
+                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; SQ_INSTS_VALU*64 / point-projections"}
 
 
-def run_cpu_baseline(sess_t, three_res, n_kf, stride, verbose, knn_k=2, knn_thr=0.01, voxel=0.05):
-    """CPU oracle (port of the reference's algorithm, single thread) on a bounded sample: the whole pipeline runs on
-    the full-size sessions but every per-keyframe loop visits only each `stride`-th keyframe; per-keyframe stage times are
-    scaled by the true visit ratio, whole-map stages (voxel grids, kd-tree builds) are timed in full."""
+def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel=0.05):
+    """CPU oracle (port of the reference's algorithm) on a bounded sample: the whole pipeline runs on the full-size sessions but
+    every per-keyframe loop visits only each `stride`-th keyframe; per-keyframe stage times are scaled by the true visit ratio,
+    whole-map stages (voxel grids, kd-tree builds) are timed in full.  Two legs: one thread (north-star denominator) and all
+    cores (the reference's OpenMP sites).  The committed full unsampled runs (profiles/, tools/cpu_baseline_full.py) are quoted."""
+    import numpy as np
     from oracle import oracle_py as orc
     from tools import synth
     C, Q = (synth.to_numpy(s) for s in sess_t)
@@ -206,24 +286,44 @@ def run_cpu_baseline(sess_t, three_res, n_kf, stride, verbose, knn_k=2, knn_thr=
             p = orc.preclean(S["scans"][int(S["offsets"][k]):int(S["offsets"][k + 1])], 2.5)
             pts.append(p); off.append(off[-1] + len(p))
         S["scans"], S["offsets"] = np.concatenate(pts), np.array(off, dtype=np.uint64)
-    stride = max(1, min(stride, n_kf))
-    visited = len(range(0, n_kf, stride))
-    scale = n_kf / visited
-    P = orc.make_params(k=knn_k, knn_thr=knn_thr, voxel=voxel, use_self_removert=three_res, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,),
-                        threads=1, kf_sample_stride=stride)
-    t0 = time.perf_counter()
-    res = orc.pipeline_run(P, C, Q)
-    wall = time.perf_counter() - t0
-    tm = res.timings()
     per_kf = ("vote_large", "vote_small", "reproject_large", "reproject_small", "knn_query", "voxel_scanwise")
-    est = sum(v * (scale if k in per_kf else 1.0) for k, v in tm.items() if k != "steps_1_to_3_total")
-    if verbose:
-        print("cpu timings", tm, "wall", wall, "scale", scale, file=sys.stderr)
-    return {"value": round(n_kf / est, 4), "unit": "keyframe-pairs/s", "cores": 1, "kind": "port",
-            "sample": f"oracle/libltm_oracle.so, full-size sessions, every {stride}th keyframe ({visited} of {n_kf} per session) in the per-keyframe "
-                      f"loops (votes, reprojections, kNN queries) scaled x{scale:.1f}; voxel grids and kd-tree builds timed in full; "
-                      f"{wall:.1f} s measured, {est:.0f} s extrapolated per step",
-            "measured_s": round(wall, 2), "extrapolated_step_s": round(est, 1)}
+
+    def leg(threads, stride):
+        stride = max(1, min(stride, n_kf))
+        visited = len(range(0, n_kf, stride))
+        scale = n_kf / visited
+        P = orc.make_params(k=knn_k, knn_thr=knn_thr, voxel=voxel, use_self_removert=three_res, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,),
+                            threads=threads, kf_sample_stride=stride)
+        t0 = time.perf_counter()
+        res = orc.pipeline_run(P, C, Q)
+        wall = time.perf_counter() - t0
+        tm = res.timings()
+        res.free()
+        est = sum(v * (scale if k in per_kf else 1.0) for k, v in tm.items() if k != "steps_1_to_3_total")
+        if args.verbose:
+            print("cpu timings", threads, tm, "wall", wall, "scale", scale, file=sys.stderr)
+        return {"value": round(n_kf / est, 4), "unit": "keyframe-pairs/s", "cores": threads, "keyframe_stride": stride,
+                "keyframes_visited_per_session": visited, "measured_s": round(wall, 2), "extrapolated_step_s": round(est, 1)}
+
+    ncores = os.cpu_count() or 1
+    one = leg(1, args.cpu_stride)
+    allc = leg(ncores, args.cpu_stride_allcore) if ncores > 1 else None
+    full = {}
+    for tag in ("1thread", "allcore"):
+        try:
+            d = json.load(open(os.path.join(ROOT, "profiles", f"r2_cpu_baseline_full_{tag}.json")))
+            full[tag] = {k: d[k] for k in ("threads", "nproc", "cpu", "median_wall_s", "keyframe_pairs_per_s", "commit") if k in d}
+        except Exception:
+            pass
+    out = {"value": one["value"], "unit": "keyframe-pairs/s", "cores": 1, "kind": "port",
+           "sample": f"oracle/libltm_oracle.so (sort-based voxel grid + kd-tree: faster than the PCL-based reference), full-size sessions, every "
+                     f"{one['keyframe_stride']}th keyframe ({one['keyframes_visited_per_session']} of {n_kf} per session) in the per-keyframe loops (votes, "
+                     f"reprojections, kNN queries) scaled x{n_kf / one['keyframes_visited_per_session']:.1f}; voxel grids and kd-tree builds timed in full; "
+                     f"{one['measured_s']:.1f} s measured, {one['extrapolated_step_s']:.0f} s extrapolated per step",
+           "measured_s": one["measured_s"], "extrapolated_step_s": one["extrapolated_step_s"], "host_cores": ncores,
+           "all_cores": allc,
+           "full_unsampled_runs_committed": full or None}
+    return out
 
 
 if __name__ == "__main__":

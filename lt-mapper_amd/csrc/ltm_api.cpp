@@ -288,6 +288,10 @@ void approx_pose(const double* b2l16, const double* inv16, float* out)
     const double det = a * (e * i - f * h) - b * (d * i - f * g) + c3 * (d * h - e * g);
     for (int k = 0; k < 16; ++k) out[k] = 0.0f;
     if (!(std::fabs(det) > 1e-12) || !std::isfinite(det)) return;          // ok stays 0: every point takes the exact path
+    // The exact path rounds to float BETWEEN the inverse pose and base->lidar (utility.cpp:70-71), so its error relative to the
+    // range grows with |lever arm| / range; the bounds ltm_debug_cull_check validates (3e-3 px, 3e-6 r) assume a sensor mounted
+    // within a few metres of the pose base.  A larger extrinsic translation sends every point down the exact path.
+    if (std::sqrt(b2l16[3] * b2l16[3] + b2l16[7] * b2l16[7] + b2l16[11] * b2l16[11]) > 10.0) return;
     const double inv[9] = {(e * i - f * h) / det, (c3 * h - b * i) / det, (b * f - c3 * e) / det,
                            (f * g - d * i) / det, (a * i - c3 * g) / det, (c3 * d - a * f) / det,
                            (d * h - e * g) / det, (b * g - a * h) / det, (a * e - b * d) / det};
@@ -434,7 +438,18 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
         {
             // class name = kernel: k_vote_map_cull for mode 0 (when enabled), k_map_rimg_blockmin otherwise
             const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
-            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
+            // algorithmic bytes = map tiles read + images written.  Tiles that the whole-tile range cull drops are never read, so
+            // (measurement only, when profiling is on) they are counted by the same predicate and left out.
+            double pts = (double)map.n * nb;
+            if (cull && c->prof_on && tile_cull_enabled() && smax) {
+                DevBuf live(c, 8);
+                LTM_HIP(hipMemsetAsync(live.p, 0, 8, c->stream));
+                LTM_HIP(count_live_tiles(ps.approx_dev, kb, nb, tb.as<float>(), n_tiles, smax, thr, live.as<unsigned long long>(), c->stream));
+                unsigned long long nlive = 0;
+                d2h(c, &nlive, live.p, 8);
+                pts = std::min(pts, (double)nlive * 4096.0);
+            }
+            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, 16.0 * pts + (double)nb * 8.0 * npx);
             LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img,
                                           mode == 0 ? tb.as<float>() : nullptr, smax, thr, mode, map_img.as<uint64_t>(), c->stream));
         }
@@ -1182,6 +1197,7 @@ int ltm_partition_by_labels(ltm_ctx* c, ltm_cloud hmap, const uint8_t* labels_de
         LTM_REQUIRE(labels_dev || get_cloud(c, hmap).n == 0, "null labels buffer");
         const Cloud map = get_cloud(c, hmap);
         do_partition(c, map, labels_dev, kept, flagged);
+        sync(c);   // labels_dev is the caller's (e.g. a torch tensor that may be recycled on another stream as soon as we return)
     });
 }
 
@@ -1418,7 +1434,6 @@ int ltm_debug_cull_check(ltm_ctx* c, const float* xyz, size_t n, const double* i
         LTM_HIP(hipMemsetAsync(bad.p, 0, 8, c->stream));
         HostMat34 T{};
         if (inv_pose16) {
-            LTM_REQUIRE(c->b2l_identity, "cull check with a pose needs an identity extrinsic");
             float ap[16];
             double b2l16[16] = {0};
             memcpy(b2l16, c->B2L.m, 12 * sizeof(double)); b2l16[15] = 1.0;
@@ -1426,7 +1441,7 @@ int ltm_debug_cull_check(ltm_ctx* c, const float* xyz, size_t n, const double* i
             h2d(c, apd.p, ap, 64);
             T = to34(inv_pose16);
         }
-        LTM_HIP(cull_check(in.as<float>(), n, inv_pose16 ? &T : nullptr, apd.as<float>(), g, bad.as<unsigned long long>(), c->stream));
+        LTM_HIP(cull_check(in.as<float>(), n, inv_pose16 ? &T : nullptr, &c->B2L, c->b2l_identity, apd.as<float>(), g, bad.as<unsigned long long>(), c->stream));
         unsigned long long v = 0;
         d2h(c, &v, bad.p, 8);
         *violations = v;

@@ -45,9 +45,13 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
                                  const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s);
 void set_vote_cull(int v);
 int vote_cull_enabled();
+int tile_cull_enabled();
+hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,
+                            const uint32_t* smax_bits_dev, float thr, unsigned long long* live_dev, hipStream_t s);
 void set_kf_per_block(int v);    // keyframes that share one map-tile read inside a workgroup (1, 2, 4, 8)
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s);   // {survivors, points} since the last reset
-hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const float* approx_pose_dev, Geom g, unsigned long long* bad_dev, hipStream_t s);
+hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,
+                      Geom g, unsigned long long* bad_dev, hipStream_t s);
 void set_map_kernel_variant(int v);   // 0 = per-point global atomics, 1 = LDS pre-reduction (default)
 // generic single image with up to two explicit transforms (debug / parity)
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,

@@ -116,7 +116,7 @@ k_scan_rimg(const float4* __restrict__ scans, const uint64_t* __restrict__ offse
     img_min_u32(img + (lo - kb) * (size_t)(g.rows * g.cols) + px, f2u(s.r));
 }
 
-// smax[kf] = float bits of the largest VALID (< 9000) pixel of the finished scan image of keyframe kf: a map point farther than
+// smax[kf] = float bits of the largest NON-EMPTY (< 10000) pixel of the finished scan image of keyframe kf: a map point farther than
 // smax - thr cannot be flagged in mode 0.  grid = (chunks, keyframes); positive floats order like their bit patterns.
 __global__ void __launch_bounds__(kBlock)
 k_image_max(const uint32_t* __restrict__ img, uint32_t npx, uint32_t* __restrict__ smax)
@@ -126,7 +126,7 @@ k_image_max(const uint32_t* __restrict__ img, uint32_t npx, uint32_t* __restrict
     uint32_t m = 0;
     for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < npx; i += gridDim.x * blockDim.x) {
         const uint32_t v = imgk[i];
-        m = max(m, (v < 0x460ca000u /* 9000.0f */) ? v : 0u);
+        m = max(m, (v < 0x461c4000u /* 10000.0f = empty */) ? v : 0u);
     }
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, off, 64));
@@ -343,7 +343,11 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     // rowh/colh are bounded (|atan| <= pi) unless something upstream made a NaN, and a NaN fails the "<=" below as well.
     const float rfr = __builtin_amdgcn_fractf(cc.rowh), cfr = __builtin_amdgcn_fractf(cc.colh);   // distance above the rounding boundary
     const bool certain = fmaxf(fabsf(rfr - 0.5f), fabsf(cfr - 0.5f)) <= 0.5f - kCullEpsPx;
-    cc.unusual = (p.y == 0.0f) | !(cc.rowh + cc.colh + r < 3.0e4f);   // NaN anywhere (e.g. denormal y with x = 0), absurd ranges (r >= ~2.8e4 incl. inf)
+    // The same compare also sends every point with r >= ~8000 m down the exact path (rowh + colh >= -1.3 R, so passing it means
+    // r < 8000 + 1.3 R < 9800 for any image below 1300 rows): the reference's "empty pixel = 10000 m" sentinel arithmetic
+    // (diff = 10000 - r, Removerter.cpp:398-404) flags a map point 9800..9999.9 m from the sensor on an EMPTY scan pixel, which
+    // the fast test below (empty pixels never flag) would drop.
+    cc.unusual = (p.y == 0.0f) | !(cc.rowh + cc.colh + r < 8.0e3f);   // also NaN anywhere (e.g. denormal y with x = 0) and inf
     cc.multi = !certain;
     // clamp(floor(v), 0, n-1) == trunc(med3(v, 0, n-1)): the bounds are integers and the clamped value is non-negative
     cc.rb = (int)__builtin_amdgcn_fmed3f(cc.rowh, 0.0f, g.frows - 1.0f);
@@ -422,6 +426,51 @@ __device__ __forceinline__ uint32_t exact_range_bits(const float4 p4, const Mat3
     return f2u(__builtin_sqrtf(xy + p.z * p.z));
 }
 
+// Whole-tile range cull: no point of a tile can be nearer to the sensor than the distance from the sensor position to the tile's
+// bounding box; if that already exceeds the keyframe's longest scan return (minus thr, with margins for a slightly
+// non-orthonormal pose and float rounding) nothing there can be flagged and the workgroup is done.
+// ap = the keyframe's approximate pose (16 floats), tb = {min xyz, max xyz} of the tile, smax = longest non-empty scan return.
+__device__ __forceinline__ bool tile_out_of_reach(const float* __restrict__ ap, const float* __restrict__ tb, float smax, float thr)
+{
+    float d2 = 0.0f, far2 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+        const float c = ap[9 + d];                            // sensor position to ~1e-5 m: the margins below are 1e-2
+        const float lo = tb[d] - c, hi = c - tb[3 + d];
+        const float e = fmaxf(fmaxf(lo, hi), 0.0f);          // distance to the box along this axis
+        const float f = fmaxf(fabsf(lo), fabsf(hi));          // distance to its farthest face
+        d2 = __builtin_fmaf(e, e, d2);
+        far2 = __builtin_fmaf(f, f, far2);
+    }
+    // exact local range of any point of the tile: |A (p - c)| >= smin * |p - c| >= smin * dist(c, box); ap[15] = lower bound of smin
+    const float smin = ap[15];
+    const float reach = fmaxf(smax - thr, 0.0f) + 1.0e-2f + smax * 1.0e-3f;
+    // far2 guard: beyond ~8.9 km the reference's "empty pixel = 10000" sentinel arithmetic could flag a point; never cull there
+    return smin > 0.5f && far2 < 8.0e7f && d2 * smin * smin * 0.996f > reach * reach;
+}
+
+// number of (tile, keyframe) workgroups of a k_vote_map_cull launch that survive the whole-tile cull (measurement only: the
+// algorithmic bytes of a launch count the map tiles that are actually read)
+__global__ void __launch_bounds__(kBlock)
+k_count_live_tiles(const float* __restrict__ approx_poses, uint32_t kb, uint32_t nb, const float* __restrict__ tile_bounds, uint32_t n_tiles,
+                   const uint32_t* __restrict__ smax_bits, float thr, unsigned long long* __restrict__ live)
+{
+    const uint32_t tile = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t kfb = blockIdx.y;
+    bool alive = false;
+    if (tile < n_tiles) alive = !tile_out_of_reach(approx_poses + 16 * (size_t)(kb + kfb), tile_bounds + 6 * (size_t)tile, u2f(smax_bits[kfb]), thr);
+    const uint64_t b = __builtin_amdgcn_ballot_w64(alive);
+    if ((threadIdx.x & 63u) == 0u && b) atomicAdd(live, (unsigned long long)__popcll(b));
+}
+hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,
+                            const uint32_t* smax_bits_dev, float thr, unsigned long long* live_dev, hipStream_t s)
+{
+    if (!nb || !n_tiles) return hipSuccess;
+    k_count_live_tiles<<<dim3(grid_for(n_tiles), (unsigned)nb), dim3(kBlock), 0, s>>>(approx_poses_dev, (uint32_t)kb, (uint32_t)nb, tile_bounds_dev,
+                                                                                    (uint32_t)n_tiles, smax_bits_dev, thr, live_dev);
+    return hipGetLastError();
+}
+
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
 template <bool B2L_IDENTITY>
@@ -439,29 +488,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     if (!tk.valid) return;
-    if (tile_bounds) {
-        // Whole-tile range cull: no point of this tile can be nearer to the sensor than the distance from the sensor position
-        // to the tile's bounding box; if that already exceeds the keyframe's longest scan return (minus thr, with margins for a
-        // slightly non-orthonormal pose and float rounding) nothing here can be flagged and the workgroup is done.
-        const float* __restrict__ ap = approx_poses + 16 * (size_t)(kb + tk.kfb);
-        const float* __restrict__ tb = tile_bounds + 6 * (size_t)tk.tile;
-        float d2 = 0.0f, far2 = 0.0f;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-            const float c = ap[9 + d];                            // sensor position to ~1e-5 m: the margins below are 1e-2
-            const float lo = tb[d] - c, hi = c - tb[3 + d];
-            const float e = fmaxf(fmaxf(lo, hi), 0.0f);          // distance to the box along this axis
-            const float f = fmaxf(fabsf(lo), fabsf(hi));          // distance to its farthest face
-            d2 = __builtin_fmaf(e, e, d2);
-            far2 = __builtin_fmaf(f, f, far2);
-        }
-        // exact local range of any point of the tile: |A (p - c)| >= smin * |p - c| >= smin * dist(c, box); ap[15] = lower bound of smin
-        const float smin = ap[15];
-        const float smax = u2f(smax_bits[tk.kfb]);                // longest scan return of this keyframe (0 if none)
-        const float reach = fmaxf(smax - thr, 0.0f) + 1.0e-2f + smax * 1.0e-3f;
-        // far2 guard: beyond ~8.9 km the reference's "empty pixel = 10000" sentinel arithmetic could flag a point; never cull there
-        if (smin > 0.5f && far2 < 8.0e7f && d2 * smin * smin * 0.996f > reach * reach) return;
-    }
+    if (tile_bounds && tile_out_of_reach(approx_poses + 16 * (size_t)(kb + tk.kfb), tile_bounds + 6 * (size_t)tk.tile, u2f(smax_bits[tk.kfb]), thr)) return;
     for (int s = threadIdx.x; s < kCullSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; }
     if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
     __syncthreads();
@@ -595,6 +622,7 @@ void set_tile_cull(int v) { g_tile_cull = v; }
 static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
 void set_vote_cull(int v) { g_vote_cull = v; }
 int vote_cull_enabled() { return g_vote_cull != 0; }
+int tile_cull_enabled() { return g_tile_cull != 0; }
 
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                  HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, const float* tile_bounds_dev,
@@ -614,7 +642,8 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
 // debug: number of points whose exact pixel is NOT inside the candidate set of the bounded-error projection.
 // T (3x4 double) / ap (16 floats) are the exact and the approximate form of the same keyframe transform, or null.
 __global__ void __launch_bounds__(kBlock)
-k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, const float* __restrict__ ap, Geom gg, unsigned long long* __restrict__ bad)
+k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, HostMat34 b2l, int b2l_identity, const float* __restrict__ ap, Geom gg,
+             unsigned long long* __restrict__ bad)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -622,7 +651,11 @@ k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, const float* 
     const float4 p4 = make_float4(xyz[3 * i], xyz[3 * i + 1], xyz[3 * i + 2], 0.0f);
     float3 pe = make_float3(p4.x, p4.y, p4.z), pa = pe;
     bool ok = true;
-    if (ap) { pe = xform(to_dev(T), pe); pa = xform_approx(ap, p4, ok); }
+    if (ap) {   // exact side exactly as the vote kernels do it: inverse pose, float store, then base->lidar (utility.cpp:64-72)
+        pe = xform(to_dev(T), pe);
+        pe = b2l_identity ? xform_identity(pe) : xform(to_dev(b2l), pe);
+        pa = xform_approx(ap, p4, ok);
+    }
     const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
     CullCand cc = cull_candidates(g, pa, row_scale, col_scale);
     if (cc.unusual || !ok) return;
@@ -633,11 +666,13 @@ k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, const float* 
     const bool good = (row == cc.r0 || row == cc.r1) && (col == cc.c0 || col == cc.c1) && (cc.r_lo <= s.r) && (s.r <= cc.r_lo * (1.0f + 3.0e-6f));
     if (!good) atomicAdd(bad, 1ull);
 }
-hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const float* approx_pose_dev, Geom g, unsigned long long* bad_dev, hipStream_t s)
+hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,
+                      Geom g, unsigned long long* bad_dev, hipStream_t s)
 {
     if (!n) return hipSuccess;
     HostMat34 z{};
-    k_cull_check<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(xyz_dev, n, T ? *T : z, T ? approx_pose_dev : nullptr, g, bad_dev);
+    k_cull_check<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(xyz_dev, n, T ? *T : z, b2l ? *b2l : z, b2l ? b2l_identity : 1,
+                                                            T ? approx_pose_dev : nullptr, g, bad_dev);
     return hipGetLastError();
 }
 

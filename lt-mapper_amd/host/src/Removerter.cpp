@@ -349,11 +349,18 @@ void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _
 // the resolution factor whose image shape is `_rimg_shape` (resetRimgSize inverted; the shapes come from it in the first place)
 static float alphaOfShape(float vfov, float hfov, std::pair<int, int> shape)
 {
-    const float alpha = (float)shape.first / vfov;
-    int r = 0, c = 0;
-    ltm_rimg_size(vfov, hfov, alpha, &r, &c);
-    if (r != shape.first || c != shape.second) throw std::runtime_error("range image shape is not a resolution of this field of view");
-    return alpha;
+    // any alpha with round(vfov * alpha) == rows and round(hfov * alpha) == cols reproduces the shape (e.g. the revert resolution
+    // 0.95 * 2.5 gives 119 x 855, which neither rows / vfov = 2.38 nor an integer ratio reproduces): take the middle of the
+    // intersection of the two rounding intervals and verify it with the library's own resetRimgSize
+    const double lo = std::max(((double)shape.first - 0.5) / vfov, ((double)shape.second - 0.5) / hfov);
+    const double hi = std::min(((double)shape.first + 0.5) / vfov, ((double)shape.second + 0.5) / hfov);
+    const float cand[3] = {(float)(0.5 * (lo + hi)), (float)shape.second / hfov, (float)shape.first / vfov};
+    for (float alpha : cand) {
+        int r = 0, c = 0;
+        ltm_rimg_size(vfov, hfov, alpha, &r, &c);
+        if (r == shape.first && c == shape.second) return alpha;
+    }
+    throw std::runtime_error("range image shape is not a resolution of this field of view");
 }
 
 Removerter::RangeImage Removerter::scan2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size)
@@ -542,6 +549,9 @@ void Removerter::run(void)                                                      
     const auto t3 = clk::now();
     auto s = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
     LTM_INFO(" [timing] step0 (load+map) " << s(t0, t1) << " s, steps 1-3 " << s(t1, t2) << " s (includes map PCD writes), scan writes " << s(t2, t3) << " s");
+    // files -> files wall time (SURVEY 8d "T_total"), machine readable
+    std::cout << "[timing] T_total " << s(t0, t3) << " s T_step0 " << s(t0, t1) << " s T_steps123 " << s(t1, t2) << " s T_scan_writes " << s(t2, t3)
+              << " s keyframes " << central_sess_.keyframe_names_.size() << " " << query_sess_.keyframe_names_.size() << std::endl;
 }
 
 } // namespace ltremovert

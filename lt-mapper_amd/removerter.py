@@ -62,7 +62,10 @@ class HipOps:
 
     def new_labels(self, n):
         import torch
-        return torch.zeros(max(n, 1), dtype=torch.uint8, device=f"cuda:{self.ctx.device}")[:n]
+        t = torch.zeros(max(n, 1), dtype=torch.uint8, device=f"cuda:{self.ctx.device}")[:n]
+        # the zero-fill runs on torch's stream, the vote writes the buffer on the context's own (non-blocking) stream: order them
+        torch.cuda.current_stream().synchronize()
+        return t
 
     def vote(self, cmap, scans, poses, kb, ke, alpha, thr, mode, labels):
         if labels.numel():
@@ -185,7 +188,7 @@ class Removerter:
     def selfRemovert(self, sess, repeat=1):             # Removerter.cpp:1378-1393
         for res in self.P.remove_resolution_list:
             res = float(np.float32(res))
-            for _ in range(max(1, repeat)):
+            for _ in range(repeat):                                            # `i < _repeat`, Removerter.cpp:1381: repeat 0 runs nothing
                 self.removeOnce(sess, sess, res)
                 sess.map_global_curr_ = sess.map_global_curr_dynamic_          # resetCurrrentMapAsDynamic :714-737
                 self.revertOnce(sess, sess, float(np.float32(0.95 * res)))     # :1385 double product narrowed to float

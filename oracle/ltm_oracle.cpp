@@ -423,7 +423,7 @@ void self_removert(Ctx& c, Sess& s)
 {
     for (int r = 0; r < c.P.n_res; ++r) {
         const float res = c.P.res_list[r];
-        for (int i = 0; i < std::max(1, c.P.repeat); ++i) {
+        for (int i = 0; i < c.P.repeat; ++i) {              /* `i < _repeat`, :1381 */
             remove_once(c, s, s, res);
             s.map_curr = s.map_dynamic;                     /* resetCurrrentMapAsDynamic :714-737 */
             revert_once(c, s, s, (float)(0.95 * res));      /* :1385 double product narrowed to the float parameter */
@@ -691,6 +691,59 @@ size_t orc_preclean(const float* pts, size_t n, float radius, float* out)
         if ((r < radius) & (p[i].z < 0.5f) & (-0.5f < p[i].z)) continue;
         if (o) o[m] = p[i];
         ++m;
+    }
+    return m;
+}
+
+/* pcl::VoxelGrid<PointXYZI>::applyFilter as the loader uses it (Session.cpp:284-289; PCL 1.10 voxel_grid.hpp, restated from
+ * its published behaviour -- PARITY UNPINNED): inverse leaf size in float; getMinMax3D; the "leaf size is too small" test
+ * (dx*dy*dz > INT32_MAX with d = (int64)((max-min)*inv_leaf) + 1) returns the INPUT unchanged -- the common case for a raw
+ * 0.05 m scan; otherwise min_b / div_b from floor(min*inv), floor(max*inv), leaf index ijk0 + ijk1*div0 + ijk2*div0*div1 with
+ * ijk = (int)(floor(x*inv) - (float)min_b), points grouped by index (std::sort on the index only: the order INSIDE a voxel is
+ * unspecified in the reference; input order here), float sums (CentroidPoint accumulators), divided by the count, output in
+ * ascending leaf index.  min_points_per_voxel = 0, all fields downsampled.  Returns the output count (out may be NULL). */
+size_t orc_voxel_grid(const float* pts, size_t n, float leaf, float* out, size_t cap)
+{
+    const Pt* p = reinterpret_cast<const Pt*>(pts); Pt* o = reinterpret_cast<Pt*>(out);
+    if (n == 0) return 0;
+    const float inv = 1.0f / leaf;
+    float mn[3] = {FLT_MAX, FLT_MAX, FLT_MAX}, mx[3] = {-FLT_MAX, -FLT_MAX, -FLT_MAX};
+    for (size_t i = 0; i < n; ++i) {
+        const float c[3] = {p[i].x, p[i].y, p[i].z};
+        for (int d = 0; d < 3; ++d) { if (c[d] < mn[d]) mn[d] = c[d]; if (c[d] > mx[d]) mx[d] = c[d]; }
+    }
+    int64_t dd[3];
+    for (int d = 0; d < 3; ++d) dd[d] = (int64_t)((mx[d] - mn[d]) * inv) + 1;
+    if (dd[0] * dd[1] * dd[2] > (int64_t)INT32_MAX) {
+        for (size_t i = 0; i < n && i < cap && o; ++i) o[i] = p[i];
+        return n;
+    }
+    int min_b[3], div_b[3];
+    for (int d = 0; d < 3; ++d) {
+        min_b[d] = (int)std::floor(mn[d] * inv);
+        div_b[d] = (int)std::floor(mx[d] * inv) - min_b[d] + 1;
+    }
+    std::vector<std::pair<unsigned, unsigned>> iv(n);
+    for (size_t i = 0; i < n; ++i) {
+        const int i0 = (int)(std::floor(p[i].x * inv) - (float)min_b[0]);
+        const int i1 = (int)(std::floor(p[i].y * inv) - (float)min_b[1]);
+        const int i2 = (int)(std::floor(p[i].z * inv) - (float)min_b[2]);
+        iv[i] = {(unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]), (unsigned)i};
+    }
+    std::stable_sort(iv.begin(), iv.end(), [](const std::pair<unsigned, unsigned>& a, const std::pair<unsigned, unsigned>& b) { return a.first < b.first; });
+    size_t m = 0;
+    for (size_t a = 0; a < n;) {
+        size_t b = a;
+        float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+        while (b < n && iv[b].first == iv[a].first) {
+            const Pt& q = p[iv[b].second];
+            sx = sx + q.x; sy = sy + q.y; sz = sz + q.z; si = si + q.i;
+            ++b;
+        }
+        const float cnt = (float)(b - a);
+        if (o && m < cap) o[m] = Pt{sx / cnt, sy / cnt, sz / cnt, si / cnt};
+        ++m;
+        a = b;
     }
     return m;
 }

@@ -81,6 +81,9 @@ void orc_merge_to_global(const float* scans, const uint64_t* offsets, size_t n_k
 /* ---- pre-clean (Session.cpp:506-533) ---- returns kept count, in-order compaction into out */
 size_t orc_preclean(const float* pts, size_t n, float radius, float* out);
 
+/* ---- loader-side pcl::VoxelGrid (Session.cpp:284-289) ---- returns output count; out may be NULL to count */
+size_t orc_voxel_grid(const float* pts, size_t n, float leaf, float* out, size_t cap);
+
 /* ---- full pipeline: Removerter::run() Steps 1-3 (Removerter.cpp:1653-1678) on in-memory sessions ---- */
 /* ---- RViz images (utility.h:114-127 convertColorMappedImg, utility.cpp:248-256 pubRangeImg, Removerter.cpp:580-585) ----
  * dst8 = saturate_u8(round_half_even(src*a + b)), a = 255*(1/(max-min)), b = -255*min*(1/(max-min)) as cv::MatExpr folds

@@ -39,6 +39,7 @@ def lib():
         L.orc_voxel_centroid.restype = _sz
         L.orc_reproject.restype = _sz
         L.orc_preclean.restype = _sz
+        L.orc_voxel_grid.restype = _sz
         L.orc_pipeline_run.restype = _vp
         L.orc_inverse4x4.restype = _i
         _lib = L
@@ -186,6 +187,13 @@ def merge_to_global(scans, offsets, poses, l2b):
 def preclean(pts, radius):
     a = _pts(pts); out = np.empty_like(a)
     n = lib().orc_preclean(_p(a), _sz(a.shape[0]), _f(radius), _p(out))
+    return out[:n].copy()
+
+
+def voxel_grid(pts, leaf):
+    """pcl::VoxelGrid as the session loader applies it to every scan (Session.cpp:284-289)"""
+    a = _pts(pts); out = np.empty_like(a)
+    n = lib().orc_voxel_grid(_p(a), _sz(a.shape[0]), _f(leaf), _p(out), _sz(out.shape[0]))
     return out[:n].copy()
 
 

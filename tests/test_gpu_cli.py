@@ -11,66 +11,7 @@ from conftest import ROOT, assert_clouds_equal
 
 pytestmark = pytest.mark.gpu
 
-HDR = ("# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
-       "WIDTH {w}\nHEIGHT {h}\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS {n}\nDATA binary\n")
-
-
-def write_pcd(path, pts, ascii_=False):
-    n = len(pts)
-    with open(path, "wb") as f:
-        if ascii_:
-            f.write(HDR.format(w=n, h=1, n=n).replace("DATA binary", "DATA ascii").encode())
-            for p in pts:
-                f.write((" ".join(repr(float(v)) for v in p) + "\n").encode())
-        else:
-            f.write(HDR.format(w=n, h=1, n=n).encode())
-            f.write(np.ascontiguousarray(pts, dtype=np.float32).tobytes())
-
-
-def read_pcd(path):
-    raw = open(path, "rb").read()
-    i = raw.index(b"DATA binary\n") + len(b"DATA binary\n")
-    hdr = raw[:i].decode()
-    n = int([l for l in hdr.splitlines() if l.startswith("POINTS")][0].split()[1])
-    return hdr, np.frombuffer(raw[i:], dtype=np.float32).reshape(n, 4)
-
-
-def voxel_grid(pts, leaf):
-    """pcl::VoxelGrid as restated in host/src/utility.cpp (float arithmetic, input-order sums, int32 overflow early-out)"""
-    pts = np.asarray(pts, np.float32)
-    inv = np.float32(1.0) / np.float32(leaf)
-    mn, mx = pts[:, :3].min(0), pts[:, :3].max(0)
-    d = ((mx - mn) * inv).astype(np.int64) + 1
-    if int(d[0]) * int(d[1]) * int(d[2]) > 2 ** 31 - 1:
-        return pts
-    minb = np.floor(mn * inv).astype(np.int64)
-    divb = np.floor(mx * inv).astype(np.int64) - minb + 1
-    ijk = np.floor(pts[:, :3] * inv).astype(np.int64) - minb
-    key = ijk[:, 0] + ijk[:, 1] * divb[0] + ijk[:, 2] * divb[0] * divb[1]
-    order = np.argsort(key, kind="stable")
-    out = []
-    a = 0
-    ks = key[order]
-    while a < len(order):
-        b = a
-        s = np.zeros(4, np.float32)
-        while b < len(order) and ks[b] == ks[a]:
-            s = (s + pts[order[b]]).astype(np.float32)
-            b += 1
-        out.append(s / np.float32(b - a))
-        a = b
-    return np.array(out, np.float32)
-
-
-def parse_keyframes(n, start, end):       # Session.cpp:138-173 incl. the double increment (quirk Q6), gap 1
-    out, i = [], 0
-    while i < n:
-        if i > end or i < start:
-            i += 2
-            continue
-        out.append(i)
-        i += 1
-    return out
+from fileproto import HDR, parse_keyframes, read_pcd, write_pcd   # noqa: E402
 
 
 def test_ltm_run_file_protocol(tmp_path, orc):
@@ -137,7 +78,7 @@ def test_ltm_run_file_protocol(tmp_path, orc):
             raw = S["scans"][a:b]
             if k == 3:   # went through the ascii writer: repr() round-trips float32 exactly
                 raw = np.array([[np.float32(float(repr(float(v)))) for v in p] for p in raw], np.float32)
-            p = orc.preclean(voxel_grid(raw, 0.05), 2.5)
+            p = orc.preclean(orc.voxel_grid(raw, 0.05), 2.5)   # pcl::VoxelGrid of the loader: oracle restatement (A.6)
             pts.append(p); off.append(off[-1] + len(p))
         poses = S["poses"].reshape(-1, 16)[kfs].copy()
         # the pose file holds 12 numbers per line; the inverse is whatever the host computes (Gauss-Jordan here, Eigen in the reference)
@@ -221,7 +162,7 @@ def test_ltm_run_file_protocol(tmp_path, orc):
     upd = [read_pcd(str(outdir / "scans_updated" / sess[0]["names"][k]))[1] for k in c_kf]
     pts2, off2 = [], [0]
     for p in upd:
-        q = orc.preclean(voxel_grid(p, 0.05), 2.5)
+        q = orc.preclean(orc.voxel_grid(p, 0.05), 2.5)
         pts2.append(q); off2.append(off2[-1] + len(q))
     poses2 = sess[0]["poses"].reshape(-1, 16)[c_kf].copy()
     C2 = dict(scans=np.concatenate(pts2), offsets=np.array(off2, np.uint64), poses=poses2,

@@ -396,6 +396,73 @@ def test_cull_projection_bounds_hold(gpu_ctx):
             assert gpu_ctx.cull_check(glob.astype(np.float32), 2.5, Tinv) == 0
 
 
+def test_cull_projection_bounds_hold_with_an_extrinsic(ltm):
+    """same bound with a non-identity LiDAR->base extrinsic: the exact side is the reference's two-step transform
+    (inverse pose, float store, base->lidar), the approximate side composes both in double"""
+    rng = np.random.default_rng(33)
+    l2b = _random_pose(rng)
+    l2b[:3, 3] = [0.8, -0.3, 1.7]
+    ctx = ltm.Context(vfov=VFOV, hfov=HFOV, lidar2base=l2b, device=0)
+    n = 1_000_000
+    local = [rng.normal(0, 30, (n, 3)), rng.normal(0, 0.7, (n, 3)), rng.normal(0, 30, (n, 3)) * np.array([1.0, 1.0, 0.02])]
+    k = np.arange(n) % 900
+    az = np.deg2rad((k + 0.5) / 2.5 - 180.0 + rng.normal(0, 2e-5, n))
+    el = np.deg2rad(25.0 - (np.arange(n) % 125 + 0.5) / 2.5 + rng.normal(0, 2e-5, n))
+    r = rng.uniform(0.5, 120, n)
+    local.append(np.stack([r * np.cos(el) * np.cos(az), r * np.cos(el) * np.sin(az), r * np.sin(el)], 1))
+    for trial in range(4):
+        T = _random_pose(rng)
+        T[:3, 3] *= (1, 1, 0.05) if trial % 2 else (30, 30, 1)
+        Tinv = np.linalg.inv(T)
+        for pts in local:
+            base = (l2b[:3, :3] @ pts.T).T + l2b[:3, 3]
+            glob = (T[:3, :3] @ base.T).T + T[:3, 3]
+            assert ctx.cull_check(glob.astype(np.float32), 2.5, Tinv) == 0
+    ctx.close()
+
+
+def test_vote_sentinel_arithmetic_beyond_9800_m(gpu_ctx, orc):
+    """Removerter.cpp:398-404 with kFlagNoPOINT = 10000 (utility.h:93): diff = scan - map with an EMPTY scan pixel is 10000 - r,
+    which lies in (0.1, 200) for a map point 9800..9999.9 m away -- the reference flags it.  Points at 9850 m / 9999 m / 10050 m on
+    empty and on occupied scan pixels, plus a far scan return (9040 m) in front of a map point at 8850 m (diff 190: flagged) and one
+    at 8830 m (diff 210: not), through the range-culled kernel, the tile cull and both modes."""
+    rng = np.random.default_rng(41)
+    # scan of one keyframe at the origin: a ring of returns at 20 m in the sector az in [0, 90) deg, everything else empty,
+    # plus single far returns
+    az = np.deg2rad(np.arange(0, 90, 0.2)); el = np.deg2rad(np.arange(-20, 21, 1.0))
+    A, E = np.meshgrid(az, el)
+    ring = np.stack([20 * np.cos(E) * np.cos(A), 20 * np.cos(E) * np.sin(A), 20 * np.sin(E)], -1).reshape(-1, 3)
+    def at(r, az_deg, el_deg=0.0):
+        a, e = np.deg2rad(az_deg), np.deg2rad(el_deg)
+        return [r * np.cos(e) * np.cos(a), r * np.cos(e) * np.sin(a), r * np.sin(e)]
+    far_scan = np.array([at(9040.0, 200.0), at(9040.0, 210.0), at(9900.0, 220.0)])
+    scan = np.concatenate([ring, far_scan]).astype(np.float32)
+    scan = np.concatenate([scan, np.zeros((len(scan), 1), np.float32)], 1)
+    # map: a filler so that tiles exist, then the probes
+    probes = [at(9850.0, 150.0), at(9999.0, 160.0), at(10050.0, 170.0),            # empty scan pixels
+              at(9850.0, 30.0), at(9999.0, 40.0), at(10050.0, 50.0),               # occupied (20 m) scan pixels: diff << 0
+              at(9799.0, 180.0), at(9801.0, 185.0), at(9999.95, 190.0),            # around the interval ends
+              at(8850.0, 200.0), at(8830.0, 210.0), at(9850.0, 220.0),             # behind far scan returns: 190 (flag), 210 (no), 50 (flag)
+              at(19.0, 10.0), at(25.0, 20.0)]                                      # ordinary: flagged (diff 1), occluded
+    fr, fa = rng.uniform(3, 80, 20000), np.deg2rad(rng.uniform(-100, 100, 20000))  # filler away from the probes' azimuths (150..220 deg)
+    filler = np.stack([fr * np.cos(fa), fr * np.sin(fa), rng.normal(0, 2, 20000)], 1)
+    far_cluster = np.array(at(9850.0, 140.0)) + rng.normal(0, 3.0, (6000, 3))      # a whole tile out there, on empty scan pixels
+    m = np.concatenate([filler, np.array(probes), far_cluster]).astype(np.float32)
+    cmap = np.concatenate([m, np.zeros((len(m), 1), np.float32)], 1)
+    off = np.array([0, len(scan)], dtype=np.uint64)
+    pose = np.eye(4).reshape(1, 16)
+    g_map, g_scans, g_poses = gpu_ctx.upload(cmap), gpu_ctx.upload_scans(scan, off), gpu_ctx.poses(pose, pose)
+    for mode in (0, 1):
+        for alpha in (2.5, 1.5):
+            want = orc.vote_labels(cmap, scan, off, pose, I4, VFOV, HFOV, alpha, 0.1, mode)
+            got = gpu_ctx.visibility_partition(g_map, g_scans, g_poses, alpha, 0.1, mode, want_labels=True)[2]
+            assert (got == want).all(), f"mode {mode} alpha {alpha}: labels differ at {np.nonzero(got != want)[0][:10]}"
+            if mode == 0:
+                p0 = len(filler)
+                assert want[p0 + 0] == 1 and want[p0 + 1] == 1 and want[p0 + 2] == 0, "the oracle must show the sentinel effect"
+                assert want[p0 + 9] == 1 and want[p0 + 10] == 0
+
+
 def test_tile_range_cull_on_a_long_street(gpu_ctx, orc):
     """a 300 m drive: most map tiles are out of reach of any single keyframe and are culled as a whole -- labels must not change"""
     from tools import synth

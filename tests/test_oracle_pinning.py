@@ -1,0 +1,299 @@
+"""Pins the CPU oracle from a second, independent direction.
+
+The reference ships no golden vectors and cannot be built here, so oracle/ltm_oracle.cpp *is* the contract; these tests
+shrink what rests on one restatement by re-deriving its third-party pieces differently:
+
+  * pcl::octree::OctreePointCloudVoxelCentroid  -- the oracle sorts Morton keys; here a LITERAL pointer octree: per-point
+    insert through depth-mask child indices (x<<2 | y<<1 | z), leaf containers summing in float in insertion order,
+    depth-first child order 0..7 for getVoxelCentroids
+  * pcl::KdTreeFLANN::nearestKSearch           -- scipy.spatial.cKDTree (exact k-NN), margins excluded
+  * Eigen Matrix4d::inverse()                  -- numpy.linalg.inv to 1e-12
+  * pcl::VoxelGrid                             -- an independent numpy restatement
+  * hypothesis property tests of SURVEY section 4: keyframe-order permutation, the +-180 deg seam, all points in one pixel,
+    duplicated points, empty clouds
+
+CPU only; none of this touches the product.
+"""
+import math
+
+import numpy as np
+import pytest
+from hypothesis import HealthCheck, given, settings
+from hypothesis import strategies as st
+
+FLT_EPS = float(np.finfo(np.float32).eps)
+I4 = np.eye(4)
+
+
+# ----------------------------------------------------------------------------------------------- literal pointer octree
+class _Branch:
+    __slots__ = ("child",)
+
+    def __init__(self):
+        self.child = [None] * 8
+
+
+class _Leaf:
+    __slots__ = ("sum", "n")
+
+    def __init__(self):
+        self.sum = np.zeros(4, np.float32)
+        self.n = 0
+
+
+def literal_octree_centroids(pts, leaf):
+    """utility.cpp:204-219 through a literal pcl::octree: setInputCloud, defineBoundingBox(), addPointsFromInputCloud(),
+    getVoxelCentroids() (PCL 1.10 octree_pointcloud.hpp / octree_pointcloud_voxelcentroid.hpp semantics)"""
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 4)
+    if len(pts) == 0:
+        return pts.copy()
+    res = float(np.float32(leaf))
+    mn = pts[:, :3].min(0)
+    mx = pts[:, :3].max(0)
+    lo = [float(v) for v in mn]
+    hi = [float(np.float32(v + np.float32(FLT_EPS * 512.0))) for v in mx]        # max_pt.x + minValue evaluated in float
+    # getKeyBitSize()
+    max_key = [int(math.ceil((hi[d] - lo[d] - FLT_EPS) / res)) for d in range(3)]
+    max_voxels = max(max(max_key), 2)
+    depth = max(min(32, int(math.ceil(math.log2(max_voxels) - FLT_EPS))), 0)
+    side = float(1 << depth) * res
+    for d in range(3):                                   # empty tree: the box is centred
+        over = (side - (hi[d] - lo[d])) / 2.0
+        if over > FLT_EPS:
+            lo[d] -= over
+            hi[d] += over
+    root = _Branch()
+    for p in pts:                                        # addPointIdx: genOctreeKeyforPoint + createLeafRecursive
+        assert all(lo[d] <= float(p[d]) <= hi[d] for d in range(3)), "adoptBoundingBoxToPoint would have to grow the box"
+        key = [int((float(p[d]) - lo[d]) / res) for d in range(3)]
+        node = root
+        mask = 1 << (depth - 1)
+        while True:
+            ci = ((1 if key[0] & mask else 0) << 2) | ((1 if key[1] & mask else 0) << 1) | (1 if key[2] & mask else 0)
+            if mask == 1:
+                if node.child[ci] is None:
+                    node.child[ci] = _Leaf()
+                lf = node.child[ci]
+                lf.sum = (lf.sum + p).astype(np.float32)      # point_sum_ += new_point (float fields)
+                lf.n += 1
+                break
+            if node.child[ci] is None:
+                node.child[ci] = _Branch()
+            node = node.child[ci]
+            mask >>= 1
+    out = []
+
+    def walk(node):                                      # getVoxelCentroidsRecursive: children 0..7 in order
+        for c in node.child:
+            if c is None:
+                continue
+            if isinstance(c, _Leaf):
+                out.append(c.sum / np.float32(c.n))
+            else:
+                walk(c)
+
+    walk(root)
+    return np.array(out, np.float32).reshape(-1, 4)
+
+
+@pytest.mark.parametrize("seed,n,leaf,scale", [(1, 4000, 0.05, 1.5), (2, 6000, 0.4, 20.0), (3, 3000, 1.0, 60.0), (4, 500, 0.05, 0.2), (5, 2, 0.05, 1.0),
+                                               (6, 1, 0.05, 1.0)])
+def test_voxel_centroid_equals_literal_pointer_octree(orc, seed, n, leaf, scale):
+    rng = np.random.default_rng(seed)
+    pts = np.concatenate([rng.normal(0, scale, (n, 3)), rng.uniform(0, 255, (n, 1))], 1).astype(np.float32)
+    pts[: n // 4, :3] = np.round(pts[: n // 4, :3] / leaf) * leaf        # points exactly on lattice-looking coordinates
+    pts[n // 2: n // 2 + n // 8] = pts[: n // 8]                          # duplicates
+    want = literal_octree_centroids(pts, leaf)
+    got = orc.voxel_centroid(pts, leaf)
+    assert got.shape == want.shape, f"{got.shape[0]} voxels vs {want.shape[0]} from the literal octree"
+    assert (got.view(np.uint32) == want.view(np.uint32)).all(), "centroid values / order differ from the literal octree"
+
+
+def test_voxel_centroid_of_a_revoxelised_map_equals_literal_octree(orc):
+    """the path's actual use: a 0.05 m map re-voxelised after points were removed (the lattice moves with the bounding box)"""
+    from tools import synth
+    S = synth.to_numpy(synth.make_session(1, 3, "tiny"))
+    m = orc.voxel_centroid(orc.merge_to_global(S["scans"], S["offsets"], S["poses"], I4), 0.05)
+    keep = m[np.random.default_rng(7).uniform(size=len(m)) > 0.1]
+    want = literal_octree_centroids(keep, 0.05)
+    got = orc.voxel_centroid(keep, 0.05)
+    assert got.shape == want.shape and (got.view(np.uint32) == want.view(np.uint32)).all()
+
+
+# ----------------------------------------------------------------------------------------------- exact k-NN vs cKDTree
+@pytest.mark.parametrize("k,thr", [(1, 0.01), (2, 0.01), (3, 0.1), (2, 1.0), (4, 0.04)])
+def test_knn_split_equals_ckdtree(orc, k, thr):
+    from scipy.spatial import cKDTree
+    rng = np.random.default_rng(100 + k)
+    tgt = np.concatenate([rng.uniform(-5, 5, (20000, 3)), np.zeros((20000, 1))], 1).astype(np.float32)
+    qry = np.concatenate([rng.uniform(-5.5, 5.5, (15000, 3)), np.zeros((15000, 1))], 1).astype(np.float32)
+    qry[:2000, :3] = tgt[:2000, :3] + rng.normal(0, 0.03, (2000, 3)).astype(np.float32)     # queries near targets: both labels occur
+    near = orc.knn_split(tgt, qry, k, thr).astype(bool)
+    d, _ = cKDTree(tgt[:, :3].astype(np.float64)).query(qry[:, :3].astype(np.float64), k=k)
+    d = d.reshape(len(qry), -1)
+    mean_sq = (d ** 2).sum(1) / k
+    rel = np.abs(mean_sq - thr) / thr
+    decided = rel > 1e-4                 # float32 L2_Simple vs float64 distances: skip queries within 1e-4 of the threshold
+    assert decided.mean() > 0.99
+    assert ((mean_sq < thr)[decided] == near[decided]).all()
+    assert near.any() and (~near).any()
+
+
+def test_knn_labels_equal_ckdtree_on_session_data(orc):
+    from scipy.spatial import cKDTree
+    from tools import synth
+    C = synth.to_numpy(synth.make_session(1, 4, "tiny"))
+    Q = synth.to_numpy(synth.make_session(2, 4, "tiny"))
+    tgt = orc.voxel_centroid(orc.merge_to_global(Q["scans"], Q["offsets"], Q["poses"], I4), 0.05)
+    co, _ = orc.knn_labels(tgt, C["scans"], C["offsets"], C["poses"], C["inv"], I4, 2, 0.01)
+    glob = orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4)
+    d, _ = cKDTree(tgt[:, :3].astype(np.float64)).query(glob[:, :3].astype(np.float64), k=2)
+    mean_sq = (d ** 2).sum(1) / 2
+    decided = np.abs(mean_sq - 0.01) / 0.01 > 1e-3
+    assert ((mean_sq < 0.01)[decided] == (co == 1)[decided]).all()
+
+
+# ----------------------------------------------------------------------------------------------- 4x4 inverse
+def test_inverse4x4_equals_numpy(orc):
+    rng = np.random.default_rng(5)
+    for trial in range(200):
+        yaw, pitch, roll = rng.uniform(-np.pi, np.pi), rng.uniform(-0.5, 0.5), rng.uniform(-0.5, 0.5)
+        cz, sz, cy, sy, cx, sx = np.cos(yaw), np.sin(yaw), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        R = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        T = np.eye(4)
+        T[:3, :3] = R
+        T[:3, 3] = rng.uniform(-500, 500, 3)
+        if trial % 3 == 0:                    # poses parsed from 6-significant-digit text are only approximately rigid
+            T[:3, :] = np.array([[float(f"{v:.6g}") for v in row] for row in T[:3, :]])
+        got = orc.inverse4x4(T)
+        want = np.linalg.inv(T)
+        assert np.abs(got - want).max() <= 1e-12 * max(1.0, np.abs(want).max())
+    M = rng.normal(0, 1, (4, 4))              # a general (non-rigid) matrix as well: Eigen's inverse() is general
+    assert np.abs(orc.inverse4x4(M) - np.linalg.inv(M)).max() <= 1e-10
+
+
+# ----------------------------------------------------------------------------------------------- pcl::VoxelGrid
+def numpy_voxel_grid(pts, leaf):
+    pts = np.asarray(pts, np.float32)
+    inv = np.float32(1.0) / np.float32(leaf)
+    mn, mx = pts[:, :3].min(0), pts[:, :3].max(0)
+    d = ((mx - mn) * inv).astype(np.int64) + 1
+    if int(d[0]) * int(d[1]) * int(d[2]) > 2 ** 31 - 1:
+        return pts
+    minb = np.floor(mn * inv).astype(np.int64)
+    divb = np.floor(mx * inv).astype(np.int64) - minb + 1
+    ijk = np.floor(pts[:, :3] * inv).astype(np.int64) - minb
+    key = ijk[:, 0] + ijk[:, 1] * divb[0] + ijk[:, 2] * divb[0] * divb[1]
+    order = np.argsort(key, kind="stable")
+    ks = key[order]
+    starts = np.flatnonzero(np.concatenate([[True], ks[1:] != ks[:-1]]))
+    ends = np.concatenate([starts[1:], [len(ks)]])
+    out = np.empty((len(starts), 4), np.float32)
+    for j, (a, b) in enumerate(zip(starts, ends)):
+        s = np.zeros(4, np.float32)
+        for i in order[a:b]:
+            s = (s + pts[i]).astype(np.float32)
+        out[j] = s / np.float32(b - a)
+    return out
+
+
+def test_voxel_grid_equals_numpy_restatement_and_early_out(orc):
+    rng = np.random.default_rng(9)
+    dense = np.concatenate([rng.uniform(-3, 3, (20000, 3)), rng.uniform(0, 255, (20000, 1))], 1).astype(np.float32)
+    for leaf in (0.05, 0.2, 0.5):
+        got, want = orc.voxel_grid(dense, leaf), numpy_voxel_grid(dense, leaf)
+        assert got.shape == want.shape and (got.view(np.uint32) == want.view(np.uint32)).all()
+        assert len(got) < len(dense)
+    wide = dense.copy()
+    wide[:, :2] *= 40.0                      # 240 x 240 x 6 m at 0.05 m: 4800 * 4800 * 121 cells > INT32_MAX -> output = input
+    got = orc.voxel_grid(wide, 0.05)
+    assert got.shape == wide.shape and (got.view(np.uint32) == wide.view(np.uint32)).all()
+    assert len(orc.voxel_grid(np.zeros((0, 4), np.float32), 0.05)) == 0
+
+
+# ----------------------------------------------------------------------------------------------- property tests
+def _session_arrays(scans):
+    off = np.cumsum([0] + [len(s) for s in scans]).astype(np.uint64)
+    return np.concatenate(scans).astype(np.float32), off
+
+
+@settings(max_examples=25, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 2 ** 31 - 1), n_kf=st.integers(1, 5), mode=st.integers(0, 1))
+def test_vote_union_is_invariant_to_keyframe_order(orc, seed, n_kf, mode):
+    rng = np.random.default_rng(seed)
+    cmap = np.concatenate([rng.normal(0, 15, (3000, 3)), np.zeros((3000, 1))], 1).astype(np.float32)
+    cmap[:, 2] = rng.normal(0, 1.5, 3000)
+    scans, poses = [], []
+    for _ in range(n_kf):
+        T = np.eye(4)
+        a = rng.uniform(-np.pi, np.pi)
+        T[:2, :2] = [[np.cos(a), -np.sin(a)], [np.sin(a), np.cos(a)]]
+        T[:3, 3] = rng.uniform(-5, 5, 3) * [1, 1, 0.1]
+        poses.append(T)
+        m = int(rng.integers(0, 800))
+        s = np.concatenate([rng.normal(0, 15, (m, 3)) * [1, 1, 0.1], np.zeros((m, 1))], 1).astype(np.float32)
+        scans.append(s)
+    inv = np.array([np.linalg.inv(T).reshape(16) for T in poses])
+    pts, off = _session_arrays(scans)
+    base = orc.vote_labels(cmap, pts, off, inv, I4, 50.0, 360.0, 2.5, 0.1, mode)
+    perm = rng.permutation(n_kf)
+    pts2, off2 = _session_arrays([scans[i] for i in perm])
+    again = orc.vote_labels(cmap, pts2, off2, inv[perm], I4, 50.0, 360.0, 2.5, 0.1, mode)
+    assert (base == again).all()                       # std::set union (Removerter.cpp:589-590) has no order
+    threaded = orc.vote_labels(cmap, pts, off, inv, I4, 50.0, 360.0, 2.5, 0.1, mode, threads=3)
+    assert (base == threaded).all()
+
+
+@settings(max_examples=60, deadline=None)
+@given(r=st.floats(0.5, 150.0), z=st.floats(-30.0, 30.0), tiny=st.floats(0.0, 1e-3), neg=st.booleans())
+def test_seam_points_land_on_the_edge_columns(orc, r, z, tiny, neg):
+    """utility.cpp:122-123 at az = +-180 deg: (-r, +0) rounds to column C and clamps to C-1; (-r, -0) lands in column 0"""
+    R, C = orc.rimg_size(50.0, 360.0, 2.5)
+    y = -tiny if neg else tiny
+    rc, _ = orc.pixel(np.array([[-r, y, z]], np.float32), 50.0, 360.0, R, C)
+    y32 = np.float32(y)
+    if y32 == 0 and not np.signbit(y32):
+        assert rc[0, 1] == C - 1
+    elif y32 == 0:
+        assert rc[0, 1] == 0
+    else:
+        assert rc[0, 1] in ((0, 1) if neg else (C - 1, C - 2))
+    assert 0 <= rc[0, 0] <= R - 1
+
+
+@settings(max_examples=30, deadline=None)
+@given(seed=st.integers(0, 2 ** 31 - 1), n=st.integers(1, 400))
+def test_all_points_in_one_pixel_keep_the_nearest_lowest_index(orc, seed, n):
+    """utility.cpp:134-138: strict `<` in serial order => the nearest point wins, the lowest index among equal ranges"""
+    rng = np.random.default_rng(seed)
+    R, C = orc.rimg_size(50.0, 360.0, 2.5)
+    d = np.array([np.cos(0.3), np.sin(0.3), 0.05], np.float64)
+    rr = rng.choice(np.array([5.0, 7.5, 7.5, 9.0, 12.0]), size=n)
+    pts = np.concatenate([(d[None, :] * rr[:, None]), np.zeros((n, 1))], 1).astype(np.float32)
+    rimg, idx = orc.range_image(pts, 50.0, 360.0, R, C)
+    rc, rng_f = orc.pixel(pts[:, :3], 50.0, 360.0, R, C)
+    assert len({(int(a), int(b)) for a, b in rc}) == 1, "test premise: one pixel"
+    best = int(np.flatnonzero(rng_f == rng_f.min())[0])
+    assert idx[rc[0, 0], rc[0, 1]] == best and rimg[rc[0, 0], rc[0, 1]] == rng_f[best]
+    assert (idx != 0).sum() <= 1 and (rimg < 10000.0).sum() == 1
+
+
+@settings(max_examples=20, deadline=None, suppress_health_check=[HealthCheck.too_slow])
+@given(seed=st.integers(0, 2 ** 31 - 1))
+def test_duplicated_points_do_not_change_labels_or_voxels(orc, seed):
+    rng = np.random.default_rng(seed)
+    cmap = np.concatenate([rng.normal(0, 10, (1500, 3)) * [1, 1, 0.1], np.zeros((1500, 1))], 1).astype(np.float32)
+    scan = np.concatenate([rng.normal(0, 10, (600, 3)) * [1, 1, 0.1], np.zeros((600, 1))], 1).astype(np.float32)
+    off = np.array([0, len(scan)], np.uint64)
+    pose = np.eye(4).reshape(1, 16)
+    base = orc.vote_labels(cmap, scan, off, pose, I4, 50.0, 360.0, 2.5, 0.1, 0)
+    dup = np.concatenate([cmap, cmap])                    # every point twice: the copy (higher index) never wins a tie
+    both = orc.vote_labels(dup, scan, off, pose, I4, 50.0, 360.0, 2.5, 0.1, 0)
+    assert (both[: len(cmap)] == base).all() and both[len(cmap):].sum() == 0
+    # an empty scan flags nothing (scan image all 10000: diff > 200); an empty map yields no labels
+    none = orc.vote_labels(cmap, scan[:0], np.array([0, 0], np.uint64), pose, I4, 50.0, 360.0, 2.5, 0.1, 0)
+    assert none.sum() == 0
+    assert len(orc.vote_labels(cmap[:0], scan, off, pose, I4, 50.0, 360.0, 2.5, 0.1, 0)) == 0
+    v1, v2 = orc.voxel_centroid(cmap, 0.4), orc.voxel_centroid(dup, 0.4)
+    assert len(v1) == len(v2)                             # same occupied voxels (centroids differ only by float summation order)
+    assert np.abs(v1[:, :3] - v2[:, :3]).max() < 1e-4
