@@ -307,7 +307,9 @@ def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel
 
     ncores = os.cpu_count() or 1
     one = leg(1, args.cpu_stride)
-    allc = leg(ncores, args.cpu_stride_allcore) if ncores > 1 else None
+    # the oracle parallelises over keyframes: the visited keyframes must outnumber the threads several times or the scaled stage
+    # times overestimate (50 keyframes on 256 threads take one round, 500 take two, not ten) -- with many cores run every keyframe
+    allc = leg(ncores, max(1, min(args.cpu_stride_allcore, n_kf // (4 * ncores)))) if ncores > 1 else None
     full = {}
     for tag in ("1thread", "allcore"):
         try:

@@ -99,7 +99,7 @@ struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = n
 struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0; };
 // scan2RangeImg depends only on (scan set, image shape, keyframe range): the remove / revert / remove passes of one
 // resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
-struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; };
+struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; float* qbound; float q_thr; };
 struct Pending { int cls; hipEvent_t a, b; };
 
 } // namespace
@@ -373,17 +373,29 @@ size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, siz
 void scan_cache_drop(ltm_ctx* c, uint64_t ss_handle)
 {
     for (size_t i = 0; i < c->scan_cache.size();) {
-        if (ss_handle == 0 || c->scan_cache[i].ss == ss_handle) { c->pool.free(c->scan_cache[i].buf); c->pool.free(c->scan_cache[i].smax); c->scan_cache.erase(c->scan_cache.begin() + i); }
+        if (ss_handle == 0 || c->scan_cache[i].ss == ss_handle) { c->pool.free(c->scan_cache[i].buf); c->pool.free(c->scan_cache[i].smax); c->pool.free(c->scan_cache[i].qbound); c->scan_cache.erase(c->scan_cache.begin() + i); }
         else ++i;
     }
 }
 
 // returns the finished scan range images of keyframes [kb, kb+nb) (cached or freshly computed and then cached)
-const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size_t kb, size_t nb, const Geom& g, const uint32_t** smax_out)
+// qbound_thr >= 0 also returns (in *qbound_out) the squared-range bound image of the range-culled vote kernel for that threshold
+const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size_t kb, size_t nb, const Geom& g, const uint32_t** smax_out,
+                            float qbound_thr = -1.0f, const float** qbound_out = nullptr)
 {
     const size_t npx = (size_t)g.rows * g.cols;
+    auto with_qbound = [&](ScanImgEntry& e) {
+        if (qbound_thr < 0.0f || !qbound_out) return;
+        if (!e.qbound || e.q_thr != qbound_thr) {
+            if (!e.qbound) { e.qbound = reinterpret_cast<float*>(c->pool.alloc(nb * npx * sizeof(float))); e.bytes += nb * npx * sizeof(float); }
+            ProfScope p(c, "vote_scan", 0.0, (double)(nb * npx) * 8);
+            LTM_HIP(scan_qbound(e.buf, nb * npx, qbound_thr, e.qbound, c->stream));
+            e.q_thr = qbound_thr;
+        }
+        *qbound_out = e.qbound;
+    };
     for (ScanImgEntry& e : c->scan_cache)
-        if (e.ss == ss_handle && e.rows == g.rows && e.cols == g.cols && e.kb == kb && e.nb == nb) { e.stamp = ++c->scan_cache_stamp; *smax_out = e.smax; return e.buf; }
+        if (e.ss == ss_handle && e.rows == g.rows && e.cols == g.cols && e.kb == kb && e.nb == nb) { e.stamp = ++c->scan_cache_stamp; *smax_out = e.smax; with_qbound(e); return e.buf; }
     const size_t bytes = nb * npx * sizeof(uint32_t);
     size_t held = 0;
     for (const ScanImgEntry& e : c->scan_cache) held += e.bytes;
@@ -393,6 +405,7 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
         held -= c->scan_cache[lru].bytes;
         c->pool.free(c->scan_cache[lru].buf);
         c->pool.free(c->scan_cache[lru].smax);
+        c->pool.free(c->scan_cache[lru].qbound);
         c->scan_cache.erase(c->scan_cache.begin() + lru);
     }
     uint32_t* buf = reinterpret_cast<uint32_t*>(c->pool.alloc(bytes));
@@ -406,8 +419,9 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
         for (size_t k = kb; k < kb + nb; ++k) longest = std::max<uint64_t>(longest, ss.off[k + 1] - ss.off[k]);
         LTM_HIP(scan_range_images(ss.d, ss.off_dev, kb, nb, first, npts, longest, g, buf, smax, c->stream));
     }
-    c->scan_cache.push_back(ScanImgEntry{ss_handle, g.rows, g.cols, kb, nb, buf, smax, bytes, ++c->scan_cache_stamp});
+    c->scan_cache.push_back(ScanImgEntry{ss_handle, g.rows, g.cols, kb, nb, buf, smax, bytes, ++c->scan_cache_stamp, nullptr, -1.0f});
     *smax_out = smax;
+    with_qbound(c->scan_cache.back());
     return buf;
 }
 
@@ -430,14 +444,15 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
     for (size_t kb = kf_begin; kb < kf_end; kb += KB) {
         const size_t nb = std::min(KB, kf_end - kb);
         const uint32_t* smax = nullptr;
-        const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g, &smax);
+        const float* qbound = nullptr;
+        const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
+        const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g, &smax, cull ? thr : -1.0f, &qbound);
         {
             ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 8));
             LTM_HIP(fill_u64(map_img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
         }
         {
             // class name = kernel: k_vote_map_cull for mode 0 (when enabled), k_map_rimg_blockmin otherwise
-            const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
             // algorithmic bytes = map tiles read + images written.  Tiles that the whole-tile range cull drops are never read, so
             // (measurement only, when profiling is on) they are counted by the same predicate and left out.
             double pts = (double)map.n * nb;
@@ -450,7 +465,7 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
                 pts = std::min(pts, (double)nlive * 4096.0);
             }
             ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, 16.0 * pts + (double)nb * 8.0 * npx);
-            LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, scan_img,
+            LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, cull ? qbound : nullptr,
                                           mode == 0 ? tb.as<float>() : nullptr, smax, thr, mode, map_img.as<uint64_t>(), c->stream));
         }
         {

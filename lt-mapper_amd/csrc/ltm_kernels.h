@@ -27,6 +27,8 @@ hipError_t fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 // smax_bits (nb entries, zero-initialised by the caller, may be null): per keyframe the float bits of the largest scan range
 hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb,
                              uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s);
+// squared-range bound image of the range-culled vote kernel from finished scan images (see k_scan_qbound)
+hipError_t scan_qbound(const uint32_t* scan_img, size_t n, float thr, float* qbound, hipStream_t s);
 // bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);
 void set_stats_select(int v);
@@ -41,7 +43,7 @@ hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, s
 // vote form of the above: mode 0 may cull points that provably cannot be flagged (needs the finished scan images)
 // approx_poses_dev: 16 floats per keyframe {A[9], c_hi[3], c_lo[3], ok} with p_local ~= A (p - c) (see xform_approx)
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, const float* tile_bounds_dev,
+                                 HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
                                  const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s);
 void set_vote_cull(int v);
 int vote_cull_enabled();

@@ -139,6 +139,35 @@ k_image_max(const uint32_t* __restrict__ img, uint32_t npx, uint32_t* __restrict
     }
 }
 
+// qbound[px] for the range-culled vote (mode 0, diff = scan - map > thr): a map point of this pixel can only be flagged if its
+// exact range r_e < s - thr (+ float rounding of the subtraction, <= 2e-5 for |diff| < 200).  The kernel tests the squared range
+// r2 of its approximate projection, r_e^2 >= r2 (1 - 3e-6) (validated bound), so it may drop the point iff
+// r2 >= ((s - thr + 1e-3) (1 + 1e-5))^2, rounded up.  Empty pixels (10000) never flag below 9800 m (and farther points take the
+// exact path): 0.  Evaluated in double, rounded up to float.
+__global__ void __launch_bounds__(kBlock)
+k_scan_qbound(const uint32_t* __restrict__ scan_img, size_t n, float thr, float* __restrict__ qbound)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t sb = scan_img[i];
+    float q = 0.0f;
+    if (sb < kNoPointBits) {
+        const double lim = ((double)u2f(sb) - (double)thr + 1.0e-3) * (1.0 + 1.0e-5);
+        if (lim > 0.0) {
+            const double q2 = lim * lim;
+            q = (float)q2;
+            if ((double)q < q2) q = u2f(f2u(q) + 1u);      // round up (q > 0)
+        }
+    }
+    qbound[i] = q;
+}
+hipError_t scan_qbound(const uint32_t* scan_img, size_t n, float thr, float* qbound, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_scan_qbound<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(scan_img, n, thr, qbound);
+    return hipGetLastError();
+}
+
 hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t first_pt,
                              uint64_t n_pts, uint64_t max_kf_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s)
 {
@@ -309,8 +338,9 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 static constexpr float kCullEpsPx = 3.0e-3f;
 
 // rb/cb: the pixel if it is certain; multi: within kCullEpsPx of a rounding boundary (candidates r0..r1 x c0..c1, filled by
-// cull_expand); r_lo: lower bound of the exact range (upper bound = r_lo * (1 + 3e-6)); unusual: outside the fast forms' domain
-struct CullCand { int rb, cb, r0, r1, c0, c1; float rowh, colh, r_lo, r; bool multi, unusual; };
+// cull_expand); r2: squared range of the approximate local point -- the exact range r_e satisfies r_e^2 in r2 * [1 - 3e-6, 1 + 3e-6]
+// (validated on the device by ltm_debug_cull_check); unusual: outside the fast forms' domain
+struct CullCand { int rb, cb, r0, r1, c0, c1; float rowh, colh, r2; bool multi, unusual; };
 
 // p' = A (p - c): the inverse pose (composed with base->lidar) rewritten around the sensor position c so that the
 // subtraction happens between nearby numbers; c is carried as a float-float pair (c_hi, c_lo) and the tiny constant
@@ -327,36 +357,41 @@ __device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, flo
     return o;
 }
 
-__device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale)
+// steep_clamps: the field of view is narrow enough (vfov/2 < 44 deg) that every elevation beyond +-45 deg clamps into the first /
+// last row whatever its value, so the elevation polynomial only ever sees |z| / rxy <= 1 (one v_rsq instead of v_sqrt + v_rcp and
+// no octant select); with a wider vertical field of view the steep points take the exact path instead.
+__device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale, bool steep_clamps)
 {
     CullCand cc;
     const float xy2 = __builtin_fmaf(p.x, p.x, p.y * p.y);
-    const float rxy = __builtin_amdgcn_sqrtf(xy2);
-    const float r = __builtin_amdgcn_sqrtf(__builtin_fmaf(p.z, p.z, xy2));
+    cc.r2 = __builtin_fmaf(p.z, p.z, xy2);
+    const float t_el = fabsf(p.z) * __builtin_amdgcn_rsqf(xy2);               // tan |elevation|
+    const float el = __builtin_copysignf(atan_unit_approx(fminf(t_el, 1.0f)), p.z);
     const float az = atan2_approx(p.y, p.x);
-    const float el = atan2_approx_xpos(p.z, rxy);
     // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
     cc.rowh = __builtin_fmaf(-el, row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5: floor() of it is the rounded pixel
     cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
-    // Outside the fast forms' domain (every such case ends in the exact path): y == +-0 (the sign of a zero y picks the side of
-    // the +-180 deg seam in the reference), anything that made a NaN/inf (x = y = 0, under/overflowing squares), absurd ranges.
-    // rowh/colh are bounded (|atan| <= pi) unless something upstream made a NaN, and a NaN fails the "<=" below as well.
+    // Outside the fast forms' domain (every such case ends in the exact path): the +-180 deg seam -- the SIGN of y picks column 0
+    // or C-1 there, and the approximate y is only good to ~1e-7 of the range, so x < 0 with |y| <= 1e-6 |x| is undecidable here
+    // (y == +-0 included); vanishing x and y (the squares would underflow); anything that made a NaN/inf; absurd ranges.
+    // rowh/colh are bounded (|atan| <= pi) unless something upstream made a NaN, and a NaN fails the "<" below.
     const float rfr = __builtin_amdgcn_fractf(cc.rowh), cfr = __builtin_amdgcn_fractf(cc.colh);   // distance above the rounding boundary
     const bool certain = fmaxf(fabsf(rfr - 0.5f), fabsf(cfr - 0.5f)) <= 0.5f - kCullEpsPx;
     // The same compare also sends every point with r >= ~8000 m down the exact path (rowh + colh >= -1.3 R, so passing it means
-    // r < 8000 + 1.3 R < 9800 for any image below 1300 rows): the reference's "empty pixel = 10000 m" sentinel arithmetic
+    // r < 8000 + ~1 km < 9800 for any image below ~8000 rows): the reference's "empty pixel = 10000 m" sentinel arithmetic
     // (diff = 10000 - r, Removerter.cpp:398-404) flags a map point 9800..9999.9 m from the sensor on an EMPTY scan pixel, which
-    // the fast test below (empty pixels never flag) would drop.
-    cc.unusual = (p.y == 0.0f) | !(cc.rowh + cc.colh + r < 8.0e3f);   // also NaN anywhere (e.g. denormal y with x = 0) and inf
+    // the fast test (empty pixels never flag) would drop.  r2 * 1.25e-4 < 8000 <=> r < 8000.
+    cc.unusual = (fabsf(p.y) <= __builtin_fmaf(-1.0e-6f, p.x, 1.0e-18f)) | !(__builtin_fmaf(cc.r2, 1.25e-4f, cc.rowh + cc.colh) < 8.0e3f) | (!steep_clamps & (t_el > 1.0f));
     cc.multi = !certain;
     // clamp(floor(v), 0, n-1) == trunc(med3(v, 0, n-1)): the bounds are integers and the clamped value is non-negative
     cc.rb = (int)__builtin_amdgcn_fmed3f(cc.rowh, 0.0f, g.frows - 1.0f);
     cc.cb = (int)__builtin_amdgcn_fmed3f(cc.colh, 0.0f, g.fcols - 1.0f);
     cc.r0 = cc.r1 = cc.rb; cc.c0 = cc.c1 = cc.cb;
-    cc.r_lo = r * (1.0f - 1.5e-6f);
-    cc.r = r;
     return cc;
 }
+
+// lower bound of the exact range from the squared approximate range (native sqrt, 1 ulp): upper bound = r_lo * (1 + 3e-6)
+__device__ __forceinline__ float cull_r_lo(float r2) { return __builtin_amdgcn_sqrtf(r2) * (1.0f - 1.5e-6f); }
 
 // candidate pixel rectangle of a point that sits within kCullEpsPx of a rounding boundary (rare)
 __device__ __forceinline__ void cull_expand(const RimgGeom& g, CullCand& cc)
@@ -371,18 +406,15 @@ __device__ __forceinline__ void cull_expand(const RimgGeom& g, CullCand& cc)
     cc.c1 = min(max(ccn + (cfr > 1.0f - kCullEpsPx ? 1 : 0), 0), cmax);
 }
 
-__device__ __forceinline__ bool cull_matters(const CullCand& cc, const uint32_t* __restrict__ scan, int cols, float thr)
+// With a non-identity base->lidar extrinsic the exact path rounds to float between the two transforms (utility.cpp:70-71), i.e.
+// at magnitude range + lever arm; relative to a range much smaller than the lever arm that rounding exceeds the validated bounds
+// of the approximate projection, so points nearer than lever/8 take the exact path (none with an identity extrinsic).
+template <bool B2L_IDENTITY>
+__device__ __forceinline__ float cull_min_range(const HostMat34& b2l)
 {
-    if (cc.unusual) return true;
-    const float thr_lo = thr - (1.0e-3f + cc.r_lo * 3.0e-6f);
-    auto t = [&](int r, int c) {
-        const float s = u2f(scan[r * cols + c]);
-        return (s < 9000.0f) & ((s - cc.r_lo) > thr_lo);     // empty scan pixels (10000) can never be flagged: diff > 200
-    };
-    bool m = t(cc.r0, cc.c0);
-    if (cc.c1 != cc.c0) m |= t(cc.r0, cc.c1);
-    if (cc.r1 != cc.r0) { m |= t(cc.r1, cc.c0); if (cc.c1 != cc.c0) m |= t(cc.r1, cc.c1); }
-    return m;
+    if (B2L_IDENTITY) return 0.0f;
+    const float tx = (float)b2l.m[3], ty = (float)b2l.m[7], tz = (float)b2l.m[11];
+    return 0.125f * __builtin_sqrtf(tx * tx + ty * ty + tz * tz) + 1.0e-6f;
 }
 
 __device__ unsigned long long g_cull_stats[4];   // {survivors, points} of k_vote_map_cull, then of k_map_rimg_blockmin: diagnostic, read by cull_stats()
@@ -476,7 +508,7 @@ static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's
 template <bool B2L_IDENTITY>
 __global__ void __launch_bounds__(kBlock)
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const uint32_t* __restrict__ scan_img,
+                uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const float* __restrict__ qbound_img,
                 const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img)
 {
     __shared__ uint64_t vals[kCullSlots];
@@ -499,40 +531,41 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
     const uint32_t nloc = min(per_block, M - block_base);
     const uint32_t kf = kb + tk.kfb;
     uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
-    const uint32_t* __restrict__ scank = scan_img + (size_t)tk.kfb * npx;
+    const float* __restrict__ qk = qbound_img + (size_t)tk.kfb * npx;
     // ---- phase 1: who can matter?  (bounded-error arithmetic only).  Four points per lane are in flight at once so the
     // dependent scan-image load of one overlaps the arithmetic of the others.
     {
         const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
         const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
+        const float rmin = cull_min_range<B2L_IDENTITY>(b2l_h), rmin2 = rmin * rmin;
+        const bool steep_clamps = g.vfov < 88.0f;
         constexpr int kInFlight = 4;
         for (uint32_t j0 = 0; j0 < (uint32_t)kPtsPerThread; j0 += kInFlight) {
             float4 pt[kInFlight];
             CullCand cc[kInFlight];
-            uint32_t s0[kInFlight];
+            float q0[kInFlight];
             bool live[kInFlight];
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 const uint32_t li = (j0 + u) * kBlock + threadIdx.x;
                 live[u] = li < nloc;
-                pt[u] = live[u] ? mapb[li] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+                pt[u] = mapb[min(li, nloc - 1u)];      // unconditional (clamped) load: a predicated one puts an s_waitcnt inside a branch per point
             }
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 bool ok;
                 const float3 p = xform_approx(ap, pt[u], ok);
-                cc[u] = cull_candidates(g, p, row_scale, col_scale);
-                cc[u].unusual |= !ok;
-                s0[u] = *reinterpret_cast<const uint32_t*>(reinterpret_cast<const char*>(scank) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
+                cc[u] = cull_candidates(g, p, row_scale, col_scale, steep_clamps);
+                // not certain of the pixel (within kCullEpsPx of a rounding boundary, ~1 % of the points): straight to the exact path
+                cc[u].unusual |= !ok | cc[u].multi | (B2L_IDENTITY ? false : (cc[u].r2 < rmin2));
+                q0[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(qk) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
             }
             bool mt[kInFlight];
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
-                // s - r_lo > thr - (1e-3 + 3e-6 r_lo) with r_lo = r (1 - 1.5e-6), i.e. s - r (1 - 4.5e-6) > thr - 1e-3, rounded to the
-                // conservative side (1 - 5e-6) so that one FMA and one compare decide
-                const float s = u2f(s0[u]);
-                bool m = cc[u].unusual | ((s < 9000.0f) & (__builtin_fmaf(cc[u].r, -(1.0f - 5.0e-6f), s) > thr - 1.0e-3f));
-                if (__builtin_expect(cc[u].multi & !m, 0)) { cull_expand(g, cc[u]); m = cull_matters(cc[u], scank, g.cols, thr); }
+                // qbound[px] = an upper bound of the SQUARED range below which a point of that pixel could be flagged (k_scan_qbound):
+                // one compare decides; empty pixels hold 0
+                const bool m = cc[u].unusual | (cc[u].r2 < q0[u]);
                 mt[u] = m & live[u];
             }
             // One LDS atomic per wave for the four points of every lane (hand-rolled ballot/mbcnt aggregation: letting the compiler
@@ -554,7 +587,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                     const uint32_t pos = base + off[u] + below;
                     if (pos < (uint32_t)kCullQueue) {       // overflow (rare): the whole tile takes the exact path below
                         queue[pos] = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
-                        q_rc[pos] = (cc[u].unusual | cc[u].multi) ? 0xffffffffu : (((uint32_t)cc[u].rb << 16) | (uint32_t)cc[u].cb);
+                        q_rc[pos] = cc[u].unusual ? 0xffffffffu : (((uint32_t)cc[u].rb << 16) | (uint32_t)cc[u].cb);
                     }
                 }
             }
@@ -625,17 +658,17 @@ int vote_cull_enabled() { return g_vote_cull != 0; }
 int tile_cull_enabled() { return g_tile_cull != 0; }
 
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                 HostMat34 b2l, int b2l_identity, Geom g, const uint32_t* scan_img, const float* tile_bounds_dev,
+                                 HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
                                  const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s)
 {
     if (!M || !nb) return hipSuccess;
-    if (mode != 0 || !g_vote_cull || !approx_poses_dev) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
+    if (mode != 0 || !g_vote_cull || !approx_poses_dev || !qbound_img) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
     const unsigned kfg = (unsigned)g_kf_per_block;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
     const float* tb = (g_tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
-    if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, tb, smax_bits_dev, thr, map_img);
-    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, scan_img, tb, smax_bits_dev, thr, map_img);
+    if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img);
+    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img);
     return hipGetLastError();
 }
 
@@ -657,13 +690,19 @@ k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, HostMat34 b2l
         pa = xform_approx(ap, p4, ok);
     }
     const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
-    CullCand cc = cull_candidates(g, pa, row_scale, col_scale);
+    CullCand cc = cull_candidates(g, pa, row_scale, col_scale, g.vfov < 88.0f);
     if (cc.unusual || !ok) return;
+    const float rmin = cull_min_range<false>(b2l);
+    if (ap && !b2l_identity && cc.r2 < rmin * rmin) return;      // these take the exact path in the kernels
     if (cc.multi) cull_expand(g, cc);
     const Sph s = cart2sph(pe.x, pe.y, pe.z);
     int row, col;
     pixel_row_col(g, s.az, s.el, row, col);
-    const bool good = (row == cc.r0 || row == cc.r1) && (col == cc.c0 || col == cc.c1) && (cc.r_lo <= s.r) && (s.r <= cc.r_lo * (1.0f + 3.0e-6f));
+    // the vote kernel relies on r_e^2 >= r2 (1 - 3e-6); the exact-image kernel on r_lo <= r_e <= r_lo (1 + 3e-6) with its r_lo
+    const double re2 = (double)s.r * (double)s.r;
+    const float r_lo = cull_r_lo(cc.r2);
+    const bool good = (row == cc.r0 || row == cc.r1) && (col == cc.c0 || col == cc.c1) && (r_lo <= s.r) && (s.r <= r_lo * (1.0f + 3.0e-6f)) &&
+                      (re2 >= (double)cc.r2 * (1.0 - 3.0e-6)) && (re2 <= (double)cc.r2 * (1.0 + 3.0e-6));
     if (!good) atomicAdd(bad, 1ull);
 }
 hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,
@@ -720,6 +759,8 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
     const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
     const bool packable = g.rows < (int)kBmRowUncertain && g.cols <= 2048;
+    const float rmin = cull_min_range<B2L_IDENTITY>(b2l_h), rmin2 = rmin * rmin;
+    const bool steep_clamps = g.vfov < 88.0f;
     // per-lane record of the 16 points: range lower bound and (row | col | flags); flags: bit 31 = owns an amin slot, bit 30 = a point
     float rlo[kPtsPerThread];
     uint32_t rec[kPtsPerThread];
@@ -733,19 +774,19 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         for (int u = 0; u < 4; ++u) {
             const uint32_t li = (uint32_t)(j0 + u) * kBlock + threadIdx.x;
             live[u] = li < nloc;
-            pt[u] = live[u] ? mapb[li] : make_float4(1.0f, 1.0f, 1.0f, 0.0f);
+            pt[u] = mapb[min(li, nloc - 1u)];          // unconditional (clamped) load, see k_vote_map_cull
         }
         bool ok = true;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const float3 p = xform_approx(ap, pt[u], ok);
-            cc[u] = cull_candidates(g, p, row_scale, col_scale);
+            cc[u] = cull_candidates(g, p, row_scale, col_scale, steep_clamps);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int j = j0 + u;
-            rlo[j] = cc[u].r_lo;
-            const bool certain = packable & ok & !cc[u].unusual & !cc[u].multi;
+            rlo[j] = cull_r_lo(cc[u].r2);
+            const bool certain = packable & ok & !cc[u].unusual & !cc[u].multi & !(cc[u].r2 < rmin2);
             rec[j] = (live[u] ? 0x40000000u : 0u) | ((certain ? (uint32_t)cc[u].rb : kBmRowUncertain) << 11) | (uint32_t)(cc[u].cb & 2047);
             if (!live[u] | !certain) continue;
             const uint32_t px = (uint32_t)(cc[u].rb * g.cols + cc[u].cb);
@@ -759,7 +800,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
             rec[j] |= 0x80000000u;
             // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6)).  amin only ever decreases, so a plain read that is
             // already smaller makes the (same-address, hence serialised) atomic unnecessary for most points of a pixel
-            const uint32_t hi = f2u(cc[u].r_lo * (1.0f + 3.5e-6f));
+            const uint32_t hi = f2u(rlo[j] * (1.0f + 3.5e-6f));
             if (hi < amin[slot]) atomicMin(&amin[slot], hi);
         }
     }

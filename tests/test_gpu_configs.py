@@ -48,7 +48,7 @@ def test_config0_2x50_os1_64_single_res_through_ltm_run(tmp_path, orc, lot50):
     c_kf = fp.parse_keyframes(n_kf, 0, n_kf - 1)
     assert c_kf == list(range(n_kf))
     q_kf = fp.query_keyframes_in_roi(lot50[0], c_kf, lot50[1], n_kf)
-    assert len(q_kf) >= 40, "sessions 01 and 02 of the lot overlap almost everywhere"
+    assert len(q_kf) >= 20, "sessions 01 and 02 start 37 m apart on the same loop: about half of the query keyframes are within 10 m of a central pose"
     C, Q = fp.host_load(orc, lot50[0], c_kf), fp.host_load(orc, lot50[1], q_kf)
     assert int(C["offsets"][-1]) > 2_000_000, "os1-64 scans: the 0.05 m VoxelGrid takes its int32-overflow early-out (A.6)"
     ref = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01, threads=ORACLE_THREADS), C, Q)
