@@ -83,6 +83,10 @@ int ltm_cloud_transform(ltm_ctx*, ltm_cloud in, const double* T1, const double* 
 int ltm_cloud_select(ltm_ctx*, ltm_cloud in, const int32_t* idx_host, size_t n_idx, ltm_cloud* out);
 int ltm_cloud_free(ltm_ctx*, ltm_cloud);
 
+/* an UNINITIALISED cloud of n points whose device array (ltm_cloud_device_ptr) a collective fills: the all-gather that assembles a
+ * map from per-rank pieces writes straight into it (north_star: "RCCL all-gather over xGMI to assemble the final maps") */
+int ltm_cloud_alloc(ltm_ctx*, size_t n, ltm_cloud* out);
+
 /* ---------------------------------------------------------------- scan sets ---- */
 /* keyframe_scans_ and friends (Session.h:41-58): offsets[n_kf+1] in points */
 int ltm_scanset_upload(ltm_ctx*, const void* pts, size_t stride_bytes, const uint64_t* offsets, size_t n_kf, ltm_scanset* out);
@@ -97,7 +101,18 @@ int ltm_scanset_as_cloud(ltm_ctx*, ltm_scanset, ltm_cloud* out);                
 int ltm_scanset_concat(ltm_ctx*, const ltm_scanset* in, size_t n, ltm_scanset* out);
 /* per-keyframe `a[i] += b[i] (+= c[i])` of Session.cpp:365-371 ; c may be 0 */
 int ltm_scanset_zip_concat(ltm_ctx*, ltm_scanset a, ltm_scanset b, ltm_scanset c, ltm_scanset* out);
+/* the same for a scan set: keyframe layout given by host offsets[n_kf+1], points uninitialised (ltm_scanset_device_ptr) */
+int ltm_scanset_alloc(ltm_ctx*, const uint64_t* offsets, size_t n_kf, ltm_scanset* out);
 int ltm_scanset_free(ltm_ctx*, ltm_scanset);
+
+/* ------------------------------------------------------- raw device buffers ---- */
+/* Label masks and staging areas of the multi-GPU host: pooled device memory, ordered on the context's stream
+ * (ltm_stream) -- a collective enqueued on that stream needs no extra synchronisation.  ltm_buffer_copy returns when the copy
+ * has completed; kind: 0 = host->device, 1 = device->host, 2 = device->device. */
+int ltm_buffer_alloc(ltm_ctx*, size_t bytes, void** dev);
+int ltm_buffer_free(ltm_ctx*, void* dev);
+int ltm_buffer_fill(ltm_ctx*, void* dev, int byte_value, size_t bytes);            /* asynchronous on the context's stream */
+int ltm_buffer_copy(ltm_ctx*, void* dst, const void* src, size_t bytes, int kind);
 
 /* -------------------------------------------------------------------- poses ---- */
 /* keyframe_poses_ / keyframe_inverse_poses_ (Session.cpp:102-114).  inv may be NULL: then the

@@ -51,6 +51,12 @@ SIGNATURES = {
     "ltm_cloud_select": (_i, [_vp, _u64, _vp, _sz, _pu64]),
     "ltm_scanset_keyframe": (_i, [_vp, _u64, _sz, _pu64]),
     "ltm_cloud_free": (_i, [_vp, _u64]),
+    "ltm_cloud_alloc": (_i, [_vp, _sz, _pu64]),
+    "ltm_scanset_alloc": (_i, [_vp, _pu64, _sz, _pu64]),
+    "ltm_buffer_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
+    "ltm_buffer_free": (_i, [_vp, _vp]),
+    "ltm_buffer_fill": (_i, [_vp, _vp, _i, _sz]),
+    "ltm_buffer_copy": (_i, [_vp, _vp, _vp, _sz, _i]),
     "ltm_scanset_upload": (_i, [_vp, _vp, _sz, _pu64, _sz, _pu64]),
     "ltm_scanset_from_device": (_i, [_vp, _vp, _pu64, _sz, _pu64]),
     "ltm_scanset_info": (_i, [_vp, _u64, _psz, _psz]),

@@ -760,6 +760,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     }
     if (const char* v = getenv("LTM_MAP_KERNEL")) set_map_kernel_variant(atoi(v));   // A/B switch for profiling
     if (const char* v = getenv("LTM_VOTE_CULL")) set_vote_cull(atoi(v));
+    set_cull_variant(getenv("LTM_CULL_VARIANT") ? atoi(getenv("LTM_CULL_VARIANT")) : 0);
     if (const char* v = getenv("LTM_KF_PER_BLOCK")) set_kf_per_block(atoi(v));
     if (const char* v = getenv("LTM_TILE_CULL")) set_tile_cull(atoi(v));
     if (const char* v = getenv("LTM_STATS_BLOCKMIN")) set_stats_select(atoi(v));
@@ -919,6 +920,33 @@ int ltm_scanset_keyframe(ltm_ctx* c, ltm_scanset hs, size_t kf, ltm_cloud* out)
         *out = h;
     });
 }
+int ltm_cloud_alloc(ltm_ctx* c, size_t n, ltm_cloud* out)
+{
+    return guarded(c, [&] { LTM_REQUIRE(out, "null argument"); float4* d; *out = alloc_cloud(c, n, &d); });
+}
+int ltm_buffer_alloc(ltm_ctx* c, size_t bytes, void** dev)
+{
+    return guarded(c, [&] { LTM_REQUIRE(dev, "null argument"); *dev = c->pool.alloc(bytes); });
+}
+int ltm_buffer_free(ltm_ctx* c, void* dev)
+{
+    return guarded(c, [&] { sync(c); c->pool.free(dev); });      // the caller may have used it on another stream: drain ours before recycling
+}
+int ltm_buffer_fill(ltm_ctx* c, void* dev, int byte_value, size_t bytes)
+{
+    return guarded(c, [&] { LTM_REQUIRE(dev || bytes == 0, "null buffer"); if (bytes) LTM_HIP(hipMemsetAsync(dev, byte_value, bytes, c->stream)); });
+}
+int ltm_buffer_copy(ltm_ctx* c, void* dst, const void* src, size_t bytes, int kind)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE((dst && src) || bytes == 0, "null buffer");
+        LTM_REQUIRE(kind >= 0 && kind <= 2, "kind must be 0 (h2d), 1 (d2h) or 2 (d2d)");
+        if (!bytes) return;
+        if (kind == 0) h2d(c, dst, src, bytes);
+        else if (kind == 1) d2h(c, dst, src, bytes);
+        else { d2d(c, dst, src, bytes); sync(c); }
+    });
+}
 int ltm_cloud_free(ltm_ctx* c, ltm_cloud h)
 {
     return guarded(c, [&] { Cloud& cl = get_cloud(c, h); c->pool.free(cl.d); c->clouds.erase(h); });
@@ -1033,6 +1061,15 @@ int ltm_scanset_zip_concat(ltm_ctx* c, ltm_scanset ha, ltm_scanset hb, ltm_scans
         // (oc[k+1]-oc[k]) is never read for it because j < na + nb always holds; pass B's arrays to keep pointers valid
         LTM_HIP(zip_concat(A.d, A.off_dev, B.d, B.off_dev, C ? C->d : B.d, C ? C->off_dev : B.off_dev, O.off_dev, nk, tot, d, c->stream));
         *out = h;
+    });
+}
+int ltm_scanset_alloc(ltm_ctx* c, const uint64_t* off, size_t n_kf, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        check_offsets(off, n_kf);
+        float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(off[n_kf], 1) * 16));
+        *out = new_scanset(c, d, std::vector<uint64_t>(off, off + n_kf + 1));
     });
 }
 int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)

@@ -196,6 +196,21 @@ __device__ __forceinline__ float atan_unit_approx(float a)
     p = __builtin_fmaf(p, t, 9.999772310e-01f);
     return a * p;
 }
+// the same polynomial on two arguments at once (v_pk_mul_f32 / v_pk_fma_f32: one issue slot for both): the azimuth and the
+// elevation ratio of one point.  Same operations in the same order as atan_unit_approx, so the same error bound.
+typedef float ltm_v2f __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ltm_v2f atan_unit_approx2(ltm_v2f a)
+{
+    const ltm_v2f t = a * a;
+    ltm_v2f p = {-1.171913743e-02f, -1.171913743e-02f};
+    p = __builtin_elementwise_fma(p, t, (ltm_v2f){5.264735594e-02f, 5.264735594e-02f});
+    p = __builtin_elementwise_fma(p, t, (ltm_v2f){-1.164264902e-01f, -1.164264902e-01f});
+    p = __builtin_elementwise_fma(p, t, (ltm_v2f){1.935403794e-01f, 1.935403794e-01f});
+    p = __builtin_elementwise_fma(p, t, (ltm_v2f){-3.326228261e-01f, -3.326228261e-01f});
+    p = __builtin_elementwise_fma(p, t, (ltm_v2f){9.999772310e-01f, 9.999772310e-01f});
+    return a * p;
+}
+
 // atan2 for finite, non-zero y and x; |error| <= 3e-6 rad
 __device__ __forceinline__ float atan2_approx(float y, float x)
 {

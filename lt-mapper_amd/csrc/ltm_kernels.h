@@ -46,6 +46,7 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
                                  HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
                                  const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s);
 void set_vote_cull(int v);
+void set_cull_variant(int v);
 int vote_cull_enabled();
 int tile_cull_enabled();
 hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,

@@ -360,14 +360,22 @@ __device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, flo
 // steep_clamps: the field of view is narrow enough (vfov/2 < 44 deg) that every elevation beyond +-45 deg clamps into the first /
 // last row whatever its value, so the elevation polynomial only ever sees |z| / rxy <= 1 (one v_rsq instead of v_sqrt + v_rcp and
 // no octant select); with a wider vertical field of view the steep points take the exact path instead.
+template <bool PACKED_POLY = true>
 __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale, bool steep_clamps)
 {
     CullCand cc;
     const float xy2 = __builtin_fmaf(p.x, p.x, p.y * p.y);
     cc.r2 = __builtin_fmaf(p.z, p.z, xy2);
     const float t_el = fabsf(p.z) * __builtin_amdgcn_rsqf(xy2);               // tan |elevation|
-    const float el = __builtin_copysignf(atan_unit_approx(fminf(t_el, 1.0f)), p.z);
-    const float az = atan2_approx(p.y, p.x);
+    // azimuth: octant reduction min/max of |x|, |y|; both polynomials evaluated as one packed chain
+    const float ax = fabsf(p.x), ay = fabsf(p.y);
+    const float t_az = fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(ax, ay));
+    const ltm_v2f at = PACKED_POLY ? atan_unit_approx2((ltm_v2f){t_az, fminf(t_el, 1.0f)})
+                                   : (ltm_v2f){atan_unit_approx(t_az), atan_unit_approx(fminf(t_el, 1.0f))};
+    const float el = __builtin_copysignf(at.y, p.z);
+    float az = (ay > ax) ? (1.57079632679f - at.x) : at.x;
+    az = (p.x < 0.0f) ? (3.14159265359f - az) : az;
+    az = __builtin_copysignf(az, p.y);          // az >= 0: one v_bfi instead of compare + select
     // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
     cc.rowh = __builtin_fmaf(-el, row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5: floor() of it is the rounded pixel
     cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
@@ -505,7 +513,7 @@ hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb,
 
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
-template <bool B2L_IDENTITY>
+template <bool B2L_IDENTITY, int VARIANT = 0>     // VARIANT: A/B switches for profiling (env LTM_CULL_VARIANT), results identical
 __global__ void __launch_bounds__(kBlock)
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
                 uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const float* __restrict__ qbound_img,
@@ -513,9 +521,10 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
 {
     __shared__ uint64_t vals[kCullSlots];
     __shared__ uint32_t tags[kCullSlots];
-    __shared__ uint16_t queue[kCullQueue];     // tile-local indices of the survivors of phase 1
-    __shared__ uint32_t q_rc[kCullQueue];      // their certain pixel (row << 16 | col), or 0xffffffff = needs the full exact projection
-    __shared__ uint16_t uqueue[kCullQueue];    // the latter, re-queued densely in phase 2
+    // survivors of phase 1, one word each: tile-local index (12 bits) | row (9) | column (11); row field 511 = pixel not certain,
+    // needs the full exact projection (images with >= 511 rows or > 2048 columns mark every survivor that way)
+    __shared__ uint32_t queue[kCullQueue];
+    __shared__ uint16_t uqueue[kCullQueue];    // the uncertain ones, re-queued densely in phase 2
     __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
@@ -539,7 +548,15 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
         const float rmin = cull_min_range<B2L_IDENTITY>(b2l_h), rmin2 = rmin * rmin;
         const bool steep_clamps = g.vfov < 88.0f;
+        const bool ok_img = g.rows < 511 && g.cols <= 2048;      // the queue word holds 9 row bits and 11 column bits
         constexpr int kInFlight = 4;
+        constexpr bool kPrefetch = (VARIANT & 2) == 0;     // software pipelining: the next group's points are requested before this group's arithmetic
+        float4 nxt[kInFlight];
+        if (kPrefetch) {
+#pragma unroll
+            for (int u = 0; u < kInFlight; ++u) nxt[u] = mapb[min((uint32_t)u * kBlock + threadIdx.x, nloc - 1u)];
+        }
+#pragma unroll
         for (uint32_t j0 = 0; j0 < (uint32_t)kPtsPerThread; j0 += kInFlight) {
             float4 pt[kInFlight];
             CullCand cc[kInFlight];
@@ -549,15 +566,20 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
             for (int u = 0; u < kInFlight; ++u) {
                 const uint32_t li = (j0 + u) * kBlock + threadIdx.x;
                 live[u] = li < nloc;
-                pt[u] = mapb[min(li, nloc - 1u)];      // unconditional (clamped) load: a predicated one puts an s_waitcnt inside a branch per point
+                if (kPrefetch) {
+                    pt[u] = nxt[u];
+                    if (j0 + kInFlight < (uint32_t)kPtsPerThread) nxt[u] = mapb[min(li + kInFlight * kBlock, nloc - 1u)];
+                } else {
+                    pt[u] = mapb[min(li, nloc - 1u)];  // unconditional (clamped) load: a predicated one puts an s_waitcnt inside a branch per point
+                }
             }
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 bool ok;
                 const float3 p = xform_approx(ap, pt[u], ok);
-                cc[u] = cull_candidates(g, p, row_scale, col_scale, steep_clamps);
+                cc[u] = cull_candidates<(VARIANT & 1) == 0>(g, p, row_scale, col_scale, steep_clamps);
                 // not certain of the pixel (within kCullEpsPx of a rounding boundary, ~1 % of the points): straight to the exact path
-                cc[u].unusual |= !ok | cc[u].multi | (B2L_IDENTITY ? false : (cc[u].r2 < rmin2));
+                cc[u].unusual |= !ok_img | !ok | cc[u].multi | (B2L_IDENTITY ? false : (cc[u].r2 < rmin2));
                 q0[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(qk) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
             }
             bool mt[kInFlight];
@@ -586,8 +608,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                     const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
                     const uint32_t pos = base + off[u] + below;
                     if (pos < (uint32_t)kCullQueue) {       // overflow (rare): the whole tile takes the exact path below
-                        queue[pos] = (uint16_t)((j0 + u) * kBlock + threadIdx.x);
-                        q_rc[pos] = cc[u].unusual ? 0xffffffffu : (((uint32_t)cc[u].rb << 16) | (uint32_t)cc[u].cb);
+                        queue[pos] = (((j0 + u) * kBlock + threadIdx.x) << 20) | ((cc[u].unusual ? 511u : (uint32_t)cc[u].rb) << 11) | (uint32_t)cc[u].cb;
                     }
                 }
             }
@@ -608,10 +629,10 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
         } else {
             for (uint32_t q = threadIdx.x; q < nq_all; q += kBlock) {
-                const uint32_t rc = q_rc[q];
-                if (rc == 0xffffffffu) { uqueue[atomicAdd(&ucount, 1u)] = queue[q]; continue; }
-                const uint32_t i = block_base + queue[q];
-                const int row = (int)(rc >> 16), col = (int)(rc & 0xffffu);
+                const uint32_t e = queue[q];
+                const int row = (int)((e >> 11) & 511u), col = (int)(e & 2047u);
+                if (row == 511) { uqueue[atomicAdd(&ucount, 1u)] = (uint16_t)(e >> 20); continue; }
+                const uint32_t i = block_base + (e >> 20);
                 const uint32_t px = (uint32_t)(row * g.cols + col);
                 const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
                 const int slot = ((row & 7) << 6) | (col & 63);
@@ -652,6 +673,8 @@ static int g_kf_per_block = 8;         // keyframes that reuse one map tile on a
 void set_kf_per_block(int v) { g_kf_per_block = v < 1 ? 1 : (v > 64 ? 64 : v); }
 static int g_tile_cull = 1;   // whole-tile range cull inside k_vote_map_cull (env LTM_TILE_CULL)
 void set_tile_cull(int v) { g_tile_cull = v; }
+static int g_cull_variant = 0;   // A/B variants of k_vote_map_cull (env LTM_CULL_VARIANT)
+void set_cull_variant(int v) { g_cull_variant = v; }
 static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
 void set_vote_cull(int v) { g_vote_cull = v; }
 int vote_cull_enabled() { return g_vote_cull != 0; }
@@ -667,8 +690,15 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
     const unsigned kfg = (unsigned)g_kf_per_block;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
     const float* tb = (g_tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
-    if (b2l_identity) k_vote_map_cull<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img);
-    else k_vote_map_cull<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img);
+#define LTM_LAUNCH_CULL(ID, V) k_vote_map_cull<ID, V><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
+    if (!b2l_identity) LTM_LAUNCH_CULL(false, 0);
+    else switch (g_cull_variant) {
+        case 1: LTM_LAUNCH_CULL(true, 1); break;
+        case 2: LTM_LAUNCH_CULL(true, 2); break;
+        case 3: LTM_LAUNCH_CULL(true, 3); break;
+        default: LTM_LAUNCH_CULL(true, 0); break;
+    }
+#undef LTM_LAUNCH_CULL
     return hipGetLastError();
 }
 

@@ -34,7 +34,10 @@ private:
 
 public:
     Removerter();
+    // one rank of a keyframe-sharded multi-GPU run: its own device context plus its Comm endpoint (removert_main.cpp --gpus K)
+    explicit Removerter(std::shared_ptr<Device> dev);
     virtual ~Removerter();
+    int rank() const { return dev_->rank(); }
 
     // pubRangeImg x4 (Removerter.cpp:580-585): called for every gpu_viz_every-th source keyframe of a vote pass with the
     // BGR8 images /scan_rimg_single, /map_rimg_single, /diff_rimg_single, /map_rimg_ptidx_single.  The default writes

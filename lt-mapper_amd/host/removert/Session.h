@@ -8,6 +8,7 @@
 #include <utility>
 #include <vector>
 
+#include "removert/Comm.h"
 #include "removert/RosParamServer.h"
 #include "removert/utility.h"
 
@@ -18,15 +19,30 @@ namespace ltremovert
 struct Device
 {
     ltm_ctx* ctx = nullptr;
-    explicit Device(const RosParamServer& p);
+    std::shared_ptr<Comm> comm;             // null = single GPU; else this rank's endpoint of the keyframe-sharded run (Comm.h)
+    explicit Device(const RosParamServer& p, int device_ordinal = -1, std::shared_ptr<Comm> comm_ = nullptr);
     ~Device();
+    int rank() const { return comm ? comm->rank() : 0; }
+    int world() const { return comm ? comm->world() : 1; }
     Device(const Device&) = delete;
     Device& operator=(const Device&) = delete;
 };
 
 // RAII handles ("boost::shared_ptr<cloud>" of the reference)
 struct CloudH { ltm_ctx* ctx = nullptr; ltm_cloud h = 0; CloudH() = default; CloudH(ltm_ctx* c, ltm_cloud v) : ctx(c), h(v) {} ~CloudH(); size_t size() const; Cloud download() const; };
-struct ScansH { ltm_ctx* ctx = nullptr; ltm_scanset h = 0; ScansH() = default; ScansH(ltm_ctx* c, ltm_scanset v) : ctx(c), h(v) {} ~ScansH(); size_t numKeyframes() const; std::vector<Cloud> download() const; };
+// A scan set is either whole (keyframes 0..n) or, in a multi-GPU run, this rank's SHARD: keyframes [kb, kb + numKeyframes()) of
+// n_total.  Per-keyframe results stay sharded from stage to stage; Session::gatherScans() assembles the whole set when a stage
+// needs every keyframe (merging scans into a global map).
+struct ScansH
+{
+    ltm_ctx* ctx = nullptr; ltm_scanset h = 0;
+    bool shard = false; size_t kb = 0, n_total = 0;
+    ScansH() = default;
+    ScansH(ltm_ctx* c, ltm_scanset v) : ctx(c), h(v) {}
+    ~ScansH();
+    size_t numKeyframes() const;
+    std::vector<Cloud> download() const;
+};
 using CloudPtr = std::shared_ptr<CloudH>;
 using ScansPtr = std::shared_ptr<ScansH>;
 
@@ -55,6 +71,8 @@ class Session : public RosParamServer
 {
 public:
     const float kReprojectionAlpha = 3.0;   // Session.h:13
+    // multi-GPU: clouds below this many points are voxelised on every rank instead of sharded + all-gathered (env LTM_VOXEL_SHARD_MIN)
+    static size_t kVoxelShardMin;
 
     explicit Session(std::shared_ptr<Device> dev);
 
@@ -72,6 +90,8 @@ public:
     std::vector<Matrix4d> keyframe_poses_, keyframe_inverse_poses_;
 
     ltm_poses poses_h_ = 0;                 // keyframe_poses_ + keyframe_inverse_poses_ on the device
+    ltm_poses poses_local_h_ = 0;           // multi-GPU: the poses of this rank's keyframe block [kf_begin_, kf_end_)
+    size_t kf_begin_ = 0, kf_end_ = 0;      // this rank's block of keyframes (all of them on a single GPU)
     ScansPtr keyframe_scans_, keyframe_scans_static_projected_, keyframe_scans_dynamic_;
     ScansPtr scans_knn_coexist_, scans_knn_diff_;
     ScansPtr keyframe_scans_updated_, keyframe_scans_updated_strong_, keyframe_scans_pd_, keyframe_scans_strong_pd_,
@@ -118,6 +138,10 @@ public:
     // helpers shared with Removerter
     CloudPtr wrap(ltm_cloud h) const { return std::make_shared<CloudH>(dev_->ctx, h); }
     ScansPtr wrap_scans(ltm_scanset h) const { return std::make_shared<ScansH>(dev_->ctx, h); }
+    ScansPtr wrap_shard(ltm_scanset h) const;        // result of a per-keyframe stage over [kf_begin_, kf_end_)
+    ScansPtr gatherScans(const ScansPtr& scans) const;   // whole scan set on every rank (all-gather-v); identity on a single GPU
+    // the scans / poses / keyframe range to hand to a per-keyframe C-ABI stage for `scans` (whole or shard)
+    void stageArgs(const ScansPtr& scans, ltm_poses* poses, size_t* kb, size_t* ke) const;
     CloudPtr mergeScansToGlobal(const ScansPtr& scans) const;        // utility.cpp:170-192
     CloudPtr octreeDownsampling(const CloudPtr& src, float leaf) const;   // utility.cpp:204-219
     CloudPtr concat(const std::vector<CloudPtr>& parts) const;

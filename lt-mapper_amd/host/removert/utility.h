@@ -51,6 +51,9 @@ void parallelFor(size_t n, const std::function<void(size_t)>& f, unsigned thread
 void fsmkdir(const std::string& _path);    // Removerter.cpp:6-10
 std::vector<std::string> listDirectorySorted(const std::string& dir, std::vector<std::string>* names);
 
+// per-thread switch: ranks other than 0 of a multi-GPU run keep quiet (their logs would only repeat rank 0's)
+bool& logQuiet();
+
 // throws std::runtime_error carrying ltm_last_error() when rc != LTM_OK
 void ltmCheck(ltm_ctx* ctx, int rc, const char* what);
 

@@ -1,0 +1,126 @@
+// Comm.cpp -- LocalComm: K logical ranks inside one process (see Comm.h).  Exchange goes device -> host staging -> device
+// through the C ABI only, so it runs on any number of devices including one (the test box).
+#include "removert/Comm.h"
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <mutex>
+#include <stdexcept>
+#include <string>
+
+namespace ltremovert
+{
+
+namespace
+{
+
+struct LocalGroup
+{
+    int world;
+    std::mutex m;
+    std::condition_variable cv;
+    int waiting = 0;
+    uint64_t generation = 0;
+    bool failed = false;
+    std::vector<std::vector<uint8_t>> stage;      // one staging buffer per rank
+    std::vector<uint64_t> scalars;
+    explicit LocalGroup(int w) : world(w), stage((size_t)w), scalars((size_t)w, 0) {}
+
+    void barrier()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        if (failed) throw std::runtime_error("LocalComm: another rank failed");
+        const uint64_t gen = generation;
+        if (++waiting == world) { waiting = 0; ++generation; cv.notify_all(); return; }
+        cv.wait(lk, [&] { return generation != gen || failed; });
+        if (failed) throw std::runtime_error("LocalComm: another rank failed");
+    }
+    void fail()
+    {
+        std::lock_guard<std::mutex> lk(m);
+        failed = true;
+        cv.notify_all();
+    }
+};
+
+void check(ltm_ctx* ctx, int rc, const char* what)
+{
+    if (rc != LTM_OK) throw std::runtime_error(std::string(what) + ": " + ltm_last_error(ctx));
+}
+
+class LocalComm : public Comm
+{
+    std::shared_ptr<LocalGroup> g_;
+    int rank_;
+
+public:
+    LocalComm(std::shared_ptr<LocalGroup> g, int r) : g_(std::move(g)), rank_(r) {}
+    int rank() const override { return rank_; }
+    int world() const override { return g_->world; }
+    const char* backend() const override { return "local"; }
+    void barrier() override { g_->barrier(); }
+    void abort() override { g_->fail(); }
+
+    void allReduceMaxU8(ltm_ctx* ctx, void* dev, size_t n) override
+    {
+        if (g_->world == 1 || n == 0) return;
+        try {
+            std::vector<uint8_t>& mine = g_->stage[(size_t)rank_];
+            mine.resize(n);
+            check(ctx, ltm_buffer_copy(ctx, mine.data(), dev, n, 1), "ltm_buffer_copy d2h");
+            g_->barrier();
+            // every rank reduces its own slice of the bytes into rank 0's buffer ...
+            const size_t a = n * (size_t)rank_ / (size_t)g_->world, b = n * (size_t)(rank_ + 1) / (size_t)g_->world;
+            uint8_t* out = g_->stage[0].data();
+            for (int r = 1; r < g_->world; ++r) {
+                const uint8_t* in = g_->stage[(size_t)r].data();
+                for (size_t i = a; i < b; ++i) out[i] = std::max(out[i], in[i]);
+            }
+            g_->barrier();
+            // ... and everybody takes the result
+            check(ctx, ltm_buffer_copy(ctx, dev, out, n, 0), "ltm_buffer_copy h2d");
+            g_->barrier();
+        } catch (...) { g_->fail(); throw; }
+    }
+
+    void allGatherU64(ltm_ctx*, uint64_t mine, std::vector<uint64_t>& all) override
+    {
+        try {
+            g_->scalars[(size_t)rank_] = mine;
+            g_->barrier();
+            all = g_->scalars;
+            g_->barrier();
+        } catch (...) { g_->fail(); throw; }
+    }
+
+    void allGatherV(ltm_ctx* ctx, const void* send_dev, size_t send_bytes, void* recv_dev, const std::vector<uint64_t>& bytes) override
+    {
+        try {
+            if ((int)bytes.size() != g_->world || bytes[(size_t)rank_] != send_bytes) throw std::runtime_error("LocalComm::allGatherV: size table does not match");
+            std::vector<uint8_t>& mine = g_->stage[(size_t)rank_];
+            mine.resize(send_bytes);
+            if (send_bytes) check(ctx, ltm_buffer_copy(ctx, mine.data(), send_dev, send_bytes, 1), "ltm_buffer_copy d2h");
+            g_->barrier();
+            size_t at = 0;
+            for (int r = 0; r < g_->world; ++r) {
+                if (bytes[(size_t)r]) check(ctx, ltm_buffer_copy(ctx, static_cast<uint8_t*>(recv_dev) + at, g_->stage[(size_t)r].data(), bytes[(size_t)r], 0), "ltm_buffer_copy h2d");
+                at += bytes[(size_t)r];
+            }
+            g_->barrier();
+        } catch (...) { g_->fail(); throw; }
+    }
+};
+
+} // namespace
+
+std::vector<std::shared_ptr<Comm>> makeLocalComms(int world)
+{
+    if (world < 1) throw std::runtime_error("makeLocalComms: world must be >= 1");
+    auto g = std::make_shared<LocalGroup>(world);
+    std::vector<std::shared_ptr<Comm>> out;
+    for (int r = 0; r < world; ++r) out.push_back(std::make_shared<LocalComm>(g, r));
+    return out;
+}
+
+} // namespace ltremovert

@@ -1,0 +1,107 @@
+// Comm_rccl.cpp -- RcclComm: one rank per GPU of the node, collectives over xGMI (see Comm.h).  The only host file that talks to
+// HIP / RCCL directly; everything else goes through the C ABI.
+#include "removert/Comm.h"
+
+#include <hip/hip_runtime_api.h>
+#include <rccl/rccl.h>
+
+#include <stdexcept>
+#include <string>
+
+namespace ltremovert
+{
+
+namespace
+{
+
+#define LTM_NCCL(expr)                                                                                           \
+    do {                                                                                                         \
+        ncclResult_t r__ = (expr);                                                                               \
+        if (r__ != ncclSuccess) throw std::runtime_error(std::string(#expr) + ": " + ncclGetErrorString(r__));   \
+    } while (0)
+#define LTM_HIPRT(expr)                                                                                          \
+    do {                                                                                                         \
+        hipError_t e__ = (expr);                                                                                 \
+        if (e__ != hipSuccess) throw std::runtime_error(std::string(#expr) + ": " + hipGetErrorString(e__));     \
+    } while (0)
+
+struct RcclGroup
+{
+    std::vector<ncclComm_t> comms;
+    std::vector<int> devs;
+    ~RcclGroup() { for (ncclComm_t c : comms) if (c) ncclCommDestroy(c); }
+};
+
+class RcclComm : public Comm
+{
+    std::shared_ptr<RcclGroup> g_;
+    int rank_;
+    uint64_t* scratch_ = nullptr;      // world uint64 on the device for the size exchange
+
+    ncclComm_t comm() const { return g_->comms[(size_t)rank_]; }
+    static hipStream_t stream(ltm_ctx* ctx) { return static_cast<hipStream_t>(ltm_stream(ctx)); }
+
+public:
+    RcclComm(std::shared_ptr<RcclGroup> g, int r) : g_(std::move(g)), rank_(r) {}
+    ~RcclComm() override { if (scratch_) { (void)hipSetDevice(g_->devs[(size_t)rank_]); (void)hipFree(scratch_); } }
+    int rank() const override { return rank_; }
+    int world() const override { return (int)g_->comms.size(); }
+    const char* backend() const override { return "rccl"; }
+
+    // label union of a vote pass: one all-reduce of M bytes (6.8 MB at M = 6.8 M), on the stream that produced the labels
+    void allReduceMaxU8(ltm_ctx* ctx, void* dev, size_t n) override
+    {
+        if (world() == 1 || n == 0) return;
+        LTM_HIPRT(hipSetDevice(g_->devs[(size_t)rank_]));
+        LTM_NCCL(ncclAllReduce(dev, dev, n, ncclUint8, ncclMax, comm(), stream(ctx)));
+    }
+
+    void allGatherU64(ltm_ctx* ctx, uint64_t mine, std::vector<uint64_t>& all) override
+    {
+        const int w = world();
+        all.assign((size_t)w, mine);
+        if (w == 1) return;
+        LTM_HIPRT(hipSetDevice(g_->devs[(size_t)rank_]));
+        if (!scratch_) LTM_HIPRT(hipMalloc(reinterpret_cast<void**>(&scratch_), sizeof(uint64_t) * (size_t)w));
+        LTM_HIPRT(hipMemcpyAsync(scratch_ + rank_, &mine, sizeof mine, hipMemcpyHostToDevice, stream(ctx)));
+        LTM_NCCL(ncclAllGather(scratch_ + rank_, scratch_, 1, ncclUint64, comm(), stream(ctx)));
+        LTM_HIPRT(hipMemcpyAsync(all.data(), scratch_, sizeof(uint64_t) * (size_t)w, hipMemcpyDeviceToHost, stream(ctx)));
+        LTM_HIPRT(hipStreamSynchronize(stream(ctx)));
+    }
+
+    // all-gather-v as one group of broadcasts (exact sizes, no padding): rank r's piece lands at its offset on every rank.
+    // xGMI is point-to-point; the pieces are a few MB to ~100 MB, so this is latency / link bound and one group per stage.
+    void allGatherV(ltm_ctx* ctx, const void* send_dev, size_t send_bytes, void* recv_dev, const std::vector<uint64_t>& bytes) override
+    {
+        const int w = world();
+        if ((int)bytes.size() != w || bytes[(size_t)rank_] != send_bytes) throw std::runtime_error("RcclComm::allGatherV: size table does not match");
+        LTM_HIPRT(hipSetDevice(g_->devs[(size_t)rank_]));
+        size_t at = 0;
+        LTM_NCCL(ncclGroupStart());
+        for (int r = 0; r < w; ++r) {
+            char* dst = static_cast<char*>(recv_dev) + at;
+            if (bytes[(size_t)r]) LTM_NCCL(ncclBroadcast(r == rank_ ? send_dev : dst, dst, bytes[(size_t)r], ncclChar, r, comm(), stream(ctx)));
+            at += bytes[(size_t)r];
+        }
+        LTM_NCCL(ncclGroupEnd());
+    }
+
+    void barrier() override {}      // every exchange is stream-ordered; the host threads never need to meet
+    void abort() override { for (ncclComm_t c : g_->comms) if (c) (void)ncclCommAbort(c); }
+};
+
+} // namespace
+
+std::vector<std::shared_ptr<Comm>> makeRcclComms(const std::vector<int>& devs)
+{
+    if (devs.empty()) throw std::runtime_error("makeRcclComms: no devices");
+    auto g = std::make_shared<RcclGroup>();
+    g->devs = devs;
+    g->comms.assign(devs.size(), nullptr);
+    LTM_NCCL(ncclCommInitAll(g->comms.data(), (int)devs.size(), devs.data()));
+    std::vector<std::shared_ptr<Comm>> out;
+    for (size_t r = 0; r < devs.size(); ++r) out.push_back(std::make_shared<RcclComm>(g, (int)r));
+    return out;
+}
+
+} // namespace ltremovert

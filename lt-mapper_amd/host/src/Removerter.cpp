@@ -12,11 +12,13 @@
 namespace ltremovert
 {
 
-#define LTM_INFO(msg) (std::cout << "\033[1;32m" << msg << "\033[0m" << std::endl)
+#define LTM_INFO(msg) do { if (!logQuiet()) std::cout << "\033[1;32m" << msg << "\033[0m" << std::endl; } while (0)
 
 static std::shared_ptr<Device> make_device() { RosParamServer p; return std::make_shared<Device>(p); }
 
-Removerter::Removerter() : dev_(make_device()), central_sess_(dev_), query_sess_(dev_)
+Removerter::Removerter() : Removerter(make_device()) {}
+
+Removerter::Removerter(std::shared_ptr<Device> dev) : dev_(std::move(dev)), central_sess_(dev_), query_sess_(dev_)
 {
     // Removerter.cpp:26-50 : output directory protocol
     if (save_pcd_directory_.substr(save_pcd_directory_.size() - 1, 1) != std::string("/")) save_pcd_directory_ = save_pcd_directory_ + "/";
@@ -34,6 +36,7 @@ Removerter::~Removerter() {}
 
 void Removerter::saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout)
 {
+    if (dev_->rank() != 0) return;      // maps are replicated on every rank: rank 0 writes them
     std::string err;
     if (!savePCDFileBinary(file, cloud->download(), octree_layout, &err)) throw std::runtime_error(err);
 }
@@ -79,7 +82,7 @@ void Removerter::makeGlobalMap(void) { makeGlobalMap(central_sess_); makeGlobalM
 std::pair<CloudPtr, CloudPtr> Removerter::votePartition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode)
 {
     ltm_ctx* ctx = tgt.dev_->ctx;
-    if (gpu_viz_every_ > 0 && map->size() > 0) {     // Removerter.cpp:580-585, only when asked for: it serialises the pass
+    if (gpu_viz_every_ > 0 && map->size() > 0 && dev_->world() == 1) {     // Removerter.cpp:580-585, only when asked for: it serialises the pass
         int rows = 0, cols = 0;
         ltm_rimg_size(kVFOV, kHFOV, res, &rows, &cols);
         std::vector<uint8_t> img[4];
@@ -96,8 +99,24 @@ std::pair<CloudPtr, CloudPtr> Removerter::votePartition(const Session& tgt, cons
     }
     ++viz_pass_;
     ltm_cloud kept = 0, flagged = 0;
-    ltmCheck(ctx, ltm_visibility_partition(ctx, map->h, scans->h, src.poses_h_, res, 0.1f, mode, &kept, &flagged, nullptr),
-             "ltm_visibility_partition");
+    if (dev_->world() == 1) {
+        ltmCheck(ctx, ltm_visibility_partition(ctx, map->h, scans->h, src.poses_h_, res, 0.1f, mode, &kept, &flagged, nullptr),
+                 "ltm_visibility_partition");
+        return {tgt.wrap(kept), tgt.wrap(flagged)};
+    }
+    // Multi-GPU (Removerter.cpp:555, the loop over the source keyframes): this rank votes with its block of keyframes into an
+    // M-byte mask, the masks are united by an element-wise MAX across the ranks (the std::set union of :589-590), and every rank
+    // performs the same deterministic index-ascending split -- no broadcast of the result is needed.
+    const size_t M = map->size();
+    void* labels = nullptr;
+    ltmCheck(ctx, ltm_buffer_alloc(ctx, std::max<size_t>(M, 1), &labels), "ltm_buffer_alloc");
+    ltmCheck(ctx, ltm_buffer_fill(ctx, labels, 0, std::max<size_t>(M, 1)), "ltm_buffer_fill");
+    ltm_poses ph = 0; size_t kb = 0, ke = 0;
+    src.stageArgs(scans, &ph, &kb, &ke);
+    if (M) ltmCheck(ctx, ltm_visibility_vote(ctx, map->h, scans->h, ph, kb, ke, res, 0.1f, mode, static_cast<uint8_t*>(labels)), "ltm_visibility_vote");
+    dev_->comm->allReduceMaxU8(ctx, labels, M);
+    ltmCheck(ctx, ltm_partition_by_labels(ctx, map->h, static_cast<const uint8_t*>(labels), &kept, &flagged), "ltm_partition_by_labels");
+    ltmCheck(ctx, ltm_buffer_free(ctx, labels), "ltm_buffer_free");
     return {tgt.wrap(kept), tgt.wrap(flagged)};
 }
 
@@ -336,9 +355,12 @@ void Removerter::saveStrongNDScans(Session& _sess) { saveScans(_sess, _sess.keyf
 
 void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout)   // Removerter.cpp:1637-1650
 {
+    // one file per keyframe: in a multi-GPU run every rank writes the files of its own keyframe block (no gather needed)
+    const size_t first = _scans->shard ? _scans->kb : 0;
+    if (!_scans->shard && dev_->rank() != 0) return;
     const std::vector<Cloud> scans = _scans->download();      // one D2H for the whole scan set
     parallelFor(scans.size(), [&](size_t idx_scan) {           // the files are independent: written from all host cores
-        const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(idx_scan);   // same file name as the input scan
+        const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(first + idx_scan);   // same file name as the input scan
         std::string err;
         if (!savePCDFileBinary(file_name, scans[idx_scan], octree_layout, &err)) throw std::runtime_error(err);
     }, (unsigned)std::max(1, kNumOmpCores));
@@ -511,6 +533,7 @@ bool Removerter::checkFineGrainedWrappers()
 // round-trip precision); the next run uses start_idx 0, end_idx n-1, keyframe_gap 1.
 void Removerter::saveKeyframePoses(const Session& _sess)
 {
+    if (dev_->rank() != 0) return;
     const std::string file = save_pcd_directory_ + "scans_updated_poses.txt";
     std::ofstream o(file);
     o.precision(17);
@@ -546,11 +569,14 @@ void Removerter::run(void)                                                      
     const auto t2 = clk::now();
     saveAllTypeOfScans();
     saveKeyframePoses(central_sess_);
+    ltmCheck(dev_->ctx, ltm_synchronize(dev_->ctx), "ltm_synchronize");
+    if (dev_->comm) dev_->comm->barrier();
     const auto t3 = clk::now();
     auto s = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
     LTM_INFO(" [timing] step0 (load+map) " << s(t0, t1) << " s, steps 1-3 " << s(t1, t2) << " s (includes map PCD writes), scan writes " << s(t2, t3) << " s");
     // files -> files wall time (SURVEY 8d "T_total"), machine readable
-    std::cout << "[timing] T_total " << s(t0, t3) << " s T_step0 " << s(t0, t1) << " s T_steps123 " << s(t1, t2) << " s T_scan_writes " << s(t2, t3)
+    if (dev_->rank() == 0)
+    std::cout << "[timing] ranks " << dev_->world() << " (" << (dev_->comm ? dev_->comm->backend() : "single") << ") T_total " << s(t0, t3) << " s T_step0 " << s(t0, t1) << " s T_steps123 " << s(t1, t2) << " s T_scan_writes " << s(t2, t3)
               << " s keyframes " << central_sess_.keyframe_names_.size() << " " << query_sess_.keyframe_names_.size() << std::endl;
 }
 

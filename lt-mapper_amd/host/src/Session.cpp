@@ -2,7 +2,9 @@
 // keyframe selection, PCD loading) is restated here; every loop over points is a call into libltm_hip.so.
 #include "removert/Session.h"
 
+#include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
@@ -10,10 +12,12 @@
 namespace ltremovert
 {
 
-Device::Device(const RosParamServer& p)
+size_t Session::kVoxelShardMin = getenv("LTM_VOXEL_SHARD_MIN") ? (size_t)atoll(getenv("LTM_VOXEL_SHARD_MIN")) : ((size_t)1 << 18);
+
+Device::Device(const RosParamServer& p, int device_ordinal, std::shared_ptr<Comm> comm_) : comm(std::move(comm_))
 {
     ltm_config cfg{};
-    cfg.vfov = p.kVFOV; cfg.hfov = p.kHFOV; cfg.device = p.gpu_device_; cfg.max_kf_batch = 0;
+    cfg.vfov = p.kVFOV; cfg.hfov = p.kHFOV; cfg.device = device_ordinal >= 0 ? device_ordinal : p.gpu_device_; cfg.max_kf_batch = 0;
     for (int i = 0; i < 16; ++i) cfg.lidar2base[i] = p.kSE3MatExtrinsicLiDARtoPoseBase[i];
     const int rc = ltm_create(&cfg, &ctx);
     if (rc != LTM_OK) throw std::runtime_error("ltm_create failed (" + std::to_string(rc) + "): no usable MI355X device; there is no CPU fallback");
@@ -47,11 +51,16 @@ std::vector<Cloud> ScansH::download() const
 static float alphaOfShape(ltm_ctx* ctx, const std::pair<float, float>& fov, const std::pair<int, int>& shape)
 {
     (void)ctx;
-    const float alpha = (float)shape.first / fov.first;
-    int r = 0, c = 0;
-    ltm_rimg_size(fov.first, fov.second, alpha, &r, &c);
-    if (r != shape.first || c != shape.second) throw std::runtime_error("range image shape is not a resolution of this field of view");
-    return alpha;
+    // any alpha whose rounded products reproduce both dimensions will do (see Removerter.cpp alphaOfShape)
+    const double lo = std::max(((double)shape.first - 0.5) / fov.first, ((double)shape.second - 0.5) / fov.second);
+    const double hi = std::min(((double)shape.first + 0.5) / fov.first, ((double)shape.second + 0.5) / fov.second);
+    const float cand[3] = {(float)(0.5 * (lo + hi)), (float)shape.second / fov.second, (float)shape.first / fov.first};
+    for (float alpha : cand) {
+        int r = 0, c = 0;
+        ltm_rimg_size(fov.first, fov.second, alpha, &r, &c);
+        if (r == shape.first && c == shape.second) return alpha;
+    }
+    throw std::runtime_error("range image shape is not a resolution of this field of view");
 }
 RangeImage map2RangeImg(const CloudPtr& _scan, const std::pair<float, float> _fov, const std::pair<int, int> _rimg_size)
 {
@@ -109,7 +118,7 @@ void Session::loadSessionInfo(std::string _sess_type, std::string _scan_dir, std
     sess_type_ = _sess_type; scan_dir_ = _scan_dir; pose_path_ = _pose_path;
     scan_paths_ = listDirectorySorted(_scan_dir, &scan_names_);
     num_scans_ = (int)scan_paths_.size();
-    std::cout << "\033[1;32m Total : " << num_scans_ << " scans in the directory.\033[0m" << std::endl;
+    if (!logQuiet()) std::cout << "\033[1;32m Total : " << num_scans_ << " scans in the directory.\033[0m" << std::endl;
 
     std::ifstream pose_file_handle(_pose_path);
     if (!pose_file_handle) throw std::runtime_error("cannot open pose file " + _pose_path);
@@ -153,7 +162,7 @@ void Session::parseKeyframes(std::pair<int, int> _range, int _gap)
         keyframe_inverse_poses_.emplace_back(scan_inverse_poses_.at(curr_idx));
         num_valid_parsed++;
     }
-    std::cout << "\033[1;32m Total " << keyframe_paths_.size() << " nodes are used from the index range [" << start_idx << ", " << end_idx << "]"
+    if (!logQuiet()) std::cout << "\033[1;32m Total " << keyframe_paths_.size() << " nodes are used from the index range [" << start_idx << ", " << end_idx << "]"
               << " (every " << _gap << " frames parsed)\033[0m" << std::endl;
 }
 
@@ -184,7 +193,7 @@ void Session::parseKeyframesInROI(const std::vector<Matrix4d>& _roi_poses, int _
         keyframe_inverse_poses_.emplace_back(scan_inverse_poses_.at(curr_idx));
         num_valid_parsed++;
     }
-    std::cout << "\033[1;32m Total " << keyframe_paths_.size() << " keyframes parsed in the map's ROI\033[0m" << std::endl;
+    if (!logQuiet()) std::cout << "\033[1;32m Total " << keyframe_paths_.size() << " keyframes parsed in the map's ROI\033[0m" << std::endl;
 }
 
 void Session::uploadPoses()
@@ -196,13 +205,80 @@ void Session::uploadPoses()
         pi.insert(pi.end(), keyframe_inverse_poses_[k].begin(), keyframe_inverse_poses_[k].end());
     }
     ltmCheck(dev_->ctx, ltm_poses_create(dev_->ctx, keyframe_poses_.size(), p.data(), pi.data(), &poses_h_), "ltm_poses_create");
+    // this rank's block of keyframes (Comm.h shardRange): every per-keyframe loop of the reference runs over it
+    if (poses_local_h_) { ltm_poses_free(dev_->ctx, poses_local_h_); poses_local_h_ = 0; }
+    shardRange(keyframe_poses_.size(), dev_->rank(), dev_->world(), &kf_begin_, &kf_end_);
+    if (dev_->world() > 1)
+        ltmCheck(dev_->ctx, ltm_poses_create(dev_->ctx, kf_end_ - kf_begin_, p.data() + 16 * kf_begin_, pi.data() + 16 * kf_begin_, &poses_local_h_), "ltm_poses_create");
+}
+
+ScansPtr Session::wrap_shard(ltm_scanset h) const
+{
+    ScansPtr s = wrap_scans(h);
+    if (dev_->world() > 1) { s->shard = true; s->kb = kf_begin_; s->n_total = keyframe_poses_.size(); }
+    return s;
+}
+
+void Session::stageArgs(const ScansPtr& scans, ltm_poses* poses, size_t* kb, size_t* ke) const
+{
+    if (scans->shard) {      // a shard holds exactly this rank's keyframes: address it with the local pose slice
+        if (scans->kb != kf_begin_ || scans->numKeyframes() != kf_end_ - kf_begin_) throw std::runtime_error("scan shard and keyframe block disagree");
+        *poses = poses_local_h_; *kb = 0; *ke = kf_end_ - kf_begin_;
+    } else {
+        *poses = poses_h_; *kb = kf_begin_; *ke = kf_end_;
+    }
+}
+
+// all-gather-v of a sharded scan set: keyframe counts and per-keyframe sizes first (host integers), then the points straight into
+// the assembled scan set's device array.  Blocks are contiguous in rank order, so the concatenation is in keyframe order.
+ScansPtr Session::gatherScans(const ScansPtr& scans) const
+{
+    if (!scans->shard) return scans;
+    Comm& comm = *dev_->comm;
+    ltm_ctx* ctx = dev_->ctx;
+    size_t nk = 0, np = 0;
+    ltmCheck(ctx, ltm_scanset_info(ctx, scans->h, &nk, &np), "ltm_scanset_info");
+    std::vector<uint64_t> off(nk + 1);
+    ltmCheck(ctx, ltm_scanset_offsets(ctx, scans->h, off.data()), "ltm_scanset_offsets");
+    // per-keyframe point counts of every rank: one all-gather-v of the count tables
+    std::vector<uint64_t> nks, nps;
+    comm.allGatherU64(ctx, nk, nks);
+    comm.allGatherU64(ctx, np, nps);
+    size_t total_kf = 0;
+    for (uint64_t v : nks) total_kf += v;
+    if (total_kf != scans->n_total) throw std::runtime_error("gatherScans: keyframe blocks do not add up");
+    std::vector<uint64_t> cnt_bytes(nks.size());
+    for (size_t r = 0; r < nks.size(); ++r) cnt_bytes[r] = nks[r] * sizeof(uint64_t);
+    std::vector<uint64_t> my_counts(nk), all_counts(total_kf);
+    for (size_t k = 0; k < nk; ++k) my_counts[k] = off[k + 1] - off[k];
+    void *d_my = nullptr, *d_all = nullptr;
+    ltmCheck(ctx, ltm_buffer_alloc(ctx, std::max<size_t>(nk, 1) * 8, &d_my), "ltm_buffer_alloc");
+    ltmCheck(ctx, ltm_buffer_alloc(ctx, std::max<size_t>(total_kf, 1) * 8, &d_all), "ltm_buffer_alloc");
+    ltmCheck(ctx, ltm_buffer_copy(ctx, d_my, my_counts.data(), nk * 8, 0), "ltm_buffer_copy");
+    comm.allGatherV(ctx, d_my, nk * 8, d_all, cnt_bytes);
+    ltmCheck(ctx, ltm_buffer_copy(ctx, all_counts.data(), d_all, total_kf * 8, 1), "ltm_buffer_copy");
+    ltmCheck(ctx, ltm_buffer_free(ctx, d_my), "ltm_buffer_free");
+    ltmCheck(ctx, ltm_buffer_free(ctx, d_all), "ltm_buffer_free");
+    std::vector<uint64_t> full_off(total_kf + 1, 0);
+    for (size_t k = 0; k < total_kf; ++k) full_off[k + 1] = full_off[k] + all_counts[k];
+    ltm_scanset h = 0;
+    ltmCheck(ctx, ltm_scanset_alloc(ctx, full_off.data(), total_kf, &h), "ltm_scanset_alloc");
+    ScansPtr full = wrap_scans(h);
+    const void *src = nullptr, *dst = nullptr;
+    ltmCheck(ctx, ltm_scanset_device_ptr(ctx, scans->h, &src), "ltm_scanset_device_ptr");
+    ltmCheck(ctx, ltm_scanset_device_ptr(ctx, h, &dst), "ltm_scanset_device_ptr");
+    std::vector<uint64_t> pt_bytes(nps.size());
+    for (size_t r = 0; r < nps.size(); ++r) pt_bytes[r] = nps[r] * sizeof(PointType);
+    comm.allGatherV(ctx, src, np * sizeof(PointType), const_cast<void*>(dst), pt_bytes);
+    ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+    return full;
 }
 
 void Session::loadKeyframes(void)
 {
     const int cout_interval{10};
     int cout_counter{0};
-    std::cout << std::endl << " ... (display every " << cout_interval << " readings) ..." << std::endl;
+    if (!logQuiet()) std::cout << std::endl << " ... (display every " << cout_interval << " readings) ..." << std::endl;
     // PCD decode + per-scan VoxelGrid are independent per keyframe: done on all host cores, concatenated in keyframe order
     std::vector<Cloud> per_kf(keyframe_paths_.size());
     std::vector<size_t> raw_sizes(keyframe_paths_.size(), 0);
@@ -218,7 +294,7 @@ void Session::loadKeyframes(void)
     for (size_t k = 0; k < per_kf.size(); ++k) {
         all.insert(all.end(), per_kf[k].begin(), per_kf[k].end());
         offsets.push_back(all.size());
-        if (++cout_counter % cout_interval == 0)
+        if (++cout_counter % cout_interval == 0 && !logQuiet())
             std::cout << keyframe_paths_[k] << std::endl << "Read a pointcloud with " << raw_sizes[k] << " points (downsampled size: " << per_kf[k].size() << " points)" << std::endl;
         Cloud().swap(per_kf[k]);
     }
@@ -237,14 +313,37 @@ void Session::precleaningKeyframes(float _radius)
 
 CloudPtr Session::mergeScansToGlobal(const ScansPtr& scans) const
 {
+    const ScansPtr whole = gatherScans(scans);          // needs every keyframe: the one place where per-keyframe results are exchanged
     ltm_cloud h = 0;
-    ltmCheck(dev_->ctx, ltm_merge_to_global(dev_->ctx, scans->h, poses_h_, &h), "ltm_merge_to_global");
+    ltmCheck(dev_->ctx, ltm_merge_to_global(dev_->ctx, whole->h, poses_h_, &h), "ltm_merge_to_global");
     return wrap(h);
 }
 CloudPtr Session::octreeDownsampling(const CloudPtr& src, float leaf) const
 {
+    ltm_ctx* ctx = dev_->ctx;
     ltm_cloud h = 0;
-    ltmCheck(dev_->ctx, ltm_voxel_centroid(dev_->ctx, src->h, leaf, &h), "ltm_voxel_centroid");
+    // Multi-GPU: the (replicated) input's Morton key space is cut into `world` contiguous ranges of equal point count; every rank
+    // sorts and reduces its own range and the centroid lists, all-gathered in rank order, ARE the single-GPU output
+    // (ltm_voxel_centroid_shard).  Small clouds stay replicated: the exchange would cost more than the sort.
+    if (dev_->world() > 1 && src->size() >= kVoxelShardMin) {
+        ltm_cloud piece = 0;
+        ltmCheck(ctx, ltm_voxel_centroid_shard(ctx, src->h, leaf, (uint32_t)dev_->rank(), (uint32_t)dev_->world(), &piece), "ltm_voxel_centroid_shard");
+        CloudPtr mine = wrap(piece);
+        const size_t n = mine->size();
+        std::vector<uint64_t> sizes;
+        dev_->comm->allGatherU64(ctx, n, sizes);
+        size_t total = 0;
+        for (uint64_t& v : sizes) { total += v; v *= sizeof(PointType); }
+        ltmCheck(ctx, ltm_cloud_alloc(ctx, total, &h), "ltm_cloud_alloc");
+        CloudPtr out = wrap(h);
+        const void *s = nullptr, *d = nullptr;
+        ltmCheck(ctx, ltm_cloud_device_ptr(ctx, piece, &s), "ltm_cloud_device_ptr");
+        ltmCheck(ctx, ltm_cloud_device_ptr(ctx, h, &d), "ltm_cloud_device_ptr");
+        dev_->comm->allGatherV(ctx, s, n * sizeof(PointType), const_cast<void*>(d), sizes);
+        ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");      // `mine` is released on return
+        return out;
+    }
+    ltmCheck(ctx, ltm_voxel_centroid(ctx, src->h, leaf, &h), "ltm_voxel_centroid");
     return wrap(h);
 }
 CloudPtr Session::concat(const std::vector<CloudPtr>& parts) const
@@ -260,9 +359,9 @@ void Session::mergeScansWithinGlobalCoord(void) { map_global_orig_ = mergeScansT
 
 void Session::parseScansViaProjection(const CloudPtr& _map, ScansPtr& _vec_to_store)
 {
-    ltm_scanset h = 0;
-    ltmCheck(dev_->ctx, ltm_reproject(dev_->ctx, _map->h, poses_h_, 0, keyframe_poses_.size(), kReprojectionAlpha, &h), "ltm_reproject");
-    _vec_to_store = wrap_scans(h);
+    ltm_scanset h = 0;      // Session.cpp:354: the loop over keyframes, here over this rank's block
+    ltmCheck(dev_->ctx, ltm_reproject(dev_->ctx, _map->h, poses_h_, kf_begin_, kf_end_, kReprojectionAlpha, &h), "ltm_reproject");
+    _vec_to_store = wrap_shard(h);
 }
 void Session::parseStaticScansViaProjection(void) { parseScansViaProjection(map_global_curr_, keyframe_scans_static_projected_); }
 void Session::parseUpdatedStaticScansViaProjection(void) { parseScansViaProjection(map_global_updated_, keyframe_scans_updated_); }
@@ -278,12 +377,15 @@ void Session::updateScansScanwise()
     ltmCheck(dev_->ctx, ltm_scanset_zip_concat(dev_->ctx, keyframe_scans_updated_->h, keyframe_scans_weak_nd_->h, keyframe_scans_pd_->h, &merged), "ltm_scanset_zip_concat");
     ScansPtr guard = wrap_scans(merged);
     ltmCheck(dev_->ctx, ltm_voxel_centroid_scanset(dev_->ctx, merged, 0.05f, &voxelised), "ltm_voxel_centroid_scanset");
-    keyframe_scans_updated_ = wrap_scans(voxelised);
+    // the three operands come from reprojections of the same keyframe block, so on a multi-GPU run this is shard-local
+    const bool shard = keyframe_scans_updated_->shard;
+    keyframe_scans_updated_ = shard ? wrap_shard(voxelised) : wrap_scans(voxelised);
 }
 
 static std::pair<CloudPtr, CloudPtr> knnOneScan(const Session& s, const CloudPtr& target, const ScansPtr& scans, int idx)
 {
     if (!target) throw std::runtime_error("no kNN target map yet: call extract*ViaKnnDiff first");
+    if (scans->shard) throw std::runtime_error("the per-scan kNN wrappers address whole scan sets (single-GPU runs)");
     ltm_scanset co = 0, di = 0;
     ltmCheck(s.dev_->ctx, ltm_knn_partition(s.dev_->ctx, target->h, scans->h, s.poses_h_, (size_t)idx, (size_t)idx + 1, s.kNumKnnPointsToCompare,
                                             s.kScanKnnAndMapKnnAvgDiffThreshold, &co, &di), "ltm_knn_partition");
@@ -301,18 +403,22 @@ void Session::extractLowDynPointsViaKnnDiff(const CloudPtr& _target_map)
     knn_target_map_ = _target_map;
     // Session.cpp:395-402 build a 0.4 m octree for an ICP that is disabled (useICPrefinement{false}); no observable effect, not run
     ltm_scanset co = 0, di = 0;
-    ltmCheck(dev_->ctx, ltm_knn_partition(dev_->ctx, _target_map->h, keyframe_scans_static_projected_->h, poses_h_, 0, keyframe_poses_.size(),
+    ltm_poses ph = 0; size_t kb = 0, ke = 0;      // Session.cpp:408: the OpenMP loop over keyframes, here over this rank's block
+    stageArgs(keyframe_scans_static_projected_, &ph, &kb, &ke);
+    ltmCheck(dev_->ctx, ltm_knn_partition(dev_->ctx, _target_map->h, keyframe_scans_static_projected_->h, ph, kb, ke,
                                           kNumKnnPointsToCompare, kScanKnnAndMapKnnAvgDiffThreshold, &co, &di), "ltm_knn_partition");
-    scans_knn_coexist_ = wrap_scans(co); scans_knn_diff_ = wrap_scans(di);
+    scans_knn_coexist_ = wrap_shard(co); scans_knn_diff_ = wrap_shard(di);
 }
 
 void Session::extractHighDynPointsViaKnnDiff(const CloudPtr& _target_map)
 {
     knn_target_map_ = _target_map;
     ltm_scanset di = 0;
-    ltmCheck(dev_->ctx, ltm_knn_partition(dev_->ctx, _target_map->h, keyframe_scans_->h, poses_h_, 0, keyframe_poses_.size(),
+    ltm_poses ph = 0; size_t kb = 0, ke = 0;      // Session.cpp:491
+    stageArgs(keyframe_scans_, &ph, &kb, &ke);
+    ltmCheck(dev_->ctx, ltm_knn_partition(dev_->ctx, _target_map->h, keyframe_scans_->h, ph, kb, ke,
                                           kNumKnnPointsToCompare, kScanKnnAndMapKnnAvgDiffThreshold, nullptr, &di), "ltm_knn_partition");
-    keyframe_scans_dynamic_ = wrap_scans(di);
+    keyframe_scans_dynamic_ = wrap_shard(di);
 }
 
 void Session::constructGlobalNDMap() { map_global_nd_ = octreeDownsampling(mergeScansToGlobal(scans_knn_diff_), 0.05f); }

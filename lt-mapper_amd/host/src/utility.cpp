@@ -250,6 +250,8 @@ bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_
     return true;
 }
 
+bool& logQuiet() { thread_local bool quiet = false; return quiet; }
+
 // pcl::VoxelGrid::applyFilter (PCL 1.10, from its published behaviour): inverse leaf in float, bounding box from
 // getMinMax3D, dx*dy*dz > INT32_MAX => "Leaf size is too small" and output = input; else centroids ordered by linear
 // voxel index.  The reference sorts (voxel, point) pairs with an unstable std::sort, so the summation order inside a
