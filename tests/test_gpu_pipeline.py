@@ -135,23 +135,24 @@ def _two_rank_worker(rank, world, port, q, C, Q):
     ctx.close()
 
 
-def test_sharded_ops_two_ranks_sharing_the_gpu(orc, small_pair):
-    """world_size 2 with the real HIP stages (keyframe shards, label union, rank-local scan sets, sharded voxel grids):
-    both ranks must end with the single-GPU (= oracle) result.  Collectives are staged through the host over gloo because
-    the test box has one GPU."""
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_ops_logical_ranks_sharing_the_gpu(orc, small_pair, world):
+    """world_size 2 / 4 with the real HIP stages (keyframe shards, label
+    union, rank-local scan sets, sharded voxel grids): every rank must end with the single-GPU (= oracle) result.  Collectives are
+    staged through the host over gloo because the test box has one GPU."""
     import socket
     import torch.multiprocessing as mp
     C, Q = small_pair
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     mpc = mp.get_context("spawn")
     q = mpc.Queue()
-    procs = [mpc.Process(target=_two_rank_worker, args=(r, 2, port, q, C, Q)) for r in range(2)]
+    procs = [mpc.Process(target=_two_rank_worker, args=(r, world, port, q, C, Q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
     import time
-    results, deadline = [], time.time() + 240
-    while len(results) < 2:
+    results, deadline = [], time.time() + 400
+    while len(results) < world:
         try:
             results.append(q.get(timeout=2))
         except queue.Empty:
