@@ -114,6 +114,28 @@ int ltm_buffer_free(ltm_ctx*, void* dev);
 int ltm_buffer_fill(ltm_ctx*, void* dev, int byte_value, size_t bytes);            /* asynchronous on the context's stream */
 int ltm_buffer_copy(ltm_ctx*, void* dst, const void* src, size_t bytes, int kind);
 
+/* --------------------------------------------- pipelined feeder / asynchronous fetch ---- */
+/* f-1 (Session.cpp:266-302): a scan set assembled from chunks of consecutive keyframes WHILE the host is still
+ * decoding the next files.  Each chunk is staged through one of two pinned buffers and copied on a dedicated copy stream, so the
+ * host-side packing of chunk i+1 overlaps the DMA of chunk i (and both overlap the decode threads).  capacity_points is an upper
+ * bound of the total (the POINTS fields of the PCD headers).  ltm_scanset_upload_chunk returns as soon as `pts` may be reused. */
+typedef uint64_t ltm_upload;
+int ltm_scanset_upload_begin(ltm_ctx*, size_t capacity_points, ltm_upload* up);
+int ltm_scanset_upload_chunk(ltm_ctx*, ltm_upload up, const void* pts, size_t stride_bytes, const uint64_t* kf_sizes, size_t n_kf);
+int ltm_scanset_upload_end(ltm_ctx*, ltm_upload up, ltm_scanset* out);
+
+/* f-2 (Removerter.cpp:1637-1650, 1446-1520): asynchronous device->host fetch for the output writer.  *_fetch_begin enqueues the
+ * copy of the cloud / scan set as it is after everything already submitted to the context, on the copy stream, into a pinned host
+ * buffer owned by the library; the context keeps computing.  ltm_fetch_wait blocks until that copy has completed and may be
+ * called from ANY host thread (writer threads) -- it touches only the ticket.  The points are packed XYZI (16 B); for a scan set
+ * `offsets` (n_kf + 1 entries, owned by the ticket) delimit the keyframes.  The source handle must stay alive until the wait has
+ * returned; ltm_fetch_release (context thread) recycles the pinned buffer. */
+typedef struct ltm_fetch ltm_fetch;
+int ltm_cloud_fetch_begin(ltm_ctx*, ltm_cloud, ltm_fetch** out);
+int ltm_scanset_fetch_begin(ltm_ctx*, ltm_scanset, ltm_fetch** out);
+int ltm_fetch_wait(ltm_fetch*, const void** host_xyzi, size_t* n_points, const uint64_t** offsets, size_t* n_kf);
+int ltm_fetch_release(ltm_ctx*, ltm_fetch*);
+
 /* -------------------------------------------------------------------- poses ---- */
 /* keyframe_poses_ / keyframe_inverse_poses_ (Session.cpp:102-114).  inv may be NULL: then the
  * inverse is computed in double by cofactor expansion (the reference uses Eigen's inverse()). */

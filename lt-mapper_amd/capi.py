@@ -53,6 +53,13 @@ SIGNATURES = {
     "ltm_cloud_free": (_i, [_vp, _u64]),
     "ltm_cloud_alloc": (_i, [_vp, _sz, _pu64]),
     "ltm_scanset_alloc": (_i, [_vp, _pu64, _sz, _pu64]),
+    "ltm_scanset_upload_begin": (_i, [_vp, _sz, _pu64]),
+    "ltm_scanset_upload_chunk": (_i, [_vp, _u64, _vp, _sz, _pu64, _sz]),
+    "ltm_scanset_upload_end": (_i, [_vp, _u64, _pu64]),
+    "ltm_cloud_fetch_begin": (_i, [_vp, _u64, C.POINTER(_vp)]),
+    "ltm_scanset_fetch_begin": (_i, [_vp, _u64, C.POINTER(_vp)]),
+    "ltm_fetch_wait": (_i, [_vp, C.POINTER(_vp), _psz, C.POINTER(_pu64), _psz]),
+    "ltm_fetch_release": (_i, [_vp, _vp]),
     "ltm_buffer_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "ltm_buffer_free": (_i, [_vp, _vp]),
     "ltm_buffer_fill": (_i, [_vp, _vp, _i, _sz]),

@@ -101,8 +101,14 @@ struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes
 // resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
 struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; float* qbound; float q_thr; };
 struct Pending { int cls; hipEvent_t a, b; };
+struct PinnedBlock { void* p; size_t bytes; bool in_use; };
+// pipelined scan-set upload: device array of `cap` points filled front to back, two pinned staging buffers in flight
+struct UploadState { float4* d = nullptr; size_t cap = 0, n = 0; std::vector<uint64_t> off{0}; void* stage[2] = {nullptr, nullptr}; size_t stage_sz[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int next = 0; };
 
 } // namespace
+
+// ticket of an asynchronous device->host fetch (include/ltm.h)
+struct ltm_fetch { void* host = nullptr; size_t bytes = 0, n_points = 0; std::vector<uint64_t> off; hipEvent_t done = nullptr; int device = 0; };
 
 struct ltm_ctx {
     ltm_config cfg;
@@ -129,6 +135,10 @@ struct ltm_ctx {
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
     int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
+    // copy engine side (pipelined loader / asynchronous output fetch): its own stream, pinned staging memory
+    hipStream_t copy_stream = nullptr;
+    std::vector<PinnedBlock> pinned;
+    std::unordered_map<uint64_t, UploadState> uploads;
 };
 
 namespace {
@@ -706,6 +716,37 @@ void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n,
     }
 }
 
+hipStream_t copy_stream(ltm_ctx* c)
+{
+    if (!c->copy_stream) LTM_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    return c->copy_stream;
+}
+void* pinned_alloc(ltm_ctx* c, size_t bytes)
+{
+    if (bytes == 0) bytes = 16;
+    int best = -1;
+    for (size_t i = 0; i < c->pinned.size(); ++i)
+        if (!c->pinned[i].in_use && c->pinned[i].bytes >= bytes && (best < 0 || c->pinned[i].bytes < c->pinned[(size_t)best].bytes)) best = (int)i;
+    if (best >= 0 && c->pinned[(size_t)best].bytes <= 2 * bytes + (1u << 20)) { c->pinned[(size_t)best].in_use = true; return c->pinned[(size_t)best].p; }
+    void* p = nullptr;
+    const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) throw Err{LTM_E_NOMEM, "hipHostMalloc of " + std::to_string(want) + " bytes failed"};
+    c->pinned.push_back(PinnedBlock{p, want, true});
+    return p;
+}
+void pinned_free(ltm_ctx* c, void* p)
+{
+    for (PinnedBlock& b : c->pinned) if (b.p == p) { b.in_use = false; return; }
+}
+// compute stream -> copy stream ordering: everything submitted so far on the context's stream happens before later copy-stream work
+void copy_after_compute(ltm_ctx* c)
+{
+    hipEvent_t e = get_event(c);
+    LTM_HIP(hipEventRecord(e, c->stream));
+    LTM_HIP(hipStreamWaitEvent(copy_stream(c), e, 0));
+    c->event_pool.push_back(e);      // safe to reuse: the wait has captured the recorded state
+}
+
 template <class F>
 int guarded(ltm_ctx* c, F&& f)
 {
@@ -789,6 +830,9 @@ void ltm_destroy(ltm_ctx* c)
     (void)hipStreamSynchronize(c->stream);
     for (Pending& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
+    if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
+    for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
+    for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     c->pool.release_all();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1075,6 +1119,111 @@ int ltm_scanset_alloc(ltm_ctx* c, const uint64_t* off, size_t n_kf, ltm_scanset*
 int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
 {
     return guarded(c, [&] { ScanSet& s = get_ss(c, h); scan_cache_drop(c, h); c->pool.free(s.d); c->pool.free(s.off_dev); c->scansets.erase(h); });
+}
+
+// ------------------------------------------------------------------ pipelined upload / async fetch
+int ltm_scanset_upload_begin(ltm_ctx* c, size_t capacity_points, ltm_upload* up)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(up, "null argument");
+        UploadState u;
+        u.cap = capacity_points;
+        u.d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(capacity_points, 1) * 16));
+        (void)copy_stream(c);
+        const uint64_t h = c->next_handle++;
+        c->uploads[h] = std::move(u);
+        *up = h;
+    });
+}
+
+int ltm_scanset_upload_chunk(ltm_ctx* c, ltm_upload up, const void* pts, size_t stride, const uint64_t* kf_sizes, size_t n_kf)
+{
+    return guarded(c, [&] {
+        auto it = c->uploads.find(up);
+        LTM_REQUIRE(it != c->uploads.end(), "invalid upload handle");
+        UploadState& u = it->second;
+        LTM_REQUIRE(kf_sizes || n_kf == 0, "null keyframe sizes");
+        size_t n = 0;
+        for (size_t k = 0; k < n_kf; ++k) n += kf_sizes[k];
+        LTM_REQUIRE(pts || n == 0, "null points");
+        LTM_REQUIRE(stride == 16 || stride >= 32 || n == 0, "stride must be 16 or >= 32");
+        LTM_REQUIRE(u.n + n <= u.cap, "upload exceeds the announced capacity");
+        if (n) {
+            const int b = u.next;
+            u.next ^= 1;
+            if (u.busy[b]) { LTM_HIP(hipEventSynchronize(u.ev[b])); u.busy[b] = false; }      // its previous DMA must have drained
+            if (u.stage_sz[b] < n * 16) {
+                if (u.stage[b]) pinned_free(c, u.stage[b]);
+                u.stage[b] = pinned_alloc(c, n * 16);
+                u.stage_sz[b] = n * 16;
+            }
+            if (stride == 16) memcpy(u.stage[b], pts, n * 16);
+            else {
+                const unsigned char* s = static_cast<const unsigned char*>(pts);
+                float* o = static_cast<float*>(u.stage[b]);
+                for (size_t i = 0; i < n; ++i) { memcpy(o + 4 * i, s + i * stride, 12); memcpy(o + 4 * i + 3, s + i * stride + 16, 4); }
+            }
+            if (!u.ev[b]) LTM_HIP(hipEventCreateWithFlags(&u.ev[b], hipEventDisableTiming));
+            LTM_HIP(hipMemcpyAsync(u.d + u.n, u.stage[b], n * 16, hipMemcpyHostToDevice, copy_stream(c)));
+            LTM_HIP(hipEventRecord(u.ev[b], copy_stream(c)));
+            u.busy[b] = true;
+        }
+        for (size_t k = 0; k < n_kf; ++k) { u.n += kf_sizes[k]; u.off.push_back(u.n); }
+    });
+}
+
+int ltm_scanset_upload_end(ltm_ctx* c, ltm_upload up, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        auto it = c->uploads.find(up);
+        LTM_REQUIRE(it != c->uploads.end(), "invalid upload handle");
+        UploadState u = std::move(it->second);
+        c->uploads.erase(it);
+        LTM_HIP(hipStreamSynchronize(copy_stream(c)));
+        for (int b = 0; b < 2; ++b) { if (u.ev[b]) (void)hipEventDestroy(u.ev[b]); if (u.stage[b]) pinned_free(c, u.stage[b]); }
+        *out = new_scanset(c, u.d, std::move(u.off));
+    });
+}
+
+static void fetch_begin(ltm_ctx* c, const float4* src, size_t n, std::vector<uint64_t> off, ltm_fetch** out)
+{
+    std::unique_ptr<ltm_fetch> t(new ltm_fetch());
+    t->n_points = n; t->bytes = n * 16; t->off = std::move(off); t->device = c->device;
+    t->host = pinned_alloc(c, t->bytes);
+    LTM_HIP(hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
+    copy_after_compute(c);
+    if (n) LTM_HIP(hipMemcpyAsync(t->host, src, t->bytes, hipMemcpyDeviceToHost, copy_stream(c)));
+    LTM_HIP(hipEventRecord(t->done, copy_stream(c)));
+    *out = t.release();
+}
+int ltm_cloud_fetch_begin(ltm_ctx* c, ltm_cloud h, ltm_fetch** out)
+{
+    return guarded(c, [&] { LTM_REQUIRE(out, "null argument"); const Cloud cl = get_cloud(c, h); fetch_begin(c, cl.d, cl.n, {}, out); });
+}
+int ltm_scanset_fetch_begin(ltm_ctx* c, ltm_scanset h, ltm_fetch** out)
+{
+    return guarded(c, [&] { LTM_REQUIRE(out, "null argument"); const ScanSet& s = get_ss(c, h); fetch_begin(c, s.d, s.n_pts, s.off, out); });
+}
+int ltm_fetch_wait(ltm_fetch* t, const void** host_xyzi, size_t* n_points, const uint64_t** offsets, size_t* n_kf)
+{
+    if (!t) return LTM_E_INVALID;
+    if (hipEventSynchronize(t->done) != hipSuccess) return LTM_E_DEVICE;      // thread-safe: touches only this ticket's event
+    if (host_xyzi) *host_xyzi = t->host;
+    if (n_points) *n_points = t->n_points;
+    if (offsets) *offsets = t->off.empty() ? nullptr : t->off.data();
+    if (n_kf) *n_kf = t->off.empty() ? 0 : t->off.size() - 1;
+    return LTM_OK;
+}
+int ltm_fetch_release(ltm_ctx* c, ltm_fetch* t)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(t, "null ticket");
+        (void)hipEventSynchronize(t->done);
+        (void)hipEventDestroy(t->done);
+        pinned_free(c, t->host);
+        delete t;
+    });
 }
 
 // -------------------------------------------------------------------------------- poses

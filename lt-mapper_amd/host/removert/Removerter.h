@@ -31,6 +31,11 @@ private:
     void saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout = true);
     std::pair<CloudPtr, CloudPtr> votePartition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode);
     int viz_pass_ = 0;
+    // background output writer: fetch tickets in flight + the handles that must outlive them
+    struct PendingFetch { ltm_fetch* ticket; CloudPtr cloud; ScansPtr scans; };
+    std::unique_ptr<AsyncWriter> writer_;
+    std::vector<PendingFetch> fetches_;
+    void finishOutputs();      // waits for every queued file, releases the tickets
 
 public:
     Removerter();

@@ -49,5 +49,6 @@ public:
     bool gpu_use_self_removert_;   // removert/gpu_use_self_removert: run selfRemovert() (commented out at Removerter.cpp:1582,1586)
     bool gpu_skip_hd_knn_;         // removert/gpu_skip_hd_knn: skip the visualisation-only HD kNN stage
     int gpu_device_;               // removert/gpu_device
+    bool gpu_async_io_;            // removert/gpu_async_io (default true): pipelined loader (decode || H2D) and background output writer; false = the synchronous path
     int gpu_viz_every_;            // removert/gpu_viz_every: >0 = emit the four RViz images (Removerter.cpp:580-585) of every N-th source keyframe of each vote pass
 };

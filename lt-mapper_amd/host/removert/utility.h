@@ -40,16 +40,34 @@ bool loadPCDFile(const std::string& path, Cloud& out, std::string* err = nullptr
 // byte-compatible with pcl::io::savePCDFileBinary for PointXYZI.  `octree_layout`: the reference's clouds that come
 // out of octreeDownsampling carry width=1,height=n (utility.cpp:217-218); everything else is width=n,height=1.
 bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_layout, std::string* err = nullptr);
+bool savePCDFileBinary(const std::string& path, const PointType* pts, size_t n, bool octree_layout, std::string* err = nullptr);
+// POINTS of a PCD header without touching the payload (the pipelined loader sizes its device array from these)
+bool readPCDPointCount(const std::string& path, size_t* n_points, std::string* err = nullptr);
 
 // pcl::VoxelGrid as used by Session::loadKeyframes (Session.cpp:284-289), including the int32 overflow early-out
 // (output = input) that PCL takes for large extents.  Points inside a voxel are summed in input order.
 void voxelGridFilter(const Cloud& in, float leaf, Cloud& out);
+void voxelGridFilter(Cloud&& in, float leaf, Cloud& out);      // the early-out hands the input over instead of copying it
 
 // runs f(i) for i in [0, n) on up to `threads` host threads (0 = hardware concurrency); exceptions are re-thrown on the caller
 void parallelFor(size_t n, const std::function<void(size_t)>& f, unsigned threads = 0);
 
 void fsmkdir(const std::string& _path);    // Removerter.cpp:6-10
 std::vector<std::string> listDirectorySorted(const std::string& dir, std::vector<std::string>* names);
+
+// Background writer of the output protocol (Removerter.cpp:1637-1650, 1446-1520): a pool of host threads that
+// wait for an asynchronous device->host fetch (ltm_fetch_wait) and write the PCD files while the GPU keeps computing.
+class AsyncWriter
+{
+public:
+    explicit AsyncWriter(unsigned threads);
+    ~AsyncWriter();
+    void submit(std::function<void()> task);
+    void drain();                     // returns when every submitted task has run; re-throws the first task error
+private:
+    struct Impl;
+    Impl* impl_;
+};
 
 // per-thread switch: ranks other than 0 of a multi-GPU run keep quiet (their logs would only repeat rank 0's)
 bool& logQuiet();

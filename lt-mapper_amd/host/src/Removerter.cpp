@@ -34,9 +34,33 @@ Removerter::Removerter(std::shared_ptr<Device> dev) : dev_(std::move(dev)), cent
 
 Removerter::~Removerter() {}
 
+void Removerter::finishOutputs()
+{
+    if (!writer_) return;
+    std::exception_ptr e;
+    try { writer_->drain(); } catch (...) { e = std::current_exception(); }
+    for (PendingFetch& f : fetches_) (void)ltm_fetch_release(dev_->ctx, f.ticket);
+    fetches_.clear();
+    if (e) std::rethrow_exception(e);
+}
+
 void Removerter::saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout)
 {
     if (dev_->rank() != 0) return;      // maps are replicated on every rank: rank 0 writes them
+    if (gpu_async_io_) {
+        // D2H on the copy stream into pinned memory + the file write on a writer thread; the GPU goes on with the next stage
+        if (!writer_) writer_.reset(new AsyncWriter((unsigned)std::max(1, kNumOmpCores)));
+        ltm_fetch* t = nullptr;
+        ltmCheck(dev_->ctx, ltm_cloud_fetch_begin(dev_->ctx, cloud->h, &t), "ltm_cloud_fetch_begin");
+        fetches_.push_back(PendingFetch{t, cloud, nullptr});
+        writer_->submit([t, file, octree_layout] {
+            const void* pts = nullptr; size_t n = 0;
+            if (ltm_fetch_wait(t, &pts, &n, nullptr, nullptr) != LTM_OK) throw std::runtime_error("ltm_fetch_wait failed for " + file);
+            std::string err;
+            if (!savePCDFileBinary(file, static_cast<const PointType*>(pts), n, octree_layout, &err)) throw std::runtime_error(err);
+        });
+        return;
+    }
     std::string err;
     if (!savePCDFileBinary(file, cloud->download(), octree_layout, &err)) throw std::runtime_error(err);
 }
@@ -358,6 +382,26 @@ void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _
     // one file per keyframe: in a multi-GPU run every rank writes the files of its own keyframe block (no gather needed)
     const size_t first = _scans->shard ? _scans->kb : 0;
     if (!_scans->shard && dev_->rank() != 0) return;
+    if (gpu_async_io_) {
+        // one asynchronous D2H of the whole scan set; every file is its own writer task on a slice of the pinned buffer
+        if (!writer_) writer_.reset(new AsyncWriter((unsigned)std::max(1, kNumOmpCores)));
+        ltm_fetch* t = nullptr;
+        ltmCheck(dev_->ctx, ltm_scanset_fetch_begin(dev_->ctx, _scans->h, &t), "ltm_scanset_fetch_begin");
+        fetches_.push_back(PendingFetch{t, nullptr, _scans});
+        const size_t nk = _scans->numKeyframes();
+        for (size_t idx_scan = 0; idx_scan < nk; ++idx_scan) {
+            const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(first + idx_scan);
+            writer_->submit([t, file_name, idx_scan, octree_layout] {
+                const void* pts = nullptr; size_t n = 0; const uint64_t* off = nullptr; size_t n_kf = 0;
+                if (ltm_fetch_wait(t, &pts, &n, &off, &n_kf) != LTM_OK || idx_scan >= n_kf) throw std::runtime_error("ltm_fetch_wait failed for " + file_name);
+                std::string err;
+                if (!savePCDFileBinary(file_name, static_cast<const PointType*>(pts) + off[idx_scan], (size_t)(off[idx_scan + 1] - off[idx_scan]), octree_layout, &err))
+                    throw std::runtime_error(err);
+            });
+        }
+        LTM_INFO(" " << nk << " scans queued for " << _save_dir);
+        return;
+    }
     const std::vector<Cloud> scans = _scans->download();      // one D2H for the whole scan set
     parallelFor(scans.size(), [&](size_t idx_scan) {           // the files are independent: written from all host cores
         const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(first + idx_scan);   // same file name as the input scan
@@ -565,9 +609,16 @@ void Removerter::run(void)                                                      
     updateCurrentMap();
     parseUpdatedStaticScansViaProjection();
     parseLDScansViaProjection();
+    if (gpu_async_io_) {      // four of the five per-keyframe outputs are final here: their fetch + writes overlap the last stage
+        saveScans(central_sess_, central_sess_.keyframe_scans_updated_strong_, updated_strong_scans_save_dir_, false);
+        saveLDScans(central_sess_);
+    }
     updateScansScanwise();
+    ltmCheck(dev_->ctx, ltm_synchronize(dev_->ctx), "ltm_synchronize");
     const auto t2 = clk::now();
-    saveAllTypeOfScans();
+    if (gpu_async_io_) saveScans(central_sess_, central_sess_.keyframe_scans_updated_, updated_scans_save_dir_, true);
+    else saveAllTypeOfScans();
+    finishOutputs();
     saveKeyframePoses(central_sess_);
     ltmCheck(dev_->ctx, ltm_synchronize(dev_->ctx), "ltm_synchronize");
     if (dev_->comm) dev_->comm->barrier();

@@ -137,5 +137,6 @@ RosParamServer::RosParamServer()
     gpu_use_self_removert_ = getb("gpu_use_self_removert", false);
     gpu_skip_hd_knn_ = getb("gpu_skip_hd_knn", false);
     gpu_device_ = geti("gpu_device", 0);
+    gpu_async_io_ = getb("gpu_async_io", true);
     gpu_viz_every_ = geti("gpu_viz_every", 0);
 }

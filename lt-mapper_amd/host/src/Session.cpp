@@ -7,7 +7,11 @@
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
+#include <atomic>
+#include <condition_variable>
+#include <mutex>
 #include <stdexcept>
+#include <thread>
 
 namespace ltremovert
 {
@@ -277,29 +281,76 @@ ScansPtr Session::gatherScans(const ScansPtr& scans) const
 void Session::loadKeyframes(void)
 {
     const int cout_interval{10};
-    int cout_counter{0};
     if (!logQuiet()) std::cout << std::endl << " ... (display every " << cout_interval << " readings) ..." << std::endl;
-    // PCD decode + per-scan VoxelGrid are independent per keyframe: done on all host cores, concatenated in keyframe order
-    std::vector<Cloud> per_kf(keyframe_paths_.size());
-    std::vector<size_t> raw_sizes(keyframe_paths_.size(), 0);
-    parallelFor(keyframe_paths_.size(), [&](size_t k) {
+    const size_t n_kf = keyframe_paths_.size();
+    const unsigned n_threads = (unsigned)std::max(1, kNumOmpCores);
+    std::vector<Cloud> per_kf(n_kf);
+    std::vector<size_t> raw_sizes(n_kf, 0);
+    auto decode = [&](size_t k) {          // Session.cpp:272-292: loadPCDFile + per-scan pcl::VoxelGrid
         Cloud points;
         std::string err;
         if (!loadPCDFile(keyframe_paths_[k], points, &err)) throw std::runtime_error(err);
         raw_sizes[k] = points.size();
-        voxelGridFilter(points, kDownsampleVoxelSize, per_kf[k]);
-    }, (unsigned)std::max(1, kNumOmpCores));
-    Cloud all;
-    std::vector<uint64_t> offsets(1, 0);
-    for (size_t k = 0; k < per_kf.size(); ++k) {
-        all.insert(all.end(), per_kf[k].begin(), per_kf[k].end());
-        offsets.push_back(all.size());
-        if (++cout_counter % cout_interval == 0 && !logQuiet())
+        voxelGridFilter(std::move(points), kDownsampleVoxelSize, per_kf[k]);
+    };
+    auto report = [&](size_t k) {
+        if ((k + 1) % cout_interval == 0 && !logQuiet())
             std::cout << keyframe_paths_[k] << std::endl << "Read a pointcloud with " << raw_sizes[k] << " points (downsampled size: " << per_kf[k].size() << " points)" << std::endl;
-        Cloud().swap(per_kf[k]);
-    }
+    };
     ltm_scanset h = 0;
-    ltmCheck(dev_->ctx, ltm_scanset_upload(dev_->ctx, all.data(), sizeof(PointType), offsets.data(), offsets.size() - 1, &h), "ltm_scanset_upload");
+    if (!gpu_async_io_) {
+        // synchronous path: decode everything (on all host cores), concatenate in keyframe order, one upload
+        parallelFor(n_kf, decode, n_threads);
+        Cloud all;
+        std::vector<uint64_t> offsets(1, 0);
+        for (size_t k = 0; k < n_kf; ++k) {
+            all.insert(all.end(), per_kf[k].begin(), per_kf[k].end());
+            offsets.push_back(all.size());
+            report(k);
+            Cloud().swap(per_kf[k]);
+        }
+        ltmCheck(dev_->ctx, ltm_scanset_upload(dev_->ctx, all.data(), sizeof(PointType), offsets.data(), offsets.size() - 1, &h), "ltm_scanset_upload");
+    } else {
+        // Pipelined feeder: decode threads fill per_kf[] in any order; this thread hands every keyframe to the device as
+        // soon as it AND all earlier ones are ready -- pinned double buffering on the copy stream, so PCD decode, the per-scan
+        // VoxelGrid, host packing and the H2D DMA overlap.  The device array is sized from the PCD headers (VoxelGrid never grows a scan).
+        std::vector<size_t> header_pts(n_kf, 0);
+        parallelFor(n_kf, [&](size_t k) { std::string err; if (!readPCDPointCount(keyframe_paths_[k], &header_pts[k], &err)) throw std::runtime_error(err); }, n_threads);
+        size_t capacity = 0;
+        for (size_t v : header_pts) capacity += v;
+        ltm_upload up = 0;
+        ltmCheck(dev_->ctx, ltm_scanset_upload_begin(dev_->ctx, capacity, &up), "ltm_scanset_upload_begin");
+        std::vector<char> done(n_kf, 0);
+        std::mutex m;
+        std::condition_variable cv;
+        std::exception_ptr err;
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < std::min<size_t>(n_threads, std::max<size_t>(n_kf, 1)); ++t)
+            pool.emplace_back([&] {
+                for (size_t k = next++; k < n_kf; k = next++) {
+                    try { decode(k); } catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); next = n_kf; }
+                    { std::lock_guard<std::mutex> g(m); done[k] = 1; }
+                    cv.notify_all();
+                }
+            });
+        try {
+            for (size_t k = 0; k < n_kf; ++k) {
+                {
+                    std::unique_lock<std::mutex> lk(m);
+                    cv.wait(lk, [&] { return done[k] || err; });
+                    if (err) break;
+                }
+                const uint64_t n = per_kf[k].size();
+                ltmCheck(dev_->ctx, ltm_scanset_upload_chunk(dev_->ctx, up, per_kf[k].data(), sizeof(PointType), &n, 1), "ltm_scanset_upload_chunk");
+                report(k);
+                Cloud().swap(per_kf[k]);
+            }
+        } catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); next = n_kf; }
+        for (auto& th : pool) th.join();
+        if (err) { ltm_scanset tmp = 0; (void)ltm_scanset_upload_end(dev_->ctx, up, &tmp); if (tmp) (void)ltm_scanset_free(dev_->ctx, tmp); std::rethrow_exception(err); }
+        ltmCheck(dev_->ctx, ltm_scanset_upload_end(dev_->ctx, up, &h), "ltm_scanset_upload_end");
+    }
     keyframe_scans_ = wrap_scans(h);
     uploadPoses();
 }

@@ -4,6 +4,8 @@
 
 #include <algorithm>
 #include <atomic>
+#include <condition_variable>
+#include <deque>
 #include <exception>
 #include <mutex>
 #include <thread>
@@ -236,21 +238,97 @@ bool loadPCDFile(const std::string& path, Cloud& out, std::string* err)
 
 bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_layout, std::string* err)
 {
+    return savePCDFileBinary(path, cloud.data(), cloud.size(), octree_layout, err);
+}
+
+bool readPCDPointCount(const std::string& path, size_t* n_points, std::string* err)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) { if (err) *err = path + ": cannot open"; return false; }
+    size_t n = 0, width = 0, height = 1;
+    std::string line;
+    while (std::getline(f, line)) {
+        if (!line.empty() && line.back() == '\r') line.pop_back();
+        std::stringstream ss(line);
+        std::string key; ss >> key;
+        if (key == "WIDTH") ss >> width;
+        else if (key == "HEIGHT") ss >> height;
+        else if (key == "POINTS") ss >> n;
+        else if (key == "DATA") { *n_points = n ? n : width * height; return true; }
+    }
+    if (err) *err = path + ": malformed header";
+    return false;
+}
+
+bool savePCDFileBinary(const std::string& path, const PointType* pts, size_t n, bool octree_layout, std::string* err)
+{
     std::ofstream f(path, std::ios::binary | std::ios::trunc);
     if (!f) { if (err) *err = path + ": cannot open for writing"; return false; }
-    const size_t n = cloud.size();
     const size_t width = octree_layout ? 1 : n, height = octree_layout ? n : 1;
     std::ostringstream h;   // the header pcl::PCDWriter::generateHeader emits for PointXYZI (padding fields stripped)
     h << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
       << "WIDTH " << width << "\nHEIGHT " << height << "\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA binary\n";
     const std::string hs = h.str();
     f.write(hs.data(), (std::streamsize)hs.size());
-    if (n) f.write(reinterpret_cast<const char*>(cloud.data()), (std::streamsize)(n * sizeof(PointType)));
+    if (n) f.write(reinterpret_cast<const char*>(pts), (std::streamsize)(n * sizeof(PointType)));
     if (!f) { if (err) *err = path + ": write failed"; return false; }
     return true;
 }
 
 bool& logQuiet() { thread_local bool quiet = false; return quiet; }
+
+struct AsyncWriter::Impl
+{
+    std::mutex m;
+    std::condition_variable cv_work, cv_idle;
+    std::deque<std::function<void()>> q;
+    size_t running = 0;
+    bool stop = false;
+    std::exception_ptr err;
+    std::vector<std::thread> pool;
+};
+AsyncWriter::AsyncWriter(unsigned threads) : impl_(new Impl)
+{
+    for (unsigned t = 0; t < std::max(1u, threads); ++t)
+        impl_->pool.emplace_back([this] {
+            Impl& I = *impl_;
+            for (;;) {
+                std::function<void()> task;
+                {
+                    std::unique_lock<std::mutex> lk(I.m);
+                    I.cv_work.wait(lk, [&] { return I.stop || !I.q.empty(); });
+                    if (I.q.empty()) return;
+                    task = std::move(I.q.front());
+                    I.q.pop_front();
+                    ++I.running;
+                }
+                try { task(); } catch (...) { std::lock_guard<std::mutex> g(I.m); if (!I.err) I.err = std::current_exception(); }
+                {
+                    std::lock_guard<std::mutex> g(I.m);
+                    --I.running;
+                    if (I.q.empty() && I.running == 0) I.cv_idle.notify_all();
+                }
+            }
+        });
+}
+AsyncWriter::~AsyncWriter()
+{
+    { std::lock_guard<std::mutex> g(impl_->m); impl_->stop = true; }
+    impl_->cv_work.notify_all();
+    for (auto& t : impl_->pool) t.join();
+    delete impl_;
+}
+void AsyncWriter::submit(std::function<void()> task)
+{
+    { std::lock_guard<std::mutex> g(impl_->m); impl_->q.push_back(std::move(task)); }
+    impl_->cv_work.notify_one();
+}
+void AsyncWriter::drain()
+{
+    std::unique_lock<std::mutex> lk(impl_->m);
+    impl_->cv_idle.wait(lk, [&] { return impl_->q.empty() && impl_->running == 0; });
+    if (impl_->err) { std::exception_ptr e = impl_->err; impl_->err = nullptr; std::rethrow_exception(e); }
+}
 
 // pcl::VoxelGrid::applyFilter (PCL 1.10, from its published behaviour): inverse leaf in float, bounding box from
 // getMinMax3D, dx*dy*dz > INT32_MAX => "Leaf size is too small" and output = input; else centroids ordered by linear
@@ -267,7 +345,7 @@ void voxelGridFilter(const Cloud& in, float leaf, Cloud& out)
         for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
     }
     const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
-    if (dx * dy * dz > (int64_t)std::numeric_limits<int32_t>::max()) { out = in; return; }
+    if (dx * dy * dz > (int64_t)std::numeric_limits<int32_t>::max()) { out = in; return; }      // "leaf size is too small": output = input
     int minb[3], divb[3];
     for (int d = 0; d < 3; ++d) {
         minb[d] = (int)std::floor(mn[d] * inv);
@@ -294,6 +372,23 @@ void voxelGridFilter(const Cloud& in, float leaf, Cloud& out)
         a = b;
     }
     out.swap(res);
+}
+
+// same filter; when PCL's overflow early-out applies (the usual case for a raw scan at 0.05 m) the input buffer
+// becomes the output without a copy
+void voxelGridFilter(Cloud&& in, float leaf, Cloud& out)
+{
+    if (in.empty()) { out.clear(); return; }
+    const float inv = 1.0f / leaf;
+    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
+    float mx[3] = {-mn[0], -mn[1], -mn[2]};
+    for (const PointType& p : in) {
+        const float c[3] = {p.x, p.y, p.z};
+        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
+    }
+    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
+    if (dx * dy * dz > (int64_t)std::numeric_limits<int32_t>::max()) { out = std::move(in); return; }
+    voxelGridFilter(static_cast<const Cloud&>(in), leaf, out);
 }
 
 } // namespace ltremovert

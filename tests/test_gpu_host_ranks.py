@@ -2,7 +2,8 @@
 runs K ranks -- one host thread and one device context each, all on the one GPU of the test box -- that vote / reproject / search
 only their block of keyframes and exchange label masks, per-rank voxel-grid pieces and scan shards through the Comm interface.
 Every output file must be BYTE-IDENTICAL to the single-rank run for K in {1, 2, 4, 8}, and `--gpus 1` must do the same through the
-RCCL back end (ncclCommInitAll with one device: the plumbing the 8-GPU node uses)."""
+RCCL back end (ncclCommInitAll with one device: the plumbing the 8-GPU node uses).  The same comparison covers SURVEY 8f-1 / 8f-2: the
+pipelined loader + background writer (default) must write exactly what the synchronous path writes."""
 import filecmp
 import os
 import subprocess
@@ -34,11 +35,12 @@ def test_sharded_host_outputs_do_not_depend_on_rank_count(tmp_path, three_res):
     res = (2.5, 2.0, 1.5) if three_res else (2.5,)
     env = dict(os.environ, LTM_VOXEL_SHARD_MIN="0")     # shard every voxel grid, however small
     runs = {}
-    for tag, args in (("single", []), ("k1", ["--logical-ranks", "1"]), ("k2", ["--logical-ranks", "2"]), ("k4", ["--logical-ranks", "4"]),
+    # "sync": the synchronous loader / writer (removert/gpu_async_io: false) against the pipelined feeder + background writer (default)
+    for tag, args in (("single", []), ("sync", []), ("k1", ["--logical-ranks", "1"]), ("k2", ["--logical-ranks", "2"]), ("k4", ["--logical-ranks", "4"]),
                       ("k8", ["--logical-ranks", "8"]), ("rccl1", ["--gpus", "1"])):
         outdir = tmp_path / f"out_{tag}"
         yaml = tmp_path / f"params_{tag}.yaml"
-        yaml.write_text(fp.yaml_text(tmp_path, dirs, outdir, 0, n_kf - 1, res_list=res, extra=extra))
+        yaml.write_text(fp.yaml_text(tmp_path, dirs, outdir, 0, n_kf - 1, res_list=res, extra=extra + ("  gpu_async_io: false\n" if tag == "sync" else "")))
         r = subprocess.run([exe, str(yaml)] + args, capture_output=True, text=True, timeout=600, env=env)
         assert r.returncode == 0, f"{tag}: " + r.stdout[-1500:] + r.stderr[-1500:]
         assert "T_total" in r.stdout

@@ -1,0 +1,77 @@
+#!/usr/bin/env python3
+"""T_total: files -> files wall time of the drop-in `ltm_run` on a BASELINE configuration.
+
+    python tools/t_total.py --kf 500 [--three-res] [--ranks K] [--runs 3] [--keep DIR]
+
+Writes the two synthetic `lot` sessions in the reference's on-disk format (flat directories of binary PCD scans + pose text files,
+tools/synth.py), writes a params_ltmapper.yaml, runs lt-mapper_amd/host/ltm_run and reports its own timing line: T_total, the
+Step 0 part (directory scan, PCD decode, per-scan VoxelGrid, upload, pre-clean, makeGlobalMap), Steps 1-3 (which include the 16
+map PCD writes) and the 5 x N_c scan-file writes.  One JSON line per invocation; the first run warms the page cache."""
+import argparse
+import json
+import os
+import shutil
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--kf", type=int, default=50)
+    ap.add_argument("--sensor", default="os1-64")
+    ap.add_argument("--three-res", action="store_true")
+    ap.add_argument("--ranks", type=int, default=1, help="--logical-ranks K of ltm_run (1 = plain single-GPU run)")
+    ap.add_argument("--runs", type=int, default=3)
+    ap.add_argument("--keep", default=None)
+    ap.add_argument("--extra-yaml", default="", help="additional `key: value` lines, ';'-separated")
+    args = ap.parse_args()
+    import torch
+    import fileproto as fp
+    from tools import synth
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    root = args.keep or tempfile.mkdtemp(prefix="ltm_ttotal_")
+    os.makedirs(root, exist_ok=True)
+    t0 = time.perf_counter()
+    sess = [synth.to_numpy(synth.make_session(s, args.kf, args.sensor, device=dev)) for s in (1, 2)]
+    dirs = fp.write_session_dirs(root, sess)
+    t_write_inputs = time.perf_counter() - t0
+    in_bytes = sum(int(S["offsets"][-1]) * 16 for S in sess)
+    exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
+    extra = "".join(f"  {kv.strip()}\n" for kv in args.extra_yaml.split(";") if kv.strip())
+    if args.three_res:
+        extra += "  gpu_use_self_removert: true\n"
+    runs = []
+    for r in range(args.runs):
+        outdir = os.path.join(root, f"out{r}")
+        shutil.rmtree(outdir, ignore_errors=True)
+        yaml = os.path.join(root, "params.yaml")
+        with open(yaml, "w") as f:
+            f.write(fp.yaml_text(root, dirs, outdir, 0, args.kf - 1, res_list=(2.5, 2.0, 1.5) if args.three_res else (2.5,), extra=extra))
+        cmd = [exe, yaml] + (["--logical-ranks", str(args.ranks)] if args.ranks > 1 else [])
+        t0 = time.perf_counter()
+        p = subprocess.run(cmd, capture_output=True, text=True)
+        wall = time.perf_counter() - t0
+        if p.returncode != 0:
+            sys.exit(p.stdout[-2000:] + p.stderr[-2000:])
+        line = [l for l in p.stdout.splitlines() if l.startswith("[timing]")][-1].split()
+        t = {line[i]: float(line[i + 1]) for i in range(len(line) - 1) if line[i].startswith("T_")}
+        kfs = [int(x) for x in line[line.index("keyframes") + 1: line.index("keyframes") + 3]]
+        out_bytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(outdir) for f in fs)
+        runs.append(dict(process_wall_s=round(wall, 3), **{k: round(v, 3) for k, v in t.items()}, keyframes=kfs, output_bytes=out_bytes))
+    best = min(runs, key=lambda x: x["T_total"])
+    print(json.dumps({"what": "ltm_run files -> files", "keyframes_per_session": args.kf, "sensor": args.sensor, "three_res": args.three_res,
+                      "ranks": args.ranks, "input_bytes": in_bytes, "runs": runs, "best": best,
+                      "keyframe_pairs_per_s_incl_io": round(min(best["keyframes"]) / best["T_total"], 2),
+                      "T_total_minus_steps_s": round(best["T_total"] - best["T_steps123"], 3), "input_generation_and_write_s": round(t_write_inputs, 1)}))
+    if not args.keep:
+        shutil.rmtree(root, ignore_errors=True)
+
+
+if __name__ == "__main__":
+    main()
