@@ -136,6 +136,7 @@ struct ltm_ctx {
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
     int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
     // copy engine side (pipelined loader / asynchronous output fetch): its own stream, pinned staging memory
+    void* scratch_pinned = nullptr;             // staging of the small host round trips (d2h / h2d helpers)
     hipStream_t copy_stream = nullptr;
     std::vector<PinnedBlock> pinned;
     std::unordered_map<uint64_t, UploadState> uploads;
@@ -196,17 +197,29 @@ void prof_collect(ltm_ctx* c)
 }
 
 void sync(ltm_ctx* c) { LTM_HIP(hipStreamSynchronize(c->stream)); }
+// Small host<->device transfers (counts, bounding boxes, offset tables: the host round trips between stages) go through a pinned
+// scratch buffer of the context: a copy to / from pageable memory makes the runtime stage or pin pages on every call.
+static constexpr size_t kSmallCopy = 64 << 10;
+void* small_scratch(ltm_ctx* c)
+{
+    if (!c->scratch_pinned && hipHostMalloc(&c->scratch_pinned, kSmallCopy, hipHostMallocDefault) != hipSuccess) c->scratch_pinned = nullptr;
+    return c->scratch_pinned;
+}
 void d2h(ltm_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (!bytes) return;
-    LTM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
+    void* sp = bytes <= kSmallCopy ? small_scratch(c) : nullptr;
+    LTM_HIP(hipMemcpyAsync(sp ? sp : dst, src, bytes, hipMemcpyDeviceToHost, c->stream));
     sync(c);
+    if (sp) memcpy(dst, sp, bytes);
 }
 void h2d(ltm_ctx* c, void* dst, const void* src, size_t bytes)
 {
     if (!bytes) return;
-    LTM_HIP(hipMemcpyAsync(dst, src, bytes, hipMemcpyHostToDevice, c->stream));
-    sync(c);   // the host buffer may be pageable and is not ours to keep
+    void* sp = bytes <= kSmallCopy ? small_scratch(c) : nullptr;
+    if (sp) memcpy(sp, src, bytes);
+    LTM_HIP(hipMemcpyAsync(dst, sp ? sp : src, bytes, hipMemcpyHostToDevice, c->stream));
+    sync(c);   // the host buffer may be pageable and is not ours to keep (and the scratch is reused by the next small copy)
 }
 void d2d(ltm_ctx* c, void* dst, const void* src, size_t bytes)
 {
@@ -373,9 +386,16 @@ void unpack_to_host(const float* packed, size_t n, size_t stride, void* dst)
 size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, size_t n)
 {
     uint32_t last_pos = 0; uint8_t last = 0;
-    LTM_HIP(hipMemcpyAsync(&last_pos, pos + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
-    LTM_HIP(hipMemcpyAsync(&last, labels + (n - 1), 1, hipMemcpyDeviceToHost, c->stream));
-    sync(c);
+    if (unsigned char* sp = static_cast<unsigned char*>(small_scratch(c))) {      // both words into the pinned scratch, one wait
+        LTM_HIP(hipMemcpyAsync(sp, pos + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        LTM_HIP(hipMemcpyAsync(sp + 8, labels + (n - 1), 1, hipMemcpyDeviceToHost, c->stream));
+        sync(c);
+        memcpy(&last_pos, sp, 4); last = sp[8];
+    } else {
+        LTM_HIP(hipMemcpyAsync(&last_pos, pos + (n - 1), 4, hipMemcpyDeviceToHost, c->stream));
+        LTM_HIP(hipMemcpyAsync(&last, labels + (n - 1), 1, hipMemcpyDeviceToHost, c->stream));
+        sync(c);
+    }
     return (size_t)last_pos + (last ? 1 : 0);
 }
 
@@ -688,8 +708,9 @@ struct KnnIndex {
 };
 
 // split pts[0..n) by flag (1 -> first output) keeping order; per-keyframe offsets from `bounds` (n_b+1 point positions)
-void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n, const std::vector<uint64_t>& bounds,
-                   float4** d_set, std::vector<uint64_t>* off_set, float4** d_unset, std::vector<uint64_t>* off_unset)
+// offsets_dev[kf0 + j] - first are the same boundaries on the device (the scan set's own offset table)
+void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n, const std::vector<uint64_t>& bounds, const uint64_t* offsets_dev,
+                   size_t kf0, uint64_t first, float4** d_set, std::vector<uint64_t>* off_set, float4** d_unset, std::vector<uint64_t>* off_unset)
 {
     const size_t nb = bounds.size() - 1;
     off_set->assign(nb + 1, 0); off_unset->assign(nb + 1, 0);
@@ -700,12 +721,11 @@ void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n,
         const size_t tb = scan_temp_bytes(n);
         DevBuf temp(c, tb);
         LTM_HIP(exclusive_scan_u8(flag, pos.as<uint32_t>(), n, temp.p, tb, c->stream));
-        nset = scan_total_u8(c, flag, pos.as<uint32_t>(), n);
-        DevBuf bdev(c, (nb + 1) * 8), bout(c, (nb + 1) * 4);
-        h2d(c, bdev.p, bounds.data(), (nb + 1) * 8);
-        LTM_HIP(gather_u32(pos.as<uint32_t>(), bdev.as<uint64_t>(), nb + 1, n, (uint32_t)nset, bout.as<uint32_t>(), c->stream));
+        DevBuf bout(c, (nb + 1) * 4);      // per-keyframe boundaries and the total in one small array: one host round trip
+        LTM_HIP(flag_bounds(pos.as<uint32_t>(), flag, n, offsets_dev, kf0, first, nb, bout.as<uint32_t>(), c->stream));
         std::vector<uint32_t> b(nb + 1);
         d2h(c, b.data(), bout.p, (nb + 1) * 4);
+        nset = b[nb];
         for (size_t j = 0; j <= nb; ++j) { (*off_set)[j] = b[j]; (*off_unset)[j] = bounds[j] - b[j]; }
         *d_set = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nset, 1) * sizeof(float4)));
         *d_unset = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(n - nset, 1) * sizeof(float4)));
@@ -833,6 +853,7 @@ void ltm_destroy(ltm_ctx* c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
+    if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     c->pool.release_all();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1271,7 +1292,7 @@ int ltm_preclean(ltm_ctx* c, ltm_scanset hin, float radius, ltm_scanset* out)
         LTM_HIP(preclean_flags(s.d, s.n_pts, radius, drop.as<uint8_t>(), c->stream));
         float4 *d_drop, *d_keep;
         std::vector<uint64_t> off_drop, off_keep;
-        split_by_flag(c, s.d, drop.as<uint8_t>(), s.n_pts, s.off, &d_drop, &off_drop, &d_keep, &off_keep);
+        split_by_flag(c, s.d, drop.as<uint8_t>(), s.n_pts, s.off, s.off_dev, 0, 0, &d_drop, &off_drop, &d_keep, &off_keep);
         c->pool.free(d_drop);
         *out = new_scanset(c, d_keep, std::move(off_keep));
     });
@@ -1435,7 +1456,7 @@ int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, siz
             const size_t KB = std::min(c->kf_batch, nk);
             DevBuf img(c, KB * npx * 8), pos(c, KB * npx * 4);
             const size_t tb = scan_temp_bytes(KB * npx);
-            DevBuf temp(c, tb), bdev(c, (KB + 1) * 8), bout(c, (KB + 1) * 4);
+            DevBuf temp(c, tb), bout(c, (KB + 1) * 4);
             for (size_t kb = kf_begin; kb < kf_end; kb += KB) {
                 const size_t nb = std::min(KB, kf_end - kb);
                 LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
@@ -1445,18 +1466,11 @@ int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, siz
                 }
                 ProfScope ps(c, "reproject_gather", (double)(nb * npx), (double)(nb * npx) * 12);
                 LTM_HIP(exclusive_scan_img_valid(img.as<uint64_t>(), pos.as<uint32_t>(), nb * npx, temp.p, tb, c->stream));
-                // per-keyframe boundaries = scan value at each image start; the total is the scan past the end
-                std::vector<uint64_t> bounds(nb + 1);
-                for (size_t j = 0; j <= nb; ++j) bounds[j] = j * npx;
-                uint32_t last_pos = 0; uint64_t last_img = 0;
-                LTM_HIP(hipMemcpyAsync(&last_pos, pos.as<uint32_t>() + (nb * npx - 1), 4, hipMemcpyDeviceToHost, c->stream));
-                LTM_HIP(hipMemcpyAsync(&last_img, img.as<uint64_t>() + (nb * npx - 1), 8, hipMemcpyDeviceToHost, c->stream));
-                sync(c);
-                const size_t total = (size_t)last_pos + (((uint32_t)last_img) ? 1 : 0);
-                h2d(c, bdev.p, bounds.data(), (nb + 1) * 8);
-                LTM_HIP(gather_u32(pos.as<uint32_t>(), bdev.as<uint64_t>(), nb + 1, nb * npx, (uint32_t)total, bout.as<uint32_t>(), c->stream));
+                // per-keyframe boundaries = scan value at each image start, the total = the scan past the end: one small array, one round trip
+                LTM_HIP(image_bounds(pos.as<uint32_t>(), img.as<uint64_t>(), npx, nb, bout.as<uint32_t>(), c->stream));
                 std::vector<uint32_t> b(nb + 1);
                 d2h(c, b.data(), bout.p, (nb + 1) * 4);
+                const size_t total = b[nb];
                 const uint64_t base = off[kb - kf_begin];
                 for (size_t j = 1; j <= nb; ++j) off[kb - kf_begin + j] = base + b[j];
                 float4* d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(total, 1) * 16));
@@ -1501,7 +1515,7 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
         for (size_t j = 0; j < bounds.size(); ++j) bounds[j] = s.off[kf_begin + j] - first;
         float4 *d_co, *d_di;
         std::vector<uint64_t> off_co, off_di;
-        split_by_flag(c, local.as<float4>(), flag.as<uint8_t>(), n, bounds, &d_co, &off_co, &d_di, &off_di);
+        split_by_flag(c, local.as<float4>(), flag.as<uint8_t>(), n, bounds, s.off_dev, kf_begin, first, &d_co, &off_co, &d_di, &off_di);
         if (coexist) *coexist = new_scanset(c, d_co, std::move(off_co)); else c->pool.free(d_co);
         if (diff) *diff = new_scanset(c, d_di, std::move(off_di)); else c->pool.free(d_di);
     });

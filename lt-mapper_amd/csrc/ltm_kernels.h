@@ -84,6 +84,9 @@ hipError_t reproject_gather(const uint64_t* img, const uint32_t* pos, size_t npx
                             const double* inv_poses_dev, size_t kb, HostMat34 b2l, int b2l_identity,
                             float4* out, hipStream_t s);
 // gather arbitrary positions of a u32 array: out[j] = (idx[j] < n ? in[idx[j]] : tail)
+hipError_t image_bounds(const uint32_t* pos, const uint64_t* img, size_t npx, size_t nb, uint32_t* out, hipStream_t s);
+hipError_t flag_bounds(const uint32_t* pos, const uint8_t* flag, size_t n, const uint64_t* offsets_dev, size_t kf0, uint64_t first, size_t nb,
+                       uint32_t* out, hipStream_t s);
 hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, size_t n, uint32_t tail_value_index_n,
                       uint32_t* out, hipStream_t s);
 

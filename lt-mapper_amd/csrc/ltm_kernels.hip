@@ -1119,6 +1119,40 @@ hipError_t reproject_gather(const uint64_t* img, const uint32_t* pos, size_t npx
     return hipGetLastError();
 }
 
+// out[j] = number of emitted points before image j (j = 0..nb) given the exclusive scan `pos` of the valid-pixel flags of nb images of
+// npx pixels: the per-keyframe boundaries and the total of a reprojection in ONE small array (one host round trip instead of three)
+__global__ void k_image_bounds(const uint32_t* __restrict__ pos, const uint64_t* __restrict__ img, size_t npx, size_t nb, uint32_t* __restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nb) return;
+    if (j < nb) out[j] = pos[j * npx];
+    else { const size_t last = nb * npx - 1; out[j] = pos[last] + (((uint32_t)img[last]) ? 1u : 0u); }
+}
+hipError_t image_bounds(const uint32_t* pos, const uint64_t* img, size_t npx, size_t nb, uint32_t* out, hipStream_t s)
+{
+    if (!nb || !npx) return hipSuccess;
+    k_image_bounds<<<dim3(grid_for(nb + 1)), dim3(kBlock), 0, s>>>(pos, img, npx, nb, out);
+    return hipGetLastError();
+}
+
+// out[j] (j = 0..nb) = number of set flags before point offsets[kf0 + j] - first, given the exclusive scan `pos` of `flag` over n
+// points; a boundary at or past n (the last one) yields the total.  Per-keyframe output boundaries + total in one small array.
+__global__ void k_flag_bounds(const uint32_t* __restrict__ pos, const uint8_t* __restrict__ flag, size_t n, const uint64_t* __restrict__ offsets,
+                              size_t kf0, uint64_t first, size_t nb, uint32_t* __restrict__ out)
+{
+    const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (j > nb) return;
+    const uint64_t at = offsets[kf0 + j] - first;
+    out[j] = (at < n) ? pos[at] : (pos[n - 1] + (flag[n - 1] ? 1u : 0u));
+}
+hipError_t flag_bounds(const uint32_t* pos, const uint8_t* flag, size_t n, const uint64_t* offsets_dev, size_t kf0, uint64_t first, size_t nb,
+                       uint32_t* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_flag_bounds<<<dim3(grid_for(nb + 1)), dim3(kBlock), 0, s>>>(pos, flag, n, offsets_dev, kf0, first, nb, out);
+    return hipGetLastError();
+}
+
 __global__ void k_gather_u32(const uint32_t* in, const uint64_t* idx, size_t m, size_t n, uint32_t tail, uint32_t* out)
 {
     const size_t j = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
