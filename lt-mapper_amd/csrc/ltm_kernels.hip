@@ -515,7 +515,7 @@ hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb,
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
 template <bool B2L_IDENTITY, int VARIANT = 0>     // VARIANT: A/B switches for profiling (env LTM_CULL_VARIANT), results identical
-__global__ void __launch_bounds__(kBlock)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 8 : 4, 8)))
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
                 uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const float* __restrict__ qbound_img,
                 const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img)
@@ -697,6 +697,7 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
         case 1: LTM_LAUNCH_CULL(true, 1); break;
         case 2: LTM_LAUNCH_CULL(true, 2); break;
         case 3: LTM_LAUNCH_CULL(true, 3); break;
+        case 4: LTM_LAUNCH_CULL(true, 4); break;
         default: LTM_LAUNCH_CULL(true, 0); break;
     }
 #undef LTM_LAUNCH_CULL
