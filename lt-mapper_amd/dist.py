@@ -87,8 +87,7 @@ class ShardedOps:
         gathered = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(gathered, mine, group=self.group)
         counts = []
-        for t in gathered:
-            h = t.cpu().tolist()
+        for h in torch.stack(gathered).cpu().tolist():      # one device->host copy for all ranks' tables
             counts.append(h[1: int(h[0]) + 2])
         sizes = [c[-1] for c in counts]
         cap = max(max(sizes), 1)
@@ -105,7 +104,7 @@ class ShardedOps:
         mine = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
         sizes = [torch.empty_like(mine) for _ in range(self.world)]
         self.dist.all_gather(sizes, mine, group=self.group)
-        sizes = [int(x.item()) for x in sizes]
+        sizes = [int(x) for x in torch.cat(sizes).cpu().tolist()]
         cap = max(max(sizes), 1)
         pad = torch.zeros((cap, 4), dtype=torch.float32, device=t.device)
         pad[: t.shape[0]] = t
