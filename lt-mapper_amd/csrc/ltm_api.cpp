@@ -636,21 +636,6 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
         DevBuf stemp(c, stb);
         LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, mbits, stemp.p, stb, c->stream));
     }
-    if (packed) {
-        // fused tail: inclusive scan of head flags recomputed from the sorted keys -> voxel index; nvox = its last element (one 4-byte
-        // read); every head's thread sums its own run.  The output is sized after the count (one host round trip, as before).
-        DevBuf incl(c, n * 4);
-        const size_t tb = inclusive_scan_temp_bytes(n);
-        DevBuf temp(c, tb);
-        LTM_HIP(inclusive_scan_key_heads(keys2.as<uint64_t>(), kshift, incl.as<uint32_t>(), n, temp.p, tb, c->stream));
-        uint32_t nv32 = 0;
-        d2h(c, &nv32, incl.as<uint32_t>() + (n - 1), 4);
-        const size_t nvox = nv32;
-        float4* o = reinterpret_cast<float4*>(c->pool.alloc(nvox * sizeof(float4)));
-        LTM_HIP(voxel_centroids_runs(pts, keys2.as<uint64_t>(), kshift, ((uint64_t)1 << ib) - 1, incl.as<uint32_t>(), n, o, c->stream));
-        *out = o;
-        return nvox;
-    }
     DevBuf heads(c, n), pos(c, n * 4);
     LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream, kshift));
     const size_t tb = scan_temp_bytes(n);

@@ -112,11 +112,6 @@ hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_
 hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const OctreeFrame* frames_dev,
                            unsigned shift, uint64_t* keys, uint32_t* idx, hipStream_t s);
 size_t sort_temp_bytes(size_t n);
-// fused tail of the packed voxel grid (head flags recomputed from the sorted keys; see ltm_kernels.hip)
-size_t inclusive_scan_temp_bytes(size_t n);
-hipError_t inclusive_scan_key_heads(const uint64_t* sorted_keys, unsigned shift, uint32_t* incl, size_t n, void* temp, size_t temp_bytes, hipStream_t s);
-hipError_t voxel_centroids_runs(const float4* pts, const uint64_t* sorted_keys, unsigned shift, uint64_t idx_mask, const uint32_t* incl, size_t n,
-                                float4* out, hipStream_t s);
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
                           unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s, unsigned shift = 0);   // compares keys >> shift

@@ -18,7 +18,6 @@
 #include <hip/hip_runtime.h>
 #include <rocprim/device/device_radix_sort.hpp>
 #include <rocprim/device/device_scan.hpp>
-#include <rocprim/iterator/counting_iterator.hpp>
 #include <rocprim/iterator/transform_iterator.hpp>
 
 namespace ltm {
@@ -1617,57 +1616,6 @@ k_voxel_centroids_packed(const float4* __restrict__ pts, const uint64_t* __restr
     const float cnt = (float)(b - a);
     out[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
 }
-// ---- fused tail of the packed voxel grid: the head flag of sorted element i (first of its voxel) is recomputed from the keys
-// wherever it is needed instead of being written out, inclusive-scanned into the voxel index, and the thread of every head walks
-// its own run: no head-flag array, no segment-start array, two kernels fewer per voxel grid.
-struct KeyHead
-{
-    const uint64_t* keys; unsigned shift;
-    __host__ __device__ uint32_t operator()(size_t i) const { return (i == 0 || (keys[i] >> shift) != (keys[i - 1] >> shift)) ? 1u : 0u; }
-};
-hipError_t inclusive_scan_key_heads(const uint64_t* sorted_keys, unsigned shift, uint32_t* incl, size_t n, void* temp, size_t temp_bytes, hipStream_t s)
-{
-    if (!n) return hipSuccess;
-    auto it = rocprim::make_transform_iterator(rocprim::make_counting_iterator<size_t>(0), KeyHead{sorted_keys, shift});
-    return rocprim::inclusive_scan(temp, temp_bytes, it, incl, n, rocprim::plus<uint32_t>(), s);
-}
-size_t inclusive_scan_temp_bytes(size_t n)
-{
-    size_t bytes = 0;
-    uint32_t* d = nullptr;
-    (void)rocprim::inclusive_scan(nullptr, bytes, d, d, n ? n : 1, rocprim::plus<uint32_t>());
-    return bytes + 256;
-}
-__global__ void __launch_bounds__(kBlock)
-k_voxel_centroids_runs(const float4* __restrict__ pts, const uint64_t* __restrict__ sorted_keys, unsigned shift, uint64_t idx_mask,
-                       const uint32_t* __restrict__ incl, size_t n, float4* __restrict__ out)
-{
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= n) return;
-    const uint64_t k = sorted_keys[i];
-    if (i != 0 && (k >> shift) == (sorted_keys[i - 1] >> shift)) return;      // not the first point of its voxel
-    // PCL OctreePointCloudVoxelCentroidContainer: float sums in input order (the sort is stable), divided by (float)count
-    float4 p = pts[k & idx_mask];
-    float sx = 0.0f + p.x, sy = 0.0f + p.y, sz = 0.0f + p.z, si = 0.0f + p.w;
-    uint32_t cnt = 1;
-    for (size_t j = i + 1; j < n; ++j) {
-        const uint64_t kj = sorted_keys[j];
-        if ((kj >> shift) != (k >> shift)) break;
-        p = pts[kj & idx_mask];
-        sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
-        ++cnt;
-    }
-    const float c = (float)cnt;
-    out[incl[i] - 1u] = make_float4(sx / c, sy / c, sz / c, si / c);
-}
-hipError_t voxel_centroids_runs(const float4* pts, const uint64_t* sorted_keys, unsigned shift, uint64_t idx_mask, const uint32_t* incl, size_t n,
-                                float4* out, hipStream_t s)
-{
-    if (!n) return hipSuccess;
-    k_voxel_centroids_runs<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, sorted_keys, shift, idx_mask, incl, n, out);
-    return hipGetLastError();
-}
-
 hipError_t voxel_centroids_packed(const float4* pts, const uint64_t* sorted_keys, uint64_t idx_mask, const uint32_t* starts, size_t n_vox,
                                   size_t n, float4* out, hipStream_t s)
 {
