@@ -101,6 +101,9 @@ struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes
 // resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
 struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; float* qbound; float q_thr; };
 struct Pending { int cls; hipEvent_t a, b; };
+// a vote launch whose algorithmic bytes depend on the number of (tile, keyframe) workgroups that survive the whole-tile cull:
+// counted on the device into slot `slot` of ctx->live_counts, folded into the class totals when the profile is collected
+struct PendingLive { int cls; int slot; double max_pts; double image_bytes; };
 struct PinnedBlock { void* p; size_t bytes; bool in_use; };
 // pipelined scan-set upload: device array of `cap` points filled front to back, two pinned staging buffers in flight
 struct UploadState { float4* d = nullptr; size_t cap = 0, n = 0; std::vector<uint64_t> off{0}; void* stage[2] = {nullptr, nullptr}; size_t stage_sz[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int next = 0; };
@@ -130,6 +133,8 @@ struct ltm_ctx {
     std::vector<std::string> prof_names;
     std::vector<ProfClass> prof;
     std::vector<Pending> pending;
+    std::vector<PendingLive> pending_live;
+    unsigned long long* live_counts = nullptr;   // device, kLiveSlots entries
     std::vector<hipEvent_t> event_pool;
     std::vector<ScanImgEntry> scan_cache;
     uint64_t scan_cache_stamp = 0;
@@ -184,10 +189,21 @@ struct ProfScope {   // HIP-event bracket around one kernel class on the context
         c->pending.push_back(Pending{cls, a, b});
     }
 };
+static constexpr int kLiveSlots = 4096;
 void prof_collect(ltm_ctx* c)
 {
-    if (c->pending.empty()) return;
+    if (c->pending.empty() && c->pending_live.empty()) return;
     LTM_HIP(hipStreamSynchronize(c->stream));
+    if (!c->pending_live.empty()) {
+        std::vector<unsigned long long> live(kLiveSlots);
+        LTM_HIP(hipMemcpy(live.data(), c->live_counts, sizeof(unsigned long long) * kLiveSlots, hipMemcpyDeviceToHost));
+        for (const PendingLive& p : c->pending_live) {
+            const double pts = std::min(p.max_pts, (double)live[(size_t)p.slot] * 4096.0);
+            c->prof[p.cls].units += pts;
+            c->prof[p.cls].bytes += 16.0 * pts + p.image_bytes;
+        }
+        c->pending_live.clear();
+    }
     for (Pending& p : c->pending) {
         float ms = 0;
         if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) c->prof[p.cls].ms += ms;
@@ -485,16 +501,17 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
             // class name = kernel: k_vote_map_cull for mode 0 (when enabled), k_map_rimg_blockmin otherwise
             // algorithmic bytes = map tiles read + images written.  Tiles that the whole-tile range cull drops are never read, so
             // (measurement only, when profiling is on) they are counted by the same predicate and left out.
-            double pts = (double)map.n * nb;
-            if (cull && c->prof_on && tile_cull_enabled() && smax) {
-                DevBuf live(c, 8);
-                LTM_HIP(hipMemsetAsync(live.p, 0, 8, c->stream));
-                LTM_HIP(count_live_tiles(ps.approx_dev, kb, nb, tb.as<float>(), n_tiles, smax, thr, live.as<unsigned long long>(), c->stream));
-                unsigned long long nlive = 0;
-                d2h(c, &nlive, live.p, 8);
-                pts = std::min(pts, (double)nlive * 4096.0);
+            double pts = (double)map.n * nb, bytes = 16.0 * pts + (double)nb * 8.0 * npx;
+            const bool count_live = cull && c->prof_on && tile_cull_enabled() && smax && c->pending_live.size() < (size_t)kLiveSlots;
+            if (count_live) {      // no host round trip here: the count is read when the profile is collected
+                if (!c->live_counts) LTM_HIP(hipMalloc(reinterpret_cast<void**>(&c->live_counts), sizeof(unsigned long long) * kLiveSlots));
+                const int slot = (int)c->pending_live.size();
+                LTM_HIP(hipMemsetAsync(c->live_counts + slot, 0, sizeof(unsigned long long), c->stream));
+                LTM_HIP(count_live_tiles(ps.approx_dev, kb, nb, tb.as<float>(), n_tiles, smax, thr, c->live_counts + slot, c->stream));
+                c->pending_live.push_back(PendingLive{prof_class(c, "vote_map_cull"), slot, pts, (double)nb * 8.0 * npx});
+                pts = 0.0; bytes = 0.0;      // added by prof_collect
             }
-            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, 16.0 * pts + (double)nb * 8.0 * npx);
+            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, bytes);
             LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, cull ? qbound : nullptr,
                                           mode == 0 ? tb.as<float>() : nullptr, smax, thr, mode, map_img.as<uint64_t>(), c->stream));
         }
@@ -854,6 +871,7 @@ void ltm_destroy(ltm_ctx* c)
     for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
+    if (c->live_counts) (void)hipFree(c->live_counts);
     c->pool.release_all();
     (void)hipStreamDestroy(c->stream);
     delete c;

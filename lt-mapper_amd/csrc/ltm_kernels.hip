@@ -499,8 +499,15 @@ k_count_live_tiles(const float* __restrict__ approx_poses, uint32_t kb, uint32_t
     const uint32_t kfb = blockIdx.y;
     bool alive = false;
     if (tile < n_tiles) alive = !tile_out_of_reach(approx_poses + 16 * (size_t)(kb + kfb), tile_bounds + 6 * (size_t)tile, u2f(smax_bits[kfb]), thr);
+    __shared__ uint32_t wsum[kBlock / 64];
     const uint64_t b = __builtin_amdgcn_ballot_w64(alive);
-    if ((threadIdx.x & 63u) == 0u && b) atomicAdd(live, (unsigned long long)__popcll(b));
+    if ((threadIdx.x & 63u) == 0u) wsum[threadIdx.x >> 6] = (uint32_t)__popcll(b);
+    __syncthreads();
+    if (threadIdx.x == 0) {         // one atomic per workgroup
+        uint32_t t = 0;
+        for (int w = 0; w < kBlock / 64; ++w) t += wsum[w];
+        if (t) atomicAdd(live, (unsigned long long)t);
+    }
 }
 hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,
                             const uint32_t* smax_bits_dev, float thr, unsigned long long* live_dev, hipStream_t s)
