@@ -5,7 +5,7 @@
 HIPCC ?= /opt/rocm/bin/hipcc
 ARCH  ?= gfx950
 PKG    = lt-mapper_amd
-HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-result
+HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vectorize -fhip-fp32-correctly-rounded-divide-sqrt -fPIC -Iinclude -I$(PKG)/csrc -Wall -Wno-unused-result
 
 all: hip oracle host
 

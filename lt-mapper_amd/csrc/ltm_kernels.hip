@@ -360,7 +360,7 @@ __device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, flo
 // steep_clamps: the field of view is narrow enough (vfov/2 < 44 deg) that every elevation beyond +-45 deg clamps into the first /
 // last row whatever its value, so the elevation polynomial only ever sees |z| / rxy <= 1 (one v_rsq instead of v_sqrt + v_rcp and
 // no octant select); with a wider vertical field of view the steep points take the exact path instead.
-template <bool PACKED_POLY = true>
+template <bool PACKED_POLY = false>     // packed (v_pk_*) evaluation of the two polynomials: no gain on gfx950, where v_pk_fma_f32 issues at half the rate of v_fma_f32 (tools/ubench/valu_rate.hip)
 __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale, bool steep_clamps)
 {
     CullCand cc;
@@ -584,7 +584,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
             for (int u = 0; u < kInFlight; ++u) {
                 bool ok;
                 const float3 p = xform_approx(ap, pt[u], ok);
-                cc[u] = cull_candidates<(VARIANT & 1) == 0>(g, p, row_scale, col_scale, steep_clamps);
+                cc[u] = cull_candidates<(VARIANT & 1) != 0>(g, p, row_scale, col_scale, steep_clamps);
                 // not certain of the pixel (within kCullEpsPx of a rounding boundary, ~1 % of the points): straight to the exact path
                 cc[u].unusual |= !ok_img | !ok | cc[u].multi | (B2L_IDENTITY ? false : (cc[u].r2 < rmin2));
                 q0[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(qk) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
