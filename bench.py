@@ -17,7 +17,7 @@ configs[2]: five chained pair runs 01 -> 02..06 (lt-mapper_amd/cascade.py), 2500
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
   roofline     -- the dominant kernel (k_vote_map_cull): algorithmic bytes per launch (map tiles actually read + images
                   written) / average launch duration measured with HIP events on the context's stream, against the 8 TB/s
-                  HBM peak; `valu_issue_frac` = VALU lane-instructions issued per second against the vector pipes' peak (what
+                  HBM peak; `valu_issue_frac` = VALU lane-instructions issued per second against the vector pipes' nominal peak (what
                   really bounds this kernel); `traffic` = PMC-measured HBM bytes per launch (profiles/, only if it was
                   collected for exactly this kernel source);
   rooflines    -- the same figure for every kernel class of the step;
@@ -37,7 +37,11 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
-N_CU, SIMD_PER_CU, LANES_PER_SIMD = 256, 4, 16
+# gfx950 issues one wave64 fp32 / integer VALU instruction per SIMD every 2 cycles (32 lanes per clock; packed fp32 and fp64 at half,
+# transcendentals at about a quarter of that): measured with tools/ubench/valu_rate.hip -- 0.9-1.14e12 wave-instructions/s sustained
+# over the chip for v_fma_f32 / v_mul_f32 / v_and_b32 against 1.23e12 at the nominal 2.4 GHz (the clock drops under a pure VALU load)
+N_CU, SIMD_PER_CU, LANES_PER_SIMD = 256, 4, 32
+VALU_MEASURED_CEILING_WAVE_INSTS = 1.1e12
 
 DEFAULT_WORKLOAD = "lot-2x500-os1-64-3res"
 WORKLOADS = {
@@ -213,8 +217,11 @@ def main():
                     "point_projections_per_s": round(pps, 1),
                     "valu_insts_per_point": vpp,
                     "valu_issue_frac": round(vpp * pps / valu_peak, 4) if vpp else None,
+                    "valu_issue_frac_of_measured_ceiling": round(vpp * pps / (64.0 * VALU_MEASURED_CEILING_WAVE_INSTS), 4) if vpp else None,
                     "valu_peak_lane_insts_per_s": valu_peak,
-                    "real_bound": "VALU issue (see valu_issue_frac): the map stays in L2 / Infinity Cache, measured HBM traffic is several times below the algorithmic bytes"}
+                    "real_bound": "VALU issue: SQ_INSTS_VALU wave-instructions per second against one wave64 instruction per SIMD per 2 cycles (nominal 2.4 GHz) "
+                                  "and against the ceiling tools/ubench/valu_rate.hip sustains; SQ counters (tools/pmc_sq.sh) show the waves waiting to issue, not "
+                                  "on memory -- the map stays in L2 / Infinity Cache, measured HBM traffic is several times below the algorithmic bytes"}
     rooflines = [r for r in (class_roofline(k, v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])) if r]
 
     cpu_baseline = None

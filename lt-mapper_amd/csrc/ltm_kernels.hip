@@ -377,7 +377,7 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     az = (p.x < 0.0f) ? (3.14159265359f - az) : az;
     az = __builtin_copysignf(az, p.y);          // az >= 0: one v_bfi instead of compare + select
     // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
-    cc.rowh = __builtin_fmaf(-el, row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5: floor() of it is the rounded pixel
+    cc.rowh = __builtin_fmaf(el, -row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5: floor() of it is the rounded pixel (the sign sits on the uniform factor)
     cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
     // Outside the fast forms' domain (every such case ends in the exact path): the +-180 deg seam -- the SIGN of y picks column 0
     // or C-1 there, and the approximate y is only good to ~1e-7 of the range, so x < 0 with |y| <= 1e-6 |x| is undecidable here
