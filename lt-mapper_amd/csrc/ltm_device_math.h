@@ -196,6 +196,22 @@ __device__ __forceinline__ float atan_unit_approx(float a)
     p = __builtin_fmaf(p, t, 9.999772310e-01f);
     return a * p;
 }
+// asin(s), 0 <= s <= 0.70712: s*Q(s^2), degree-5 minimax fit (Lawson iteration, tools-free numpy fit recorded in DESIGN.md 4.1);
+// |error| <= 4.0e-7 rad including binary32 evaluation.  Used for the azimuth: with inv_rxy = rsq(x^2 + y^2) already at hand for
+// the elevation, min(|x|, |y|) * inv_rxy is the SINE of the octant-reduced azimuth, which saves the v_rcp_f32 (a quarter-rate
+// instruction) and the max() that the tangent form min/max needs.
+__device__ __forceinline__ float asin_octant_approx(float s)
+{
+    const float t = s * s;
+    float p = 1.1113390326e-01f;
+    p = __builtin_fmaf(p, t, -4.4537104666e-02f);
+    p = __builtin_fmaf(p, t, 7.1046762168e-02f);
+    p = __builtin_fmaf(p, t, 7.0704236627e-02f);
+    p = __builtin_fmaf(p, t, 1.6695931554e-01f);
+    p = __builtin_fmaf(p, t, 9.9999433756e-01f);
+    return s * p;
+}
+
 // the same polynomial on two arguments at once (v_pk_mul_f32 / v_pk_fma_f32: one issue slot for both): the azimuth and the
 // elevation ratio of one point.  Same operations in the same order as atan_unit_approx, so the same error bound.
 typedef float ltm_v2f __attribute__((ext_vector_type(2)));

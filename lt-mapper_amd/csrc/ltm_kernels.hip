@@ -366,14 +366,20 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     CullCand cc;
     const float xy2 = __builtin_fmaf(p.x, p.x, p.y * p.y);
     cc.r2 = __builtin_fmaf(p.z, p.z, xy2);
-    const float t_el = fabsf(p.z) * __builtin_amdgcn_rsqf(xy2);               // tan |elevation|
-    // azimuth: octant reduction min/max of |x|, |y|; both polynomials evaluated as one packed chain
+    const float inv_rxy = __builtin_amdgcn_rsqf(xy2);
+    const float t_el = fabsf(p.z) * inv_rxy;                                  // tan |elevation|
+    // azimuth, reduced to the first octant: min(|x|, |y|) / rxy is its sine (no reciprocal of max(|x|, |y|) needed)
     const float ax = fabsf(p.x), ay = fabsf(p.y);
-    const float t_az = fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(ax, ay));
-    const ltm_v2f at = PACKED_POLY ? atan_unit_approx2((ltm_v2f){t_az, fminf(t_el, 1.0f)})
-                                   : (ltm_v2f){atan_unit_approx(t_az), atan_unit_approx(fminf(t_el, 1.0f))};
-    const float el = __builtin_copysignf(at.y, p.z);
-    float az = (ay > ax) ? (1.57079632679f - at.x) : at.x;
+    float az_oct, el_abs;
+    if (PACKED_POLY) {
+        const ltm_v2f at = atan_unit_approx2((ltm_v2f){fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(ax, ay)), fminf(t_el, 1.0f)});
+        az_oct = at.x; el_abs = at.y;
+    } else {
+        az_oct = asin_octant_approx(fminf(ax, ay) * inv_rxy);
+        el_abs = atan_unit_approx(fminf(t_el, 1.0f));
+    }
+    const float el = __builtin_copysignf(el_abs, p.z);
+    float az = (ay > ax) ? (1.57079632679f - az_oct) : az_oct;
     az = (p.x < 0.0f) ? (3.14159265359f - az) : az;
     az = __builtin_copysignf(az, p.y);          // az >= 0: one v_bfi instead of compare + select
     // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
