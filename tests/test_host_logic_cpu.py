@@ -113,3 +113,19 @@ def test_shard_ranges_cover_and_are_disjoint():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             assert max(b - a for a, b in r) - min(b - a for a, b in r) <= 1
+
+
+def test_bench_launches_itself_under_torchrun_for_several_gpus():
+    """`python bench.py --gpus N` as the driver runs it (no launcher environment) must become N ranks under torch.distributed.run;
+    without GPUs every rank then stops at the loud "needs a GPU" assertion -- which shows the re-launch happened with WORLD_SIZE = N"""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env["CUDA_VISIBLE_DEVICES"] = ""      # also on a GPU box: the point is the launch, not the run
+    env["HIP_VISIBLE_DEVICES"] = ""
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True,
+                       text=True, timeout=300, env=env)
+    assert r.returncode != 0
+    assert (r.stdout + r.stderr).count("AssertionError: bench.py needs a GPU") == 2, (r.stdout + r.stderr)[-1500:]
