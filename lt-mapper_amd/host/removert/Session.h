@@ -71,7 +71,9 @@ class Session : public RosParamServer
 {
 public:
     const float kReprojectionAlpha = 3.0;   // Session.h:13
-    // multi-GPU: clouds below this many points are voxelised on every rank instead of sharded + all-gathered (env LTM_VOXEL_SHARD_MIN)
+    // multi-GPU: clouds below this many points (default 2^24) are voxelised on every rank instead of sharded + all-gathered: the
+    // exchange ships the whole output to every rank, which costs more than the sort it saves unless the input is several times
+    // larger than the output (makeGlobalMap) (env LTM_VOXEL_SHARD_MIN)
     static size_t kVoxelShardMin;
 
     explicit Session(std::shared_ptr<Device> dev);

@@ -16,7 +16,7 @@
 namespace ltremovert
 {
 
-size_t Session::kVoxelShardMin = getenv("LTM_VOXEL_SHARD_MIN") ? (size_t)atoll(getenv("LTM_VOXEL_SHARD_MIN")) : ((size_t)1 << 18);
+size_t Session::kVoxelShardMin = getenv("LTM_VOXEL_SHARD_MIN") ? (size_t)atoll(getenv("LTM_VOXEL_SHARD_MIN")) : ((size_t)1 << 24);
 
 Device::Device(const RosParamServer& p, int device_ordinal, std::shared_ptr<Comm> comm_) : comm(std::move(comm_))
 {
