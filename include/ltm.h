@@ -152,6 +152,10 @@ int ltm_merge_to_global(ltm_ctx*, ltm_scanset scans, ltm_poses poses, ltm_cloud*
 
 /* utility.cpp:204-219 octreeDownsampling (PCL OctreePointCloudVoxelCentroid): voxel centroids in octree DFS order */
 int ltm_voxel_centroid(ltm_ctx*, ltm_cloud in, float leaf, ltm_cloud* out);
+/* the same for n independent clouds at once (e.g. the static and the dynamic map after a vote pass, Removerter.cpp:894-903; the eight
+ * maps of Removerter.cpp:1445-1476): identical results, but the host reads all bounding boxes and all voxel counts in two round
+ * trips for the whole batch instead of two per cloud */
+int ltm_voxel_centroid_batch(ltm_ctx*, size_t n, const ltm_cloud* in, const float* leaf, ltm_cloud* out);
 /* multi-GPU form of the above: only the voxels of shard `shard` of `n_shards`.  The Morton key space of the
  * octree is cut into n_shards contiguous ranges of about equal point count (a pure function of `in`), so the outputs of
  * shards 0..n_shards-1 concatenated in order ARE ltm_voxel_centroid(in); each rank sorts 1/n_shards of the points. */

@@ -80,6 +80,7 @@ SIGNATURES = {
     "ltm_merge_to_global": (_i, [_vp, _u64, _u64, _pu64]),
     "ltm_voxel_centroid": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_voxel_centroid_shard": (_i, [_vp, _u64, _f, C.c_uint32, C.c_uint32, _pu64]),
+    "ltm_voxel_centroid_batch": (_i, [_vp, _sz, _pu64, C.POINTER(_f), _pu64]),
     "ltm_voxel_centroid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
@@ -253,6 +254,14 @@ class Context:
         out = _u64()
         self._ck(self.lib.ltm_voxel_centroid(self.h, cloud.h, leaf, C.byref(out)))
         return Cloud(self, out.value)
+
+    def voxel_centroid_batch(self, clouds, leafs):
+        n = len(clouds)
+        ins = (_u64 * n)(*[c.h for c in clouds])
+        lf = (_f * n)(*[float(x) for x in leafs])
+        outs = (_u64 * n)()
+        self._ck(self.lib.ltm_voxel_centroid_batch(self.h, n, ins, lf, outs))
+        return [Cloud(self, outs[k]) for k in range(n)]
 
     def voxel_centroid_shard(self, cloud, leaf, shard, n_shards):
         out = _u64()

@@ -668,6 +668,84 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
     return nvox;
 }
 
+// Several independent voxel grids as one batch: the stages of every cloud are enqueued phase by phase and the host reads all bounding
+// boxes in ONE copy and all voxel counts in ONE copy -- two host round trips (~70 us of idle GPU each) for the whole batch instead
+// of two per cloud.  Results are exactly those of voxel_centroid_raw (same kernels, same order inside each cloud).
+struct VoxelJob {
+    const float4* pts; size_t n; float leaf;
+    OctreeFrame f; unsigned ib = 1, kshift = 0, mbits = 0; bool packed = false;
+    std::unique_ptr<DevBuf> keys, idx, keys2, idx2, heads, pos;
+    float4* out = nullptr; size_t nvox = 0;
+};
+void voxel_centroid_batch(ltm_ctx* c, std::vector<VoxelJob>& jobs)
+{
+    const size_t nj = jobs.size();
+    if (nj == 0) return;
+    double tot_pts = 0;
+    for (VoxelJob& j : jobs) {
+        LTM_REQUIRE(j.leaf > 0.0f || j.n == 0, "leaf size must be positive");
+        LTM_REQUIRE(j.n < 0xffffffffull, "cloud too large for 32-bit point indices");
+        tot_pts += (double)j.n;
+    }
+    ProfScope p(c, "voxel", tot_pts, 64.0 * tot_pts);
+    // phase A: bounding boxes, one round trip
+    DevBuf bb(c, nj * 6 * sizeof(uint32_t));
+    for (size_t k = 0; k < nj; ++k) {
+        LTM_HIP(bbox_init(bb.as<uint32_t>() + 6 * k, c->stream));
+        LTM_HIP(bbox_reduce(jobs[k].pts, jobs[k].n, bb.as<uint32_t>() + 6 * k, c->stream));
+    }
+    std::vector<uint32_t> enc(nj * 6);
+    d2h(c, enc.data(), bb.p, enc.size() * 4);
+    // phase B: keys, sort, head flags, scan; the counts go to one small device array
+    DevBuf counts(c, nj * 4);
+    for (size_t k = 0; k < nj; ++k) {
+        VoxelJob& j = jobs[k];
+        if (j.n == 0) { LTM_HIP(hipMemsetAsync(counts.as<uint32_t>() + k, 0, 4, c->stream)); continue; }
+        float mn[3], mx[3];
+        for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]); }
+        if (!octree_frame_from_bbox(mn, mx, j.leaf, &j.f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+        j.mbits = 3 * j.f.depth;
+        while (j.ib < 32 && ((size_t)1 << j.ib) < j.n) ++j.ib;
+        j.packed = c->voxel_packed_sort && j.mbits + j.ib <= 64;
+        j.kshift = j.packed ? j.ib : 0;
+        const size_t n = j.n;
+        j.keys.reset(new DevBuf(c, n * 8)); j.idx.reset(new DevBuf(c, j.packed ? 8 : n * 4));
+        j.keys2.reset(new DevBuf(c, n * 8)); j.idx2.reset(new DevBuf(c, j.packed ? 8 : n * 4));
+        if (j.packed) {
+            LTM_HIP(morton_keys_packed(j.pts, n, j.f, j.ib, j.keys->as<uint64_t>(), c->stream));
+            const size_t stb = sort_keys_temp_bytes(n);
+            DevBuf stemp(c, stb);
+            LTM_HIP(sort_keys_u64(j.keys->as<uint64_t>(), j.keys2->as<uint64_t>(), n, j.ib, j.ib + j.mbits, stemp.p, stb, c->stream));
+        } else {
+            LTM_HIP(morton_keys(j.pts, n, j.f, j.keys->as<uint64_t>(), j.idx->as<uint32_t>(), c->stream));
+            const size_t stb = sort_temp_bytes(n);
+            DevBuf stemp(c, stb);
+            LTM_HIP(sort_pairs_u64(j.keys->as<uint64_t>(), j.keys2->as<uint64_t>(), j.idx->as<uint32_t>(), j.idx2->as<uint32_t>(), n, j.mbits, stemp.p, stb, c->stream));
+        }
+        j.keys.reset(); j.idx.reset();      // stream-ordered pool: reusable by the next job's buffers
+        j.heads.reset(new DevBuf(c, n)); j.pos.reset(new DevBuf(c, n * 4));
+        LTM_HIP(head_flags(j.keys2->as<uint64_t>(), n, j.heads->as<uint8_t>(), c->stream, j.kshift));
+        const size_t tb = scan_temp_bytes(n);
+        DevBuf temp(c, tb);
+        LTM_HIP(exclusive_scan_u8(j.heads->as<uint8_t>(), j.pos->as<uint32_t>(), n, temp.p, tb, c->stream));
+        LTM_HIP(scan_total_to(j.heads->as<uint8_t>(), j.pos->as<uint32_t>(), n, counts.as<uint32_t>() + k, c->stream));
+    }
+    std::vector<uint32_t> nv(nj);
+    d2h(c, nv.data(), counts.p, nj * 4);
+    // phase C: centroids
+    for (size_t k = 0; k < nj; ++k) {
+        VoxelJob& j = jobs[k];
+        j.nvox = nv[k];
+        if (j.n == 0) continue;
+        DevBuf starts(c, j.nvox * 4);
+        LTM_HIP(segment_starts(j.heads->as<uint8_t>(), j.pos->as<uint32_t>(), j.n, starts.as<uint32_t>(), c->stream));
+        j.out = reinterpret_cast<float4*>(c->pool.alloc(j.nvox * sizeof(float4)));
+        if (j.packed) LTM_HIP(voxel_centroids_packed(j.pts, j.keys2->as<uint64_t>(), ((uint64_t)1 << j.ib) - 1, starts.as<uint32_t>(), j.nvox, j.n, j.out, c->stream));
+        else LTM_HIP(voxel_centroids(j.pts, j.idx2->as<uint32_t>(), starts.as<uint32_t>(), j.nvox, j.n, j.out, c->stream));
+        j.keys2.reset(); j.idx2.reset(); j.heads.reset(); j.pos.reset();
+    }
+}
+
 // ------------------------------------------------------------------------------------ kNN
 struct KnnIndex {
     ltm_ctx* c;
@@ -1342,6 +1420,20 @@ int ltm_voxel_centroid(ltm_ctx* c, ltm_cloud hin, float leaf, ltm_cloud* out)
         const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d);
         if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
         *out = new_cloud(c, d, nv);
+    });
+}
+
+int ltm_voxel_centroid_batch(ltm_ctx* c, size_t n, const ltm_cloud* in, const float* leaf, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE((in && leaf && out) || n == 0, "null argument");
+        std::vector<VoxelJob> jobs(n);
+        for (size_t k = 0; k < n; ++k) { const Cloud cl = get_cloud(c, in[k]); jobs[k].pts = cl.d; jobs[k].n = cl.n; jobs[k].leaf = leaf[k]; }
+        voxel_centroid_batch(c, jobs);
+        for (size_t k = 0; k < n; ++k) {
+            float4* d = jobs[k].out ? jobs[k].out : reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+            out[k] = new_cloud(c, d, jobs[k].nvox);
+        }
     });
 }
 

@@ -112,6 +112,7 @@ hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_
 hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const OctreeFrame* frames_dev,
                            unsigned shift, uint64_t* keys, uint32_t* idx, hipStream_t s);
 size_t sort_temp_bytes(size_t n);
+hipError_t scan_total_to(const uint8_t* flags, const uint32_t* pos, size_t n, uint32_t* out_dev, hipStream_t s);
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
                           unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s, unsigned shift = 0);   // compares keys >> shift

@@ -1467,6 +1467,19 @@ hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, unsign
     k_morton_keys_packed<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, f, idx_bits, keys);
     return hipGetLastError();
 }
+// number of set flags given the exclusive scan `pos` of `flags` (n > 0), written to *out on the device: lets several counts of a
+// batch travel to the host in one copy
+__global__ void k_scan_total(const uint8_t* __restrict__ flags, const uint32_t* __restrict__ pos, size_t n, uint32_t* __restrict__ out)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *out = pos[n - 1] + (flags[n - 1] ? 1u : 0u);
+}
+hipError_t scan_total_to(const uint8_t* flags, const uint32_t* pos, size_t n, uint32_t* out_dev, hipStream_t s)
+{
+    if (!n) return hipMemsetAsync(out_dev, 0, 4, s);
+    k_scan_total<<<dim3(1), dim3(64), 0, s>>>(flags, pos, n, out_dev);
+    return hipGetLastError();
+}
+
 size_t sort_keys_temp_bytes(size_t n)
 {
     size_t bytes = 0;

@@ -120,6 +120,18 @@ class ShardedOps:
             return self.ops.voxel(c, leaf)
         return self._allgather_cloud(self.ops.voxel_shard(c, leaf, self.rank, self.world))
 
+    def voxel_batch(self, clouds, leaf):
+        if self.world == 1:
+            return self.ops.voxel_batch(clouds, leaf)
+        out = [None] * len(clouds)
+        small = [i for i, c in enumerate(clouds) if self.ops.size(c) < self.VOXEL_SHARD_MIN]
+        for i, r in zip(small, self.ops.voxel_batch([clouds[i] for i in small], leaf) if small else []):
+            out[i] = r
+        for i, c in enumerate(clouds):
+            if out[i] is None:
+                out[i] = self.voxel(c, leaf)
+        return out
+
     def materialize(self, scans):
         """full scan set on every rank (used for the final per-keyframe outputs)"""
         return scans.full() if isinstance(scans, LazyScans) else scans

@@ -146,6 +146,9 @@ public:
     void stageArgs(const ScansPtr& scans, ltm_poses* poses, size_t* kb, size_t* ke) const;
     CloudPtr mergeScansToGlobal(const ScansPtr& scans) const;        // utility.cpp:170-192
     CloudPtr octreeDownsampling(const CloudPtr& src, float leaf) const;   // utility.cpp:204-219
+    // the same for several independent clouds (consecutive octreeDownsampling calls of the reference): one ltm_voxel_centroid_batch,
+    // i.e. two host round trips for all of them
+    std::vector<CloudPtr> octreeDownsamplingBatch(const std::vector<CloudPtr>& src, float leaf) const;
     CloudPtr concat(const std::vector<CloudPtr>& parts) const;
     void uploadPoses();
 };

@@ -198,10 +198,11 @@ void Removerter::removeOnce(Session& t, const Session& src, float _res_alpha)   
 {
     LTM_INFO("\nSelf-removing starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMap(t, src, _res_alpha);
-    t.map_global_curr_static_ = t.octreeDownsampling(static_tt, 0.05f);
+    auto ds = t.octreeDownsamplingBatch({static_tt, append(t, t.map_global_curr_dynamic_, dynamic_tt)}, 0.05f);    // :896, :903 -- independent
+    t.map_global_curr_static_ = ds[0];
     LTM_INFO(" Current Static pointcloud have: " << t.map_global_curr_static_->size() << " points.");
     t.map_global_curr_ = t.map_global_curr_static_;
-    t.map_global_curr_dynamic_ = t.octreeDownsampling(append(t, t.map_global_curr_dynamic_, dynamic_tt), 0.05f);
+    t.map_global_curr_dynamic_ = ds[1];
     LTM_INFO(" Current Dynamic pointcloud have: " << t.map_global_curr_dynamic_->size() << " points.");
 }
 
@@ -209,10 +210,11 @@ void Removerter::revertOnce(Session& t, const Session& src, float _res_alpha)   
 {
     LTM_INFO("\nSelf-reverting starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMap(t, src, _res_alpha);
-    t.map_global_curr_dynamic_ = t.octreeDownsampling(dynamic_tt, 0.05f);
+    auto ds = t.octreeDownsamplingBatch({dynamic_tt, append(t, t.map_global_curr_static_, static_tt)}, 0.05f);     // :921, :928
+    t.map_global_curr_dynamic_ = ds[0];
     LTM_INFO(" Current Dynamic pointcloud have: " << t.map_global_curr_dynamic_->size() << " points.");
     t.map_global_curr_ = t.map_global_curr_dynamic_;
-    t.map_global_curr_static_ = t.octreeDownsampling(append(t, t.map_global_curr_static_, static_tt), 0.05f);
+    t.map_global_curr_static_ = ds[1];
     LTM_INFO(" Current Static pointcloud have: " << t.map_global_curr_static_->size() << " points.");
 }
 
@@ -268,17 +270,19 @@ void Removerter::iremoveOnceForND(Session& t, const Session& src, float _res_alp
 {
     LTM_INFO("\nIdentifying Strong/Weak ND points starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMapForND(t, src, _res_alpha);
-    t.map_global_nd_strong_ = t.octreeDownsampling(static_tt, 0.05f);
+    auto ds = t.octreeDownsamplingBatch({static_tt, append(t, t.map_global_nd_weak_, dynamic_tt)}, 0.05f);
+    t.map_global_nd_strong_ = ds[0];
     t.map_global_nd_ = t.map_global_nd_strong_;
-    t.map_global_nd_weak_ = t.octreeDownsampling(append(t, t.map_global_nd_weak_, dynamic_tt), 0.05f);
+    t.map_global_nd_weak_ = ds[1];
 }
 void Removerter::removeOnceForPD(Session& t, const Session& src, float _res_alpha)    // Removerter.cpp:856-880
 {
     LTM_INFO("\nIdentifying Strong/Weak PD points starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMapForPD(t, src, _res_alpha);
-    t.map_global_pd_strong_ = t.octreeDownsampling(static_tt, 0.05f);
+    auto ds = t.octreeDownsamplingBatch({static_tt, append(t, t.map_global_pd_weak_, dynamic_tt)}, 0.05f);
+    t.map_global_pd_strong_ = ds[0];
     t.map_global_pd_ = t.map_global_pd_strong_;
-    t.map_global_pd_weak_ = t.octreeDownsampling(append(t, t.map_global_pd_weak_, dynamic_tt), 0.05f);
+    t.map_global_pd_weak_ = ds[1];
 }
 void Removerter::filterStrongPD(Session& a, Session& b) { const float res = 2.5; for (int i = 0; i < 3; ++i) removeOnceForPD(a, b, res); }   // :1395-1401
 void Removerter::filterStrongND(Session& a, Session& b) { const float res = 2.5; for (int i = 0; i < 3; ++i) iremoveOnceForND(a, b, res); }  // :1403-1411
@@ -304,23 +308,29 @@ void Removerter::detectLowDynamicPoints(void)                                   
 
     // :1443-1480 merged maps "for visual debug" (they also re-voxelise state that Step 3 reads)
     Session& C = central_sess_; Session& Q = query_sess_;
-    union_q_ = Q.octreeDownsampling(Q.mergeScansToGlobal(Q.scans_knn_coexist_), 0.05f);
+    const bool has_strong_nd = C.map_global_nd_strong_->size() != 0;
+    std::vector<CloudPtr> ins = {Q.mergeScansToGlobal(Q.scans_knn_coexist_), C.mergeScansToGlobal(C.scans_knn_coexist_),
+                                 Q.mergeScansToGlobal(Q.scans_knn_diff_), C.mergeScansToGlobal(C.scans_knn_diff_),
+                                 C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_};
+    if (has_strong_nd) ins.push_back(C.map_global_nd_strong_);
+    auto ds = C.octreeDownsamplingBatch(ins, 0.05f);        // the eight independent voxel grids of :1445-1476 as one batch
+    union_q_ = ds[0];
     saveMap(save_pcd_directory_ + "union_map_queryside.pcd", union_q_);
-    union_c_ = C.octreeDownsampling(C.mergeScansToGlobal(C.scans_knn_coexist_), 0.05f);
+    union_c_ = ds[1];
     saveMap(save_pcd_directory_ + "union_map_centralside.pcd", union_c_);
-    saveMap(save_pcd_directory_ + "pd_map.pcd", Q.octreeDownsampling(Q.mergeScansToGlobal(Q.scans_knn_diff_), 0.05f));
-    saveMap(save_pcd_directory_ + "nd_map.pcd", C.octreeDownsampling(C.mergeScansToGlobal(C.scans_knn_diff_), 0.05f));
+    saveMap(save_pcd_directory_ + "pd_map.pcd", ds[2]);
+    saveMap(save_pcd_directory_ + "nd_map.pcd", ds[3]);
     LTM_INFO(" Union, PD, and ND map saved ");
-    if (C.map_global_nd_strong_->size() != 0) {
-        C.map_global_nd_strong_ = C.octreeDownsampling(C.map_global_nd_strong_, 0.05f);
+    if (has_strong_nd) {
+        C.map_global_nd_strong_ = ds[7];
         saveMap(save_pcd_directory_ + "strong_nd_map.pcd", C.map_global_nd_strong_);
     }
-    C.map_global_nd_weak_ = C.octreeDownsampling(C.map_global_nd_weak_, 0.05f);
+    C.map_global_nd_weak_ = ds[4];
     saveMap(save_pcd_directory_ + "weak_nd_map.pcd", C.map_global_nd_weak_);
     LTM_INFO(" Strong/Weak ND map saved ");
-    Q.map_global_pd_strong_ = Q.octreeDownsampling(Q.map_global_pd_strong_, 0.05f);
+    Q.map_global_pd_strong_ = ds[5];
     saveMap(save_pcd_directory_ + "strong_pd_map.pcd", Q.map_global_pd_strong_);
-    Q.map_global_pd_weak_ = Q.octreeDownsampling(Q.map_global_pd_weak_, 0.05f);
+    Q.map_global_pd_weak_ = ds[6];
     saveMap(save_pcd_directory_ + "weak_pd_map.pcd", Q.map_global_pd_weak_);
     LTM_INFO(" Strong/Weak PD map saved ");
 }
@@ -331,9 +341,10 @@ void Removerter::updateCurrentMap(void)                                         
     // the union maps of :1489-1493 are recomputed from unchanged inputs in the reference: identical to :1445-1451
     CloudPtr updated = C.concat({union_q_, union_c_, C.map_global_nd_weak_});
     LTM_INFO(" -- The number of map points (updating ...): " << updated->size());
-    C.map_global_updated_strong_ = C.octreeDownsampling(C.concat({updated, C.map_global_pd_strong_}), 0.05f);
+    auto ds = C.octreeDownsamplingBatch({C.concat({updated, C.map_global_pd_strong_}), C.concat({updated, C.map_global_pd_orig_})}, 0.05f);
+    C.map_global_updated_strong_ = ds[0];
     LTM_INFO(" -- The number of strong map points (updating ...): " << C.map_global_updated_strong_->size());
-    C.map_global_updated_ = C.octreeDownsampling(C.concat({updated, C.map_global_pd_orig_}), 0.05f);
+    C.map_global_updated_ = ds[1];
     LTM_INFO(" -- The number of map points (updating ...): " << C.map_global_updated_->size());
     saveMap(save_pcd_directory_ + "updated_map.pcd", C.map_global_updated_);
     saveMap(save_pcd_directory_ + "updated_map_strong.pcd", C.map_global_updated_strong_);

@@ -397,6 +397,23 @@ CloudPtr Session::octreeDownsampling(const CloudPtr& src, float leaf) const
     ltmCheck(ctx, ltm_voxel_centroid(ctx, src->h, leaf, &h), "ltm_voxel_centroid");
     return wrap(h);
 }
+std::vector<CloudPtr> Session::octreeDownsamplingBatch(const std::vector<CloudPtr>& src, float leaf) const
+{
+    std::vector<CloudPtr> out(src.size());
+    std::vector<size_t> batch;
+    for (size_t i = 0; i < src.size(); ++i) {
+        if (dev_->world() > 1 && src[i]->size() >= kVoxelShardMin) out[i] = octreeDownsampling(src[i], leaf);      // sharded + all-gathered
+        else batch.push_back(i);
+    }
+    if (!batch.empty()) {
+        std::vector<ltm_cloud> in(batch.size()), res(batch.size(), 0);
+        std::vector<float> leafs(batch.size(), leaf);
+        for (size_t k = 0; k < batch.size(); ++k) in[k] = src[batch[k]]->h;
+        ltmCheck(dev_->ctx, ltm_voxel_centroid_batch(dev_->ctx, in.size(), in.data(), leafs.data(), res.data()), "ltm_voxel_centroid_batch");
+        for (size_t k = 0; k < batch.size(); ++k) out[batch[k]] = wrap(res[k]);
+    }
+    return out;
+}
 CloudPtr Session::concat(const std::vector<CloudPtr>& parts) const
 {
     std::vector<ltm_cloud> hs;

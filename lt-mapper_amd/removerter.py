@@ -46,6 +46,7 @@ class HipOps:
     # stages
     def merge_to_global(self, scans, poses): return self.ctx.merge_to_global(scans, poses)
     def voxel(self, c, leaf): return self.ctx.voxel_centroid(c, leaf)
+    def voxel_batch(self, clouds, leaf): return self.ctx.voxel_centroid_batch(clouds, [leaf] * len(clouds))   # independent grids, two host round trips in all
     def voxel_shard(self, c, leaf, shard, n_shards): return self.ctx.voxel_centroid_shard(c, leaf, shard, n_shards)
     def voxel_scanset(self, s, leaf): return self.ctx.voxel_centroid_scanset(s, leaf)
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
@@ -159,6 +160,9 @@ class Removerter:
     def octreeDownsampling(self, cloud, leaf):          # utility.cpp:204-219
         return self.ops.voxel(cloud, leaf)
 
+    def octreeDownsamplingBatch(self, clouds, leaf):    # the same for several independent clouds (consecutive calls in the reference)
+        return self.ops.voxel_batch(list(clouds), leaf)
+
     def _append(self, a, b):                            # `*a += *b`
         if a is None:
             return self.ops.clone(b)
@@ -166,24 +170,26 @@ class Removerter:
 
     # ------------------------------------------------------------------ Step 0
     def makeGlobalMap(self):                            # Removerter.cpp:213-252 (+ Session.cpp:186-202)
-        for s in (self.central_sess_, self.query_sess_):
+        sess = (self.central_sess_, self.query_sess_)
+        for s in sess:
             s.map_global_orig_ = self.ops.merge_to_global(s.keyframe_scans_, s.keyframe_poses)
-            s.map_global_curr_ = self.octreeDownsampling(s.map_global_orig_, self.P.downsample_voxel_size)
+        for s, m in zip(sess, self.octreeDownsamplingBatch([s.map_global_orig_ for s in sess], self.P.downsample_voxel_size)):
+            s.map_global_curr_ = m
             self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_curr_
             s.map_global_orig_ = None   # only ever read by makeGlobalMap
 
     # ------------------------------------------------------------------ Step 1
     def removeOnce(self, target, source, res_alpha):    # Removerter.cpp:882-905
         static_tt, dynamic_tt = self.ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
-        target.map_global_curr_static_ = self.octreeDownsampling(static_tt, 0.05)
+        target.map_global_curr_static_, target.map_global_curr_dynamic_ = self.octreeDownsamplingBatch(
+            [static_tt, self._append(target.map_global_curr_dynamic_, dynamic_tt)], 0.05)      # :896, :903 -- independent of each other
         target.map_global_curr_ = target.map_global_curr_static_
-        target.map_global_curr_dynamic_ = self.octreeDownsampling(self._append(target.map_global_curr_dynamic_, dynamic_tt), 0.05)
 
     def revertOnce(self, target, source, res_alpha):    # Removerter.cpp:908-931
         static_tt, dynamic_tt = self.ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
-        target.map_global_curr_dynamic_ = self.octreeDownsampling(dynamic_tt, 0.05)
+        target.map_global_curr_dynamic_, target.map_global_curr_static_ = self.octreeDownsamplingBatch(
+            [dynamic_tt, self._append(target.map_global_curr_static_, static_tt)], 0.05)       # :921, :928
         target.map_global_curr_ = target.map_global_curr_dynamic_
-        target.map_global_curr_static_ = self.octreeDownsampling(self._append(target.map_global_curr_static_, static_tt), 0.05)
 
     def selfRemovert(self, sess, repeat=1):             # Removerter.cpp:1378-1393
         for res in self.P.remove_resolution_list:
@@ -208,9 +214,11 @@ class Removerter:
         if not self.P.gpu_skip_hd_knn:
             t0 = time.perf_counter()
             k, thr = self.P.num_nn_points_within, self.P.dist_nn_points_within
-            for s, name in ((C, "central_sess_high_dyn"), (Q, "query_sess_high_dyn")):
+            merged = []
+            for s in (C, Q):
                 _, s.keyframe_scans_dynamic_ = self.ops.knn_partition(s.map_global_curr_static_, s.keyframe_scans_, s.keyframe_poses, k, thr)  # Session.cpp:487-504
-                self.outputs[name] = self.octreeDownsampling(self.ops.merge_to_global(s.keyframe_scans_dynamic_, s.keyframe_poses), 0.05)
+                merged.append(self.ops.merge_to_global(s.keyframe_scans_dynamic_, s.keyframe_poses))
+            self.outputs["central_sess_high_dyn"], self.outputs["query_sess_high_dyn"] = self.octreeDownsamplingBatch(merged, 0.05)
             self._tick("hd_knn", t0)
 
     def parseStaticScansViaProjection(self):            # Removerter.cpp:1527-1538, Session.cpp:305-309
@@ -223,9 +231,8 @@ class Removerter:
     def _removeOnceLD(self, target_maps, source, res_alpha, mode):   # iremoveOnceForND :831-854 / removeOnceForPD :856-880
         cur, strong, weak = target_maps
         static_tt, dynamic_tt = self.ops.vote_partition(cur, source.keyframe_scans_static_projected_, source.keyframe_poses, res_alpha, 0.1, mode)
-        strong = self.octreeDownsampling(static_tt, 0.05)
+        strong, weak = self.octreeDownsamplingBatch([static_tt, self._append(weak, dynamic_tt)], 0.05)
         cur = strong
-        weak = self.octreeDownsampling(self._append(weak, dynamic_tt), 0.05)
         return cur, strong, weak
 
     def detectLowDynamicPoints(self):                   # Removerter.cpp:1413-1481
@@ -259,15 +266,21 @@ class Removerter:
         t0 = time.perf_counter()
         # :1443-1480 merged maps "for visual debug" -- several of these re-voxelise state that Step 3 reads
         o = self.outputs
-        self._union_q = o["union_map_queryside"] = self.octreeDownsampling(self.ops.merge_to_global(Q.scans_knn_coexist_, Q.keyframe_poses), 0.05)
-        self._union_c = o["union_map_centralside"] = self.octreeDownsampling(self.ops.merge_to_global(C.scans_knn_coexist_, C.keyframe_poses), 0.05)
-        o["pd_map"] = self.octreeDownsampling(self.ops.merge_to_global(Q.scans_knn_diff_, Q.keyframe_poses), 0.05)
-        o["nd_map"] = self.octreeDownsampling(self.ops.merge_to_global(C.scans_knn_diff_, C.keyframe_poses), 0.05)
-        if self.ops.size(C.map_global_nd_strong_) != 0:
-            C.map_global_nd_strong_ = o["strong_nd_map"] = self.octreeDownsampling(C.map_global_nd_strong_, 0.05)
-        C.map_global_nd_weak_ = o["weak_nd_map"] = self.octreeDownsampling(C.map_global_nd_weak_, 0.05)
-        Q.map_global_pd_strong_ = o["strong_pd_map"] = self.octreeDownsampling(Q.map_global_pd_strong_, 0.05)
-        Q.map_global_pd_weak_ = o["weak_pd_map"] = self.octreeDownsampling(Q.map_global_pd_weak_, 0.05)
+        ins = [self.ops.merge_to_global(Q.scans_knn_coexist_, Q.keyframe_poses), self.ops.merge_to_global(C.scans_knn_coexist_, C.keyframe_poses),
+               self.ops.merge_to_global(Q.scans_knn_diff_, Q.keyframe_poses), self.ops.merge_to_global(C.scans_knn_diff_, C.keyframe_poses),
+               C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_]
+        has_strong_nd = self.ops.size(C.map_global_nd_strong_) != 0
+        if has_strong_nd:
+            ins.append(C.map_global_nd_strong_)
+        res = self.octreeDownsamplingBatch(ins, 0.05)      # eight independent grids (:1445-1476), one batch
+        self._union_q = o["union_map_queryside"] = res[0]
+        self._union_c = o["union_map_centralside"] = res[1]
+        o["pd_map"], o["nd_map"] = res[2], res[3]
+        C.map_global_nd_weak_ = o["weak_nd_map"] = res[4]
+        Q.map_global_pd_strong_ = o["strong_pd_map"] = res[5]
+        Q.map_global_pd_weak_ = o["weak_pd_map"] = res[6]
+        if has_strong_nd:
+            C.map_global_nd_strong_ = o["strong_nd_map"] = res[7]
         self._tick("ld_maps", t0)
 
     # ------------------------------------------------------------------ Step 3
@@ -276,8 +289,8 @@ class Removerter:
         C = self.central_sess_
         # the two union maps are recomputed at :1489-1493 from unchanged inputs: identical to the ones of :1445-1451
         updated = self.ops.concat([self._union_q, self._union_c, C.map_global_nd_weak_])
-        C.map_global_updated_strong_ = self.octreeDownsampling(self.ops.concat([updated, C.map_global_pd_strong_]), 0.05)
-        C.map_global_updated_ = self.octreeDownsampling(self.ops.concat([updated, C.map_global_pd_orig_]), 0.05)
+        C.map_global_updated_strong_, C.map_global_updated_ = self.octreeDownsamplingBatch(
+            [self.ops.concat([updated, C.map_global_pd_strong_]), self.ops.concat([updated, C.map_global_pd_orig_])], 0.05)
         self.outputs["updated_map"] = C.map_global_updated_
         self.outputs["updated_map_strong"] = C.map_global_updated_strong_
         self._tick("update_map", t0)

@@ -45,6 +45,7 @@ class OracleOps:
     def sync(self): pass
     def merge_to_global(self, s, p): return _c(orc.merge_to_global(s.pts, s.off, p.poses, self.l2b))
     def voxel(self, c, leaf): return _c(orc.voxel_centroid(c, leaf))
+    def voxel_batch(self, cs, leaf): return [self.voxel(c, leaf) for c in cs]
 
     def voxel_shard(self, c, leaf, shard, n_shards):
         # any contiguous split of the full output has the property ShardedOps relies on (concatenation == unsharded)
