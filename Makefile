@@ -23,7 +23,11 @@ oracle:
 host:
 	@if [ -f $(PKG)/host/Makefile ]; then $(MAKE) -C $(PKG)/host; fi
 
+ubench: tools/ubench/valu_rate
+tools/ubench/valu_rate: tools/ubench/valu_rate.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -w $< -o $@
+
 clean:
-	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so
+	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so tools/ubench/valu_rate
 	$(MAKE) -C oracle clean
-.PHONY: all hip oracle host clean
+.PHONY: all hip oracle host ubench clean
