@@ -64,6 +64,10 @@ json.dump(out, open(sys.argv[1], "w"), indent=1)
 PY
 cp "$OUT/pmc_latest.json" "$OUT/${TAG}_pmc.json"
 
+# 3b. SQ issue / wait counters of the heaviest kernels, and the VALU issue-rate micro-benchmark (make ubench)
+(cd "$ROOT" && bash tools/pmc_sq.sh) > "$OUT/${TAG}_pmc_sq.txt" 2>&1
+[ -x "$ROOT/tools/ubench/valu_rate" ] && "$ROOT/tools/ubench/valu_rate" > "$OUT/${TAG}_valu_rate_ubench.txt" 2>&1
+
 # 4. the other configurations (one run each)
 if [ -z "$QUICK" ]; then
   $BENCH --workload street-2x2000-hdl64e-1res --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_street_2x2000_hdl64e.json"
