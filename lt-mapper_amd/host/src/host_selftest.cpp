@@ -32,6 +32,16 @@ static std::string lzf_literals(const std::string& in)
 
 int main(int argc, char** argv)
 {
+    // host_selftest --voxelgrid <in.pcd> <leaf> <out.pcd>: the loader's per-scan step (loadPCDFile + pcl::VoxelGrid restatement,
+    // Session.cpp:272-292) on one file, so that tests can compare it with the oracle's restatement
+    if (argc == 5 && std::string(argv[1]) == "--voxelgrid") {
+        Cloud in, out;
+        std::string err;
+        if (!loadPCDFile(argv[2], in, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        voxelGridFilter(std::move(in), std::stof(argv[3]), out);
+        if (!savePCDFileBinary(argv[4], out, false, &err)) { std::fprintf(stderr, "%s\n", err.c_str()); return 1; }
+        return 0;
+    }
     const std::string dir = argc > 1 ? argv[1] : "/tmp";
     Cloud c;
     for (int i = 0; i < 1000; ++i) c.push_back(PointType{0.1f * i, -0.25f * i, 1.0f / (i + 1), (float)(i % 256)});

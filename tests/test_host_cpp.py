@@ -58,3 +58,29 @@ def test_cascade_yaml_hand_over(tmp_path):
     assert 'query_sess_scan_dir: "/data/03/Scans/"' in y2 and 'query_sess_pose_path: "/data/03/poses.txt"' in y2
     assert "start_idx: 0" in y2 and "end_idx: 6" in y2 and "keyframe_gap: 1" in y2 and "use_keyframe_gap: true" in y2
     assert "num_nn_points_within: 2" in y2 and f'save_pcd_directory: "{tmp_path}/out2/"' in y2
+
+
+def test_loader_voxelgrid_equals_oracle_restatement(tmp_path, orc):
+    """Session::loadKeyframes' per-scan pcl::VoxelGrid (host/src/utility.cpp) against the oracle's restatement (orc_voxel_grid, SURVEY
+    A.6) on the files themselves: a dense cloud that is really down-sampled (several leaf sizes) and a wide one that takes PCL's
+    int32-overflow early-out (output = input) -- bitwise, including the output order by voxel index"""
+    import numpy as np
+    import fileproto as fp
+    _build()
+    exe = os.path.join(HOST, "host_selftest")
+    rng = np.random.default_rng(3)
+    dense = np.concatenate([rng.uniform(-4, 4, (30000, 3)), rng.uniform(0, 255, (30000, 1))], 1).astype(np.float32)
+    wide = dense.copy()
+    wide[:, :2] *= 30.0
+    for name, pts, leafs in (("dense", dense, (0.05, 0.2, 0.5)), ("wide", wide, (0.05,))):
+        src = tmp_path / f"{name}.pcd"
+        fp.write_pcd(str(src), pts)
+        for leaf in leafs:
+            dst = tmp_path / f"{name}_{leaf}.pcd"
+            r = subprocess.run([exe, "--voxelgrid", str(src), repr(leaf), str(dst)], capture_output=True, text=True, timeout=120)
+            assert r.returncode == 0, r.stderr
+            got = fp.read_pcd(str(dst))[1]
+            want = orc.voxel_grid(pts, leaf)
+            assert got.shape == want.shape, f"{name} leaf {leaf}: {got.shape[0]} vs {want.shape[0]} points"
+            assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"{name} leaf {leaf}: values / order differ"
+            assert (len(got) == len(pts)) == (name == "wide")
