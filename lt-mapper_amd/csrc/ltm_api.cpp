@@ -140,6 +140,8 @@ struct ltm_ctx {
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
     int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
+    float cull_eps_scale = 6.0e-4f;             // LTM_CULL_EPS_SCALE: pixels of distrust per (pixel per degree), see geom_for
+    float cull_eps_floor = 1.0e-3f;             // LTM_CULL_EPS_FLOOR: the band is never narrower than this [pixels]
     // copy engine side (pipelined loader / asynchronous output fetch): its own stream, pinned staging memory
     void* scratch_pinned = nullptr;             // staging of the small host round trips (d2h / h2d helpers)
     hipStream_t copy_stream = nullptr;
@@ -369,6 +371,12 @@ Geom geom_for(const ltm_ctx* c, float alpha)
     g.rows = (int)roundf(c->cfg.vfov * alpha);
     g.cols = (int)roundf(c->cfg.hfov * alpha);
     g.fast = c->fast_math;
+    // Error budget of the bounded-error projection in ANGLE: polynomial 1.8e-6 rad (elevation) / 4e-7 (azimuth), transform 5e-7,
+    // v_rsq 1e-7, plus the reference's own float roundings of the degree / pixel arithmetic (~6e-7 rad equivalent): < 3.2e-6 rad.
+    // In pixels that is 3.2e-6 * (pixels per radian) = 1.8e-4 * alpha; the band is 6e-4 * alpha (3.3x), never below 1e-3.
+    // ltm_debug_cull_check validates it on the device (tests: 1e8 points incl. points placed on pixel boundaries).
+    const float ppd = std::max((float)g.rows / g.vfov, (float)g.cols / g.hfov);      // pixels per degree = alpha
+    g.cull_eps_px = std::max(c->cull_eps_floor, c->cull_eps_scale * ppd);
     return g;
 }
 
@@ -933,6 +941,8 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         c->fast_math = (c->selfcheck[0] == 0 && c->selfcheck[1] == 0 && c->selfcheck[2] == 0) ? 1 : 0;
         if (const char* v = getenv("LTM_FAST_MATH")) c->fast_math = c->fast_math && atoi(v);
         if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
+        if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
+        if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
     }
     *out = c;
     return LTM_OK;

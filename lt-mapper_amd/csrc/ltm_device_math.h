@@ -162,6 +162,7 @@ struct RimgGeom {
     int rows, cols;
     float frows, fcols, row_max, col_max;
     bool fast;          // the fast forms were verified for these constants
+    float eps;          // Geom::cull_eps_px
 };
 
 // utility.cpp:114-125

@@ -11,6 +11,8 @@ struct Geom {            // range-image geometry (utility.cpp:222-236 resetRimgS
     float vfov, hfov;
     int rows, cols;
     int fast;            // 1: use the self-checked fast arithmetic forms (ltm_device_math.h), 0: plain IEEE divisions
+    float cull_eps_px;   // half-width [pixels] of the band around a pixel-rounding boundary inside which the bounded-error projection
+                         // does not trust its pixel (proportional to the image resolution: the angular error is fixed, see geom_for)
 };
 
 // 3x4 row-major double (last row of the 4x4 is never used by PCL's se3 transformer)

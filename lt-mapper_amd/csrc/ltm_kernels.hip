@@ -31,6 +31,7 @@ __host__ __device__ inline RimgGeom make_geom(Geom g)
     r.half_v = g.vfov / 2.0f; r.half_h = g.hfov / 2.0f;
     r.inv_v = 1.0f / g.vfov; r.inv_h = 1.0f / g.hfov;
     r.fast = g.fast != 0;
+    r.eps = g.cull_eps_px;
     r.rows = g.rows; r.cols = g.cols;
     r.frows = (float)g.rows; r.fcols = (float)g.cols;
     r.row_max = (float)(g.rows - 1); r.col_max = (float)(g.cols - 1);
@@ -264,8 +265,10 @@ __device__ __forceinline__ TileKf tile_kf_of_block(uint32_t b, uint32_t n_tiles,
     const uint32_t kfl = r % kfg, q = r / kfg;
     const uint32_t tg = q % n_tg, kg = q / n_tg;
     TileKf t;
-    t.tile = tg * 8u + x;
-    t.kfb = kg * kfg + kfl;
+    // the divisions above run on the vector unit; hand the (uniform) results back to scalar registers so that every address derived
+    // from them is a scalar base instead of a per-use v_readfirstlane
+    t.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(tg * 8u + x));
+    t.kfb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(kg * kfg + kfl));
     t.valid = (t.tile < n_tiles) & (t.kfb < nb);
     return t;
 }
@@ -330,14 +333,13 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // pixel stays unflagged; and any flagged winner is nearer than P, so P never displaces it.  The scan images are
 // complete before this kernel runs, so the test needs no inter-workgroup ordering.
 // Phase 1 (every point): exact fp64 transform, then a bounded-error projection (atan2 within 3e-6 rad, native
-// sqrt) gives the pixel up to +-kCullEpsPx; the point survives if for ANY candidate pixel the scan range exceeds a
+// sqrt) gives the pixel up to +-Geom::cull_eps_px; the point survives if for ANY candidate pixel the scan range exceeds a
 // lower bound of its range by more than thr minus a margin (or if it is in a domain the fast forms do not cover).
 // Survivors (typically 10-20 %) are queued in LDS.  Phase 2: survivors get the exact arithmetic and the same LDS
 // pre-reduction as k_map_rimg_lds.  Labels are identical to the un-culled path (parity tests); the map image is
 // not (culled points are absent), which is why ltm_debug_range_image / reprojection / mode 1 use k_map_rimg_lds.
-static constexpr float kCullEpsPx = 3.0e-3f;
 
-// rb/cb: the pixel if it is certain; multi: within kCullEpsPx of a rounding boundary (candidates r0..r1 x c0..c1, filled by
+// rb/cb: the pixel if it is certain; multi: within cull_eps_px of a rounding boundary (candidates r0..r1 x c0..c1, filled by
 // cull_expand); r2: squared range of the approximate local point -- the exact range r_e satisfies r_e^2 in r2 * [1 - 3e-6, 1 + 3e-6]
 // (validated on the device by ltm_debug_cull_check); unusual: outside the fast forms' domain
 struct CullCand { int rb, cb, r0, r1, c0, c1; float rowh, colh, r2; bool multi, unusual; };
@@ -382,20 +384,24 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     float az = (ay > ax) ? (1.57079632679f - az_oct) : az_oct;
     az = (p.x < 0.0f) ? (3.14159265359f - az) : az;
     az = __builtin_copysignf(az, p.y);          // az >= 0: one v_bfi instead of compare + select
-    // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H))
-    cc.rowh = __builtin_fmaf(el, -row_scale, 0.5f * g.frows + 0.5f);   // rowf + 0.5: floor() of it is the rounded pixel (the sign sits on the uniform factor)
-    cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f);
-    // Outside the fast forms' domain (every such case ends in the exact path): the +-180 deg seam -- the SIGN of y picks column 0
-    // or C-1 there, and the approximate y is only good to ~1e-7 of the range, so x < 0 with |y| <= 1e-6 |x| is undecidable here
-    // (y == +-0 included); vanishing x and y (the squares would underflow); anything that made a NaN/inf; absurd ranges.
-    // rowh/colh are bounded (|atan| <= pi) unless something upstream made a NaN, and a NaN fails the "<" below.
-    const float rfr = __builtin_amdgcn_fractf(cc.rowh), cfr = __builtin_amdgcn_fractf(cc.colh);   // distance above the rounding boundary
-    const bool certain = fmaxf(fabsf(rfr - 0.5f), fabsf(cfr - 0.5f)) <= 0.5f - kCullEpsPx;
-    // The same compare also sends every point with r >= ~8000 m down the exact path (rowh + colh >= -1.3 R, so passing it means
-    // r < 8000 + ~1 km < 9800 for any image below ~8000 rows): the reference's "empty pixel = 10000 m" sentinel arithmetic
-    // (diff = 10000 - r, Removerter.cpp:398-404) flags a map point 9800..9999.9 m from the sensor on an EMPTY scan pixel, which
-    // the fast test (empty pixels never flag) would drop.  r2 * 1.25e-4 < 8000 <=> r < 8000.
-    cc.unusual = (fabsf(p.y) <= __builtin_fmaf(-1.0e-6f, p.x, 1.0e-18f)) | !(__builtin_fmaf(cc.r2, 1.25e-4f, cc.rowh + cc.colh) < 8.0e3f) | (!steep_clamps & (t_el > 1.0f));
+    // rowf = R*(1 - (el_deg + V/2)/V) = R/2 - el*(R*180/(pi*V)) ; colf = C*((az_deg + H/2)/H) = C/2 + az*(C*180/(pi*H)).
+    // rowh = rowf + 0.5 - eps: floor(rowf + 0.5) is the rounded pixel, and with the band half-width eps taken off up front
+    //   fract(rowh) < 1 - 2 eps  <=>  fract(rowf + 0.5) in [eps, 1 - eps)  <=>  the pixel is certain, and then floor(rowh) is that pixel
+    // (one fract and one compare per axis instead of a two-sided test; the sign of el sits on the uniform factor).
+    cc.rowh = __builtin_fmaf(el, -row_scale, 0.5f * g.frows + 0.5f - g.eps);
+    cc.colh = __builtin_fmaf(az, col_scale, 0.5f * g.fcols + 0.5f - g.eps);
+    const bool certain = fmaxf(__builtin_amdgcn_fractf(cc.rowh), __builtin_amdgcn_fractf(cc.colh)) < 1.0f - 2.0f * g.eps;
+    // Outside the fast forms' domain (every such case ends in the exact path):
+    //  - the +-180 deg seam -- the SIGN of y picks column 0 or C-1 there, and the approximate y is only good to ~1e-7 of the range,
+    //    so x < 0 with |y| <= 1e-6 |x| is undecidable here (y == +-0 included); the same test catches vanishing x and y (the squares
+    //    would underflow and 0 * rsq(0) makes a NaN azimuth);
+    //  - r >= 8000 m (inf included): the reference's "empty pixel = 10000 m" sentinel arithmetic (diff = 10000 - r,
+    //    Removerter.cpp:398-404) flags a map point 9800..9999.9 m from the sensor on an EMPTY scan pixel, which the fast test (empty
+    //    pixels never flag) would drop;
+    //  - steep elevations when the field of view does not clamp them.
+    // A NaN coordinate needs no guard: its range is NaN, `r < rimg` is false in the reference (utility.cpp:134), so the point never
+    // wins a pixel -- and here r2 = NaN fails both compares below and the caller's r2 < qbound, so it is dropped, which is the same.
+    cc.unusual = (fabsf(p.y) <= __builtin_fmaf(-1.0e-6f, p.x, 1.0e-18f)) | (cc.r2 > 6.4e7f) | (!steep_clamps & (t_el > 1.0f));
     cc.multi = !certain;
     // clamp(floor(v), 0, n-1) == trunc(med3(v, 0, n-1)): the bounds are integers and the clamped value is non-negative
     cc.rb = (int)__builtin_amdgcn_fmed3f(cc.rowh, 0.0f, g.frows - 1.0f);
@@ -407,17 +413,20 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
 // lower bound of the exact range from the squared approximate range (native sqrt, 1 ulp): upper bound = r_lo * (1 + 3e-6)
 __device__ __forceinline__ float cull_r_lo(float r2) { return __builtin_amdgcn_sqrtf(r2) * (1.0f - 1.5e-6f); }
 
-// candidate pixel rectangle of a point that sits within kCullEpsPx of a rounding boundary (rare)
+// candidate pixel rectangle of a point that sits within cull_eps_px of a rounding boundary (rare)
 __device__ __forceinline__ void cull_expand(const RimgGeom& g, CullCand& cc)
 {
+    // rowh / colh carry the -eps shift of cull_candidates: a fraction >= 1 - 2 eps means the unshifted value is within eps of the
+    // integer above floor(rowh) -- either pixel floor(rowh) or floor(rowh) + 1
     const float rfl = floorf(cc.rowh), cfl = floorf(cc.colh);
     const float rfr = cc.rowh - rfl, cfr = cc.colh - cfl;
     const int rc = (int)rfl, ccn = (int)cfl;
     const int rmax = g.rows - 1, cmax = g.cols - 1;
-    cc.r0 = min(max(rc - (rfr < kCullEpsPx ? 1 : 0), 0), rmax);
-    cc.r1 = min(max(rc + (rfr > 1.0f - kCullEpsPx ? 1 : 0), 0), rmax);
-    cc.c0 = min(max(ccn - (cfr < kCullEpsPx ? 1 : 0), 0), cmax);
-    cc.c1 = min(max(ccn + (cfr > 1.0f - kCullEpsPx ? 1 : 0), 0), cmax);
+    const float lim = 1.0f - 2.0f * g.eps;
+    cc.r0 = min(max(rc, 0), rmax);
+    cc.r1 = min(max(rc + (rfr >= lim ? 1 : 0), 0), rmax);
+    cc.c0 = min(max(ccn, 0), cmax);
+    cc.c1 = min(max(ccn + (cfr >= lim ? 1 : 0), 0), cmax);
 }
 
 // With a non-identity base->lidar extrinsic the exact path rounds to float between the two transforms (utility.cpp:70-71), i.e.
@@ -555,8 +564,10 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
     uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
     const float* __restrict__ qk = qbound_img + (size_t)tk.kfb * npx;
     // ---- phase 1: who can matter?  (bounded-error arithmetic only).  Four points per lane are in flight at once so the
-    // dependent scan-image load of one overlaps the arithmetic of the others.
-    {
+    // dependent scan-image load of one overlaps the arithmetic of the others.  Only full tiles: the one partial tile at the end
+    // of the map takes the exact path as a whole (below), which keeps bounds tests and clamped indices out of this loop.
+    const bool full_tile = nloc == per_block;
+    if (full_tile) {
         const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
         const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
         const float rmin = cull_min_range<B2L_IDENTITY>(b2l_h), rmin2 = rmin * rmin;
@@ -567,23 +578,22 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         float4 nxt[kInFlight];
         if (kPrefetch) {
 #pragma unroll
-            for (int u = 0; u < kInFlight; ++u) nxt[u] = mapb[min((uint32_t)u * kBlock + threadIdx.x, nloc - 1u)];
+            for (int u = 0; u < kInFlight; ++u) nxt[u] = mapb[(uint32_t)u * kBlock + threadIdx.x];
         }
+        const uint32_t lane_word = threadIdx.x << 20;            // queue word: tile-local index (12 bits) | row (9) | column (11)
 #pragma unroll
         for (uint32_t j0 = 0; j0 < (uint32_t)kPtsPerThread; j0 += kInFlight) {
             float4 pt[kInFlight];
             CullCand cc[kInFlight];
             float q0[kInFlight];
-            bool live[kInFlight];
 #pragma unroll
             for (int u = 0; u < kInFlight; ++u) {
                 const uint32_t li = (j0 + u) * kBlock + threadIdx.x;
-                live[u] = li < nloc;
                 if (kPrefetch) {
                     pt[u] = nxt[u];
-                    if (j0 + kInFlight < (uint32_t)kPtsPerThread) nxt[u] = mapb[min(li + kInFlight * kBlock, nloc - 1u)];
+                    if (j0 + kInFlight < (uint32_t)kPtsPerThread) nxt[u] = mapb[li + kInFlight * kBlock];
                 } else {
-                    pt[u] = mapb[min(li, nloc - 1u)];  // unconditional (clamped) load: a predicated one puts an s_waitcnt inside a branch per point
+                    pt[u] = mapb[li];
                 }
             }
 #pragma unroll
@@ -591,7 +601,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 bool ok;
                 const float3 p = xform_approx(ap, pt[u], ok);
                 cc[u] = cull_candidates<(VARIANT & 1) != 0>(g, p, row_scale, col_scale, steep_clamps);
-                // not certain of the pixel (within kCullEpsPx of a rounding boundary, ~1 % of the points): straight to the exact path
+                // not certain of the pixel (within cull_eps_px of a rounding boundary, ~1 % of the points): straight to the exact path
                 cc[u].unusual |= !ok_img | !ok | cc[u].multi | (B2L_IDENTITY ? false : (cc[u].r2 < rmin2));
                 q0[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(qk) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
             }
@@ -600,8 +610,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
             for (int u = 0; u < kInFlight; ++u) {
                 // qbound[px] = an upper bound of the SQUARED range below which a point of that pixel could be flagged (k_scan_qbound):
                 // one compare decides; empty pixels hold 0
-                const bool m = cc[u].unusual | (cc[u].r2 < q0[u]);
-                mt[u] = m & live[u];
+                mt[u] = cc[u].unusual | (cc[u].r2 < q0[u]);
             }
             // One LDS atomic per wave for the four points of every lane (hand-rolled ballot/mbcnt aggregation: letting the compiler
             // aggregate four separate atomicAdd(&qcount, 1) costs ~40 instructions each and one of them is taken almost always).
@@ -613,15 +622,16 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 uint32_t base = 0;
                 if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&qcount, total);
                 base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-                const uint64_t bal[kInFlight] = {b0, b1, b2, b3};
-                const uint32_t off[kInFlight] = {0u, n0, n0 + n1, n0 + n1 + n2};
+                // overflow (rare) is decided per wave and group, on the scalar unit: the whole tile takes the exact path below then
+                if (base + total <= (uint32_t)kCullQueue) {
+                    const uint64_t bal[kInFlight] = {b0, b1, b2, b3};
+                    const uint32_t off[kInFlight] = {0u, n0, n0 + n1, n0 + n1 + n2};
 #pragma unroll
-                for (int u = 0; u < kInFlight; ++u) {
-                    if (!mt[u]) continue;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-                    const uint32_t pos = base + off[u] + below;
-                    if (pos < (uint32_t)kCullQueue) {       // overflow (rare): the whole tile takes the exact path below
-                        queue[pos] = (((j0 + u) * kBlock + threadIdx.x) << 20) | ((cc[u].unusual ? 511u : (uint32_t)cc[u].rb) << 11) | (uint32_t)cc[u].cb;
+                    for (int u = 0; u < kInFlight; ++u) {
+                        if (!mt[u]) continue;
+                        const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
+                        const uint32_t rowq = cc[u].unusual ? 511u : (uint32_t)cc[u].rb;
+                        queue[base + off[u] + below] = (((rowq << 11) | (uint32_t)cc[u].cb) | lane_word) | (((j0 + u) * kBlock) << 20);
                     }
                 }
             }
@@ -630,8 +640,8 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
     __syncthreads();
     // ---- phase 2: survivors.  Certain pixel: only the exact range is computed; the ~1 % others are re-queued densely at the
     // top of the same array and get the full exact projection afterwards (keeps both loops free of divergence).
-    const uint32_t nq_all = qcount;
-    if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled 1/64: same-address atomics from every workgroup would serialise the grid
+    const uint32_t nq_all = full_tile ? qcount : (uint32_t)kCullQueue + 1u;
+    if (full_tile && threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled 1/64: same-address atomics from every workgroup would serialise the grid
         atomicAdd(&g_cull_stats[0], (unsigned long long)nq_all);
         atomicAdd(&g_cull_stats[1], (unsigned long long)nloc);
     }

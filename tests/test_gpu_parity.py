@@ -385,6 +385,14 @@ def test_cull_projection_bounds_hold(gpu_ctx):
     for alpha in (2.5, 2.375, 1.5):
         for pts in sets:
             assert gpu_ctx.cull_check(pts.astype(np.float32), alpha) == 0
+    # the distrust band is proportional to the resolution (Geom::cull_eps_px): boundary points of EVERY resolution, with a noise
+    # of the order of the band itself (tools/eps_sweep.py finds the first misses at 1/6 of the shipped band, at every alpha)
+    from tools.eps_sweep import boundary_points
+    for alpha in (1.5, 2.5, 4.0, 6.0):
+        for sigma in (1e-6, 4e-6, 1.5e-5):
+            for rmin, rmax in ((0.3, 3.0), (3.0, 150.0), (150.0, 9000.0)):
+                pts = boundary_points(rng, 1_000_000, alpha, VFOV, HFOV, sigma, rmin, rmax)
+                assert gpu_ctx.cull_check(pts, alpha) == 0, f"alpha {alpha} sigma {sigma} r {rmin}-{rmax}"
     # with the keyframe transform: exact fp64 PCL form vs the sensor-centred float-float form used by the cull test
     prng = np.random.default_rng(32)
     for trial in range(6):
