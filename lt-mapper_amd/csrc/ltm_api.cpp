@@ -140,8 +140,11 @@ struct ltm_ctx {
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
     int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
-    float cull_eps_scale = 6.0e-4f;             // LTM_CULL_EPS_SCALE: pixels of distrust per (pixel per degree), see geom_for
+    float cull_eps_scale = 0.0f;                // LTM_CULL_EPS_SCALE: pixels of distrust per (pixel per degree); 0 = the validated default of geom_for
     float cull_eps_floor = 1.0e-3f;             // LTM_CULL_EPS_FLOOR: the band is never narrower than this [pixels]
+    int el_fit = 0;                             // fitted elevation polynomial usable (vfov/2 + 2 deg <= 45 deg and error <= 1e-6 rad)
+    float el_c[4] = {1.0f, 0.0f, 0.0f, 0.0f};
+    double el_fit_err = 0.0;
     // copy engine side (pipelined loader / asynchronous output fetch): its own stream, pinned staging memory
     void* scratch_pinned = nullptr;             // staging of the small host round trips (d2h / h2d helpers)
     hipStream_t copy_stream = nullptr;
@@ -363,6 +366,64 @@ void approx_pose(const double* b2l16, const double* inv16, float* out)
     out[15] = smin > 0.5 ? (float)std::nextafter((float)smin, 0.0f) : 1.0e-30f;   // tiny = usable transform, no tile cull
 }
 
+// Degree-3 polynomial in u = t^2 with atan(t) ~ t * p(u) on t in [0, tmax], minimising the largest ANGLE error |t p(t^2) - atan t|
+// (Lawson's iteratively re-weighted least squares on a grid: 4 unknowns, converges to the minimax fit), coefficients rounded to
+// binary32.  Returns the largest error [rad] of the binary32 Horner evaluation the kernels use (fmaf = v_fma_f32), scanned on a
+// dense grid against atan in double.
+static double fit_elevation_poly(double tmax, float c_out[4])
+{
+    const int N = 4000;
+    std::vector<double> t(N), y(N), w(N, 1.0 / N), B(4 * (size_t)N);
+    for (int i = 0; i < N; ++i) {
+        t[i] = tmax * (i + 1) / N;
+        y[i] = std::atan(t[i]);
+        const double u = (t[i] / tmax) * (t[i] / tmax);        // scaled so that the normal equations stay well conditioned
+        double b = t[i];
+        for (int k = 0; k < 4; ++k) { B[4 * (size_t)i + k] = b; b *= u; }
+    }
+    double c[4] = {1.0, 0.0, 0.0, 0.0};
+    for (int it = 0; it < 200; ++it) {
+        double M[4][5] = {};
+        for (int i = 0; i < N; ++i)
+            for (int r = 0; r < 4; ++r) {
+                const double wb = w[i] * B[4 * (size_t)i + r];
+                for (int k = 0; k < 4; ++k) M[r][k] += wb * B[4 * (size_t)i + k];
+                M[r][4] += wb * y[i];
+            }
+        for (int col = 0; col < 4; ++col) {                      // Gauss-Jordan with partial pivoting
+            int piv = col;
+            for (int r = col + 1; r < 4; ++r) if (std::fabs(M[r][col]) > std::fabs(M[piv][col])) piv = r;
+            for (int k = 0; k < 5; ++k) std::swap(M[col][k], M[piv][k]);
+            if (M[col][col] == 0.0) return 1.0;
+            for (int r = 0; r < 4; ++r) {
+                if (r == col) continue;
+                const double f = M[r][col] / M[col][col];
+                for (int k = col; k < 5; ++k) M[r][k] -= f * M[col][k];
+            }
+        }
+        for (int k = 0; k < 4; ++k) c[k] = M[k][4] / M[k][k];
+        double sum = 0.0;
+        for (int i = 0; i < N; ++i) {
+            double p = 0.0;
+            for (int k = 0; k < 4; ++k) p += c[k] * B[4 * (size_t)i + k];
+            w[i] *= std::fabs(p - y[i]);
+            sum += w[i];
+        }
+        if (!(sum > 0.0)) break;
+        for (int i = 0; i < N; ++i) w[i] /= sum;
+    }
+    double scale = 1.0;
+    for (int k = 0; k < 4; ++k) { c_out[k] = (float)(c[k] * scale); scale /= tmax * tmax; }
+    double worst = 0.0;
+    const int G = 200000;
+    for (int i = 0; i <= G; ++i) {
+        const float tf = (float)(tmax * i / G), uu = tf * tf;
+        const float pf = tf * std::fmaf(std::fmaf(std::fmaf(c_out[3], uu, c_out[2]), uu, c_out[1]), uu, c_out[0]);
+        worst = std::max(worst, std::fabs((double)pf - std::atan((double)tf)));
+    }
+    return worst;
+}
+
 // utility.cpp:222-236 resetRimgSize
 Geom geom_for(const ltm_ctx* c, float alpha)
 {
@@ -371,12 +432,21 @@ Geom geom_for(const ltm_ctx* c, float alpha)
     g.rows = (int)roundf(c->cfg.vfov * alpha);
     g.cols = (int)roundf(c->cfg.hfov * alpha);
     g.fast = c->fast_math;
-    // Error budget of the bounded-error projection in ANGLE: polynomial 1.8e-6 rad (elevation) / 4e-7 (azimuth), transform 5e-7,
-    // v_rsq 1e-7, plus the reference's own float roundings of the degree / pixel arithmetic (~6e-7 rad equivalent): < 3.2e-6 rad.
-    // In pixels that is 3.2e-6 * (pixels per radian) = 1.8e-4 * alpha; the band is 6e-4 * alpha (3.3x), never below 1e-3.
-    // ltm_debug_cull_check validates it on the device (tests: 1e8 points incl. points placed on pixel boundaries).
+    // Error budget of the bounded-error projection in ANGLE: elevation polynomial 6e-7 rad fitted / 1.8e-6 generic, azimuth 4e-7,
+    // transform 5e-7, v_rsq 1e-7, plus the reference's own float roundings of the degree / pixel arithmetic (~6e-7 rad equivalent).
+    // In pixels the error is proportional to the resolution, and so is the band; never below cull_eps_floor (1e-3 px).
+    // ltm_debug_cull_check validates it on the device (tests: 1e8 points incl. points placed on pixel boundaries of every resolution).
     const float ppd = std::max((float)g.rows / g.vfov, (float)g.cols / g.hfov);      // pixels per degree = alpha
-    g.cull_eps_px = std::max(c->cull_eps_floor, c->cull_eps_scale * ppd);
+    // tools/eps_sweep.py (profiles/r2_cull_eps_sweep*.json): with the band switched down the first exact pixels are missed at
+    // 1e-4 * ppd with the generic elevation polynomial and at 5e-5 * ppd with the fitted one, at every resolution; the shipped band
+    // is six times that.
+    const float scale = c->cull_eps_scale > 0.0f ? c->cull_eps_scale : (c->el_fit ? 3.0e-4f : 6.0e-4f);
+    g.cull_eps_px = std::max(c->cull_eps_floor, scale * ppd);
+    // elevation of the bounded-error projection (see Geom): the clamp sits one pixel outside the image, at most 2 deg (the fitted range)
+    g.el_fit = c->el_fit;
+    for (int i = 0; i < 4; ++i) g.el_c[i] = c->el_c[i];
+    const double out_deg = std::min(2.0, (double)g.vfov / std::max(g.rows, 1));
+    g.el_tclamp = (float)std::tan((0.5 * (double)g.vfov + out_deg) * (3.14159265358979323846 / 180.0));
     return g;
 }
 
@@ -943,6 +1013,10 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
+        if (c->cfg.vfov > 0.0f && 0.5 * c->cfg.vfov + 2.0 <= 45.0) {
+            c->el_fit_err = fit_elevation_poly(std::tan((0.5 * c->cfg.vfov + 2.0) * (3.14159265358979323846 / 180.0)), c->el_c);
+            c->el_fit = c->el_fit_err <= 1.0e-6;       // the generic polynomial on [0, 1] is good to 1.8e-6 rad: the error budget of geom_for holds
+        }
     }
     *out = c;
     return LTM_OK;

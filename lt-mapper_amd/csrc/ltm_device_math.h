@@ -163,6 +163,8 @@ struct RimgGeom {
     float frows, fcols, row_max, col_max;
     bool fast;          // the fast forms were verified for these constants
     float eps;          // Geom::cull_eps_px
+    float el_c0, el_c1, el_c2, el_c3, el_tclamp;   // Geom::el_c / el_tclamp
+    bool el_fit;
 };
 
 // utility.cpp:114-125

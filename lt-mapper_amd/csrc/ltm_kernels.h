@@ -13,6 +13,13 @@ struct Geom {            // range-image geometry (utility.cpp:222-236 resetRimgS
     int fast;            // 1: use the self-checked fast arithmetic forms (ltm_device_math.h), 0: plain IEEE divisions
     float cull_eps_px;   // half-width [pixels] of the band around a pixel-rounding boundary inside which the bounded-error projection
                          // does not trust its pixel (proportional to the image resolution: the angular error is fixed, see geom_for)
+    // Elevation of the bounded-error projection when the field of view clamps everything steeper than vfov/2 + 2 deg < 45 deg:
+    // atan(t) ~ t * (el_c[0] + u (el_c[1] + u (el_c[2] + u el_c[3]))), u = t^2, fitted on [0, tan(vfov/2 + 2 deg)] when the context is
+    // created (fit_elevation_poly in ltm_api.cpp) and evaluated at min(t, el_tclamp); el_tclamp = tan(vfov/2 + one pixel) puts
+    // every clamped elevation in the MIDDLE of the out-of-image row -1 / R, where its pixel (row 0 / R-1 after the clamp) is certain.
+    int el_fit;          // 0: the fit is not good enough for this field of view, the kernels use the generic polynomial on [0, 1]
+    float el_c[4];
+    float el_tclamp;
 };
 
 // 3x4 row-major double (last row of the 4x4 is never used by PCL's se3 transformer)

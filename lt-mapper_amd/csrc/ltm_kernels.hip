@@ -32,6 +32,7 @@ __host__ __device__ inline RimgGeom make_geom(Geom g)
     r.inv_v = 1.0f / g.vfov; r.inv_h = 1.0f / g.hfov;
     r.fast = g.fast != 0;
     r.eps = g.cull_eps_px;
+    r.el_c0 = g.el_c[0]; r.el_c1 = g.el_c[1]; r.el_c2 = g.el_c[2]; r.el_c3 = g.el_c[3]; r.el_tclamp = g.el_tclamp; r.el_fit = g.el_fit != 0;
     r.rows = g.rows; r.cols = g.cols;
     r.frows = (float)g.rows; r.fcols = (float)g.cols;
     r.row_max = (float)(g.rows - 1); r.col_max = (float)(g.cols - 1);
@@ -362,7 +363,11 @@ __device__ __forceinline__ float3 xform_approx(const float* __restrict__ ap, flo
 // steep_clamps: the field of view is narrow enough (vfov/2 < 44 deg) that every elevation beyond +-45 deg clamps into the first /
 // last row whatever its value, so the elevation polynomial only ever sees |z| / rxy <= 1 (one v_rsq instead of v_sqrt + v_rcp and
 // no octant select); with a wider vertical field of view the steep points take the exact path instead.
-template <bool PACKED_POLY = false>     // packed (v_pk_*) evaluation of the two polynomials: no gain on gfx950, where v_pk_fma_f32 issues at half the rate of v_fma_f32 (tools/ubench/valu_rate.hip)
+// EL3: the field of view is narrow enough for the fitted degree-3 elevation polynomial (Geom::el_fit, two FMAs fewer and ~2x more
+// accurate than the generic one on [0, 1]); then elevations beyond the clamp need no special case at all.
+// (Tried: packed v_pk_* evaluation of the two polynomials -- no gain on gfx950, where v_pk_fma_f32 issues at half the rate of
+// v_fma_f32, tools/ubench/valu_rate.hip.)
+template <bool EL3 = false>
 __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p, float row_scale, float col_scale, bool steep_clamps)
 {
     CullCand cc;
@@ -372,12 +377,12 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     const float t_el = fabsf(p.z) * inv_rxy;                                  // tan |elevation|
     // azimuth, reduced to the first octant: min(|x|, |y|) / rxy is its sine (no reciprocal of max(|x|, |y|) needed)
     const float ax = fabsf(p.x), ay = fabsf(p.y);
-    float az_oct, el_abs;
-    if (PACKED_POLY) {
-        const ltm_v2f at = atan_unit_approx2((ltm_v2f){fminf(ax, ay) * __builtin_amdgcn_rcpf(fmaxf(ax, ay)), fminf(t_el, 1.0f)});
-        az_oct = at.x; el_abs = at.y;
+    const float az_oct = asin_octant_approx(fminf(ax, ay) * inv_rxy);
+    float el_abs;
+    if (EL3) {
+        const float t = fminf(t_el, g.el_tclamp), u = t * t;
+        el_abs = t * __builtin_fmaf(__builtin_fmaf(__builtin_fmaf(g.el_c3, u, g.el_c2), u, g.el_c1), u, g.el_c0);
     } else {
-        az_oct = asin_octant_approx(fminf(ax, ay) * inv_rxy);
         el_abs = atan_unit_approx(fminf(t_el, 1.0f));
     }
     const float el = __builtin_copysignf(el_abs, p.z);
@@ -401,7 +406,8 @@ __device__ __forceinline__ CullCand cull_candidates(const RimgGeom& g, float3 p,
     //  - steep elevations when the field of view does not clamp them.
     // A NaN coordinate needs no guard: its range is NaN, `r < rimg` is false in the reference (utility.cpp:134), so the point never
     // wins a pixel -- and here r2 = NaN fails both compares below and the caller's r2 < qbound, so it is dropped, which is the same.
-    cc.unusual = (fabsf(p.y) <= __builtin_fmaf(-1.0e-6f, p.x, 1.0e-18f)) | (cc.r2 > 6.4e7f) | (!steep_clamps & (t_el > 1.0f));
+    cc.unusual = (fabsf(p.y) <= __builtin_fmaf(-1.0e-6f, p.x, 1.0e-18f)) | (cc.r2 > 6.4e7f);
+    if (!EL3) cc.unusual |= !steep_clamps & (t_el > 1.0f);
     cc.multi = !certain;
     // clamp(floor(v), 0, n-1) == trunc(med3(v, 0, n-1)): the bounds are integers and the clamped value is non-negative
     cc.rb = (int)__builtin_amdgcn_fmed3f(cc.rowh, 0.0f, g.frows - 1.0f);
@@ -446,6 +452,22 @@ void set_stats_select(int v) { g_stats_select = v ? 1 : 0; }
 
 static constexpr int kCullQueue = 2048;   // survivor queue capacity (~370 of 4096 expected); overflow sends the whole tile down the exact path
 
+// Direct-mapped pixel table of a workgroup: tags[slot] = the pixel that owns the slot (first come), slot = low bits of row / column.
+// Returns the slot if `px` owns it, or -1 (then the caller goes to the global image).  A slot never changes owner.
+// (Tried: a second chance in the (ROWS/2) x (2 COLS) cut of the coordinates.  It turns ~7 % of misses into ~2 % on octree-ordered
+// map tiles, but the extra probe costs as much as the saved global atomics: no change in either kernel.)
+template <int ROWS, int COLS>
+__device__ __forceinline__ int table_claim(uint32_t* __restrict__ tags, int row, int col, uint32_t px)
+{
+    const int slot = ((row & (ROWS - 1)) * COLS) | (col & (COLS - 1));
+    uint32_t t = tags[slot];
+    if (t == kEmptyTag) {
+        const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
+        t = (old == kEmptyTag) ? px : old;
+    }
+    return (t == px) ? slot : -1;
+}
+
 // exact projection of one map point into image `imgk`, reduced through the workgroup's LDS table
 template <bool B2L_IDENTITY, int SLOTS_R, int SLOTS_C>
 __device__ __forceinline__ void exact_insert(const float4* __restrict__ map, uint32_t i, const Mat34& Tinv, const HostMat34& b2l_h, const RimgGeom& g,
@@ -459,13 +481,8 @@ __device__ __forceinline__ void exact_insert(const float4* __restrict__ map, uin
     pixel_row_col(g, s.az, s.el, row, col);
     const uint32_t px = (uint32_t)(row * g.cols + col);
     const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
-    const int slot = ((row & (SLOTS_R - 1)) * SLOTS_C) | (col & (SLOTS_C - 1));
-    uint32_t t = tags[slot];
-    if (t == kEmptyTag) {
-        const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-        t = (old == kEmptyTag) ? px : old;
-    }
-    if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
+    const int slot = table_claim<SLOTS_R, SLOTS_C>(tags, row, col, px);
+    if (slot >= 0) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
     else img_min_u64(imgk + px, v);
 }
 
@@ -535,8 +552,8 @@ hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb,
 
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
-template <bool B2L_IDENTITY, int VARIANT = 0>     // VARIANT: A/B switches for profiling (env LTM_CULL_VARIANT), results identical
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((VARIANT & 4) ? 8 : 4, 8)))
+template <bool B2L_IDENTITY, bool EL3>     // EL3: fitted elevation polynomial (Geom::el_fit), see cull_candidates
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
                 uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const float* __restrict__ qbound_img,
                 const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img)
@@ -574,7 +591,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         const bool steep_clamps = g.vfov < 88.0f;
         const bool ok_img = g.rows < 511 && g.cols <= 2048;      // the queue word holds 9 row bits and 11 column bits
         constexpr int kInFlight = 4;
-        constexpr bool kPrefetch = (VARIANT & 2) == 0;     // software pipelining: the next group's points are requested before this group's arithmetic
+        constexpr bool kPrefetch = true;     // software pipelining: the next group's points are requested before this group's arithmetic
         float4 nxt[kInFlight];
         if (kPrefetch) {
 #pragma unroll
@@ -600,7 +617,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
             for (int u = 0; u < kInFlight; ++u) {
                 bool ok;
                 const float3 p = xform_approx(ap, pt[u], ok);
-                cc[u] = cull_candidates<(VARIANT & 1) != 0>(g, p, row_scale, col_scale, steep_clamps);
+                cc[u] = cull_candidates<EL3>(g, p, row_scale, col_scale, steep_clamps);
                 // not certain of the pixel (within cull_eps_px of a rounding boundary, ~1 % of the points): straight to the exact path
                 cc[u].unusual |= !ok_img | !ok | cc[u].multi | (B2L_IDENTITY ? false : (cc[u].r2 < rmin2));
                 q0[u] = *reinterpret_cast<const float*>(reinterpret_cast<const char*>(qk) + ((__umul24((uint32_t)cc[u].rb, (uint32_t)g.cols) + (uint32_t)cc[u].cb) << 2));   // uniform base + 32-bit offset
@@ -658,13 +675,8 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 const uint32_t i = block_base + (e >> 20);
                 const uint32_t px = (uint32_t)(row * g.cols + col);
                 const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
-                const int slot = ((row & 7) << 6) | (col & 63);
-                uint32_t t = tags[slot];
-                if (t == kEmptyTag) {
-                    const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-                    t = (old == kEmptyTag) ? px : old;
-                }
-                if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
+                const int slot = table_claim<8, 64>(tags, row, col, px);
+                if (slot >= 0) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
                 else img_min_u64(imgk + px, v);
             }
             __syncthreads();
@@ -696,7 +708,7 @@ static int g_kf_per_block = 8;         // keyframes that reuse one map tile on a
 void set_kf_per_block(int v) { g_kf_per_block = v < 1 ? 1 : (v > 64 ? 64 : v); }
 static int g_tile_cull = 1;   // whole-tile range cull inside k_vote_map_cull (env LTM_TILE_CULL)
 void set_tile_cull(int v) { g_tile_cull = v; }
-static int g_cull_variant = 0;   // A/B variants of k_vote_map_cull (env LTM_CULL_VARIANT)
+static int g_cull_variant = 0;   // env LTM_CULL_VARIANT=1: the vote / exact-image kernels use the generic elevation polynomial even where the fitted one applies (A/B)
 void set_cull_variant(int v) { g_cull_variant = v; }
 static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
 void set_vote_cull(int v) { g_vote_cull = v; }
@@ -713,15 +725,10 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
     const unsigned kfg = (unsigned)g_kf_per_block;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
     const float* tb = (g_tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
-#define LTM_LAUNCH_CULL(ID, V) k_vote_map_cull<ID, V><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
-    if (!b2l_identity) LTM_LAUNCH_CULL(false, 0);
-    else switch (g_cull_variant) {
-        case 1: LTM_LAUNCH_CULL(true, 1); break;
-        case 2: LTM_LAUNCH_CULL(true, 2); break;
-        case 3: LTM_LAUNCH_CULL(true, 3); break;
-        case 4: LTM_LAUNCH_CULL(true, 4); break;
-        default: LTM_LAUNCH_CULL(true, 0); break;
-    }
+#define LTM_LAUNCH_CULL(ID, E) k_vote_map_cull<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
+    const bool el3 = g.el_fit != 0 && g_cull_variant != 1;       // LTM_CULL_VARIANT=1: generic elevation polynomial (A/B)
+    if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL(false, true); else LTM_LAUNCH_CULL(false, false); }
+    else { if (el3) LTM_LAUNCH_CULL(true, true); else LTM_LAUNCH_CULL(true, false); }
 #undef LTM_LAUNCH_CULL
     return hipGetLastError();
 }
@@ -744,7 +751,7 @@ k_cull_check(const float* __restrict__ xyz, size_t n, HostMat34 T, HostMat34 b2l
         pa = xform_approx(ap, p4, ok);
     }
     const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
-    CullCand cc = cull_candidates(g, pa, row_scale, col_scale, g.vfov < 88.0f);
+    CullCand cc = g.el_fit ? cull_candidates<true>(g, pa, row_scale, col_scale, g.vfov < 88.0f) : cull_candidates<false>(g, pa, row_scale, col_scale, g.vfov < 88.0f);
     if (cc.unusual || !ok) return;
     const float rmin = cull_min_range<false>(b2l);
     if (ap && !b2l_identity && cc.r2 < rmin * rmin) return;      // these take the exact path in the kernels
@@ -779,18 +786,20 @@ hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const 
 //             table's minimum upper bound (then some other point of the tile is strictly nearer in the same exact pixel);
 //   phase 2   survivors (a few per pixel) get the exact arithmetic and the usual 64-bit LDS/global min.
 // The result is bit-identical to k_map_rimg_lds / the serial reference: discarded points are provably not arg-mins.
-static constexpr int kBmSlots = 1024;
+static constexpr int kBmSlotsMax = 1024;   // LDS table of the pre-filter: SLOT_ROWS x 64 pixels.  8 rows (8 workgroups per CU instead of 6) were tried: 15.3 ms against 10.3 ms per full-map launch -- the misses of the smaller table cost far more than the occupancy brings
 static constexpr int kBmQueue = 2048;     // survivor queue capacity (~11 % of 4096 expected); overflow: the whole tile goes exact
 // per-point record / queue entry: tile-local index (12 bits) | row (9) | column (11).  Row field 511 = pixel not certain
 // (needs the full exact projection).  Images with >= 511 rows or >= 2048 columns mark every point that way.
 static constexpr uint32_t kBmRowUncertain = 511u;
 static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain survivors (~1 % of the tile); beyond it they are handled in place
 
-template <bool B2L_IDENTITY>
+template <bool B2L_IDENTITY, bool EL3, int SLOT_ROWS = 16>
 __global__ void __launch_bounds__(kBlock)
 k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
                     uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img)
 {
+    constexpr int kBmSlots = SLOT_ROWS * 64;
+    static_assert(kBmSlots <= kBmSlotsMax, "");
     __shared__ uint64_t vals[kBmSlots];
     __shared__ uint32_t tags[kBmSlots];
     __shared__ uint32_t amin[kBmSlots];
@@ -815,91 +824,91 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     const bool packable = g.rows < (int)kBmRowUncertain && g.cols <= 2048;
     const float rmin = cull_min_range<B2L_IDENTITY>(b2l_h), rmin2 = rmin * rmin;
     const bool steep_clamps = g.vfov < 88.0f;
-    // per-lane record of the 16 points: range lower bound and (row | col | flags); flags: bit 31 = owns an amin slot, bit 30 = a point
+    // per-lane record of the 16 points: amin slot (bits 20+) | row | col, and the range lower bound -- of the points that own an
+    // amin slot; -1 for the others, which no table entry can beat (their slot field is 0: any valid index)
     float rlo[kPtsPerThread];
     uint32_t rec[kPtsPerThread];
-    // ---- phase 1a (four points per lane in flight, as in k_vote_map_cull)
+    // Only full tiles run the pre-filter: the one partial tile at the end of the map takes the exact path as a whole (phase 2),
+    // which keeps bounds tests and clamped indices out of these loops.
+    const bool full_tile = nloc == per_block;
+    if (full_tile) {
+        // ---- phase 1a (four points per lane in flight, as in k_vote_map_cull)
 #pragma unroll
-    for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
-        float4 pt[4];
-        bool live[4];
-        CullCand cc[4];
+        for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
+            float4 pt[4];
+            CullCand cc[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t li = (uint32_t)(j0 + u) * kBlock + threadIdx.x;
-            live[u] = li < nloc;
-            pt[u] = mapb[min(li, nloc - 1u)];          // unconditional (clamped) load, see k_vote_map_cull
-        }
-        bool ok = true;
+            for (int u = 0; u < 4; ++u) pt[u] = mapb[(uint32_t)(j0 + u) * kBlock + threadIdx.x];
+            bool ok = true;
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const float3 p = xform_approx(ap, pt[u], ok);
-            cc[u] = cull_candidates(g, p, row_scale, col_scale, steep_clamps);
-        }
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int j = j0 + u;
-            rlo[j] = cull_r_lo(cc[u].r2);
-            const bool certain = packable & ok & !cc[u].unusual & !cc[u].multi & !(cc[u].r2 < rmin2);
-            rec[j] = (live[u] ? 0x40000000u : 0u) | ((certain ? (uint32_t)cc[u].rb : kBmRowUncertain) << 11) | (uint32_t)(cc[u].cb & 2047);
-            if (!live[u] | !certain) continue;
-            const uint32_t px = (uint32_t)(cc[u].rb * g.cols + cc[u].cb);
-            const int slot = ((cc[u].rb & 15) << 6) | (cc[u].cb & 63);
-            uint32_t t = tags[slot];
-            if (t == kEmptyTag) {
-                const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-                t = (old == kEmptyTag) ? px : old;
+            for (int u = 0; u < 4; ++u) {
+                const float3 p = xform_approx(ap, pt[u], ok);
+                cc[u] = cull_candidates<EL3>(g, p, row_scale, col_scale, steep_clamps);
             }
-            if (t != px) continue;                                     // slot owned by another pixel: survive unconditionally
-            rec[j] |= 0x80000000u;
-            // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6)).  amin only ever decreases, so a plain read that is
-            // already smaller makes the (same-address, hence serialised) atomic unnecessary for most points of a pixel
-            const uint32_t hi = f2u(rlo[j] * (1.0f + 3.5e-6f));
-            if (hi < amin[slot]) atomicMin(&amin[slot], hi);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int j = j0 + u;
+                const float r_lo = cull_r_lo(cc[u].r2);
+                rlo[j] = -1.0f;
+                const bool certain = packable & ok & !cc[u].unusual & !cc[u].multi & !(cc[u].r2 < rmin2);
+                rec[j] = ((certain ? (uint32_t)cc[u].rb : kBmRowUncertain) << 11) | (uint32_t)(cc[u].cb & 2047);
+                if (!certain) continue;
+                const uint32_t px = (uint32_t)(cc[u].rb * g.cols + cc[u].cb);
+                const int slot = table_claim<SLOT_ROWS, 64>(tags, cc[u].rb, cc[u].cb, px);
+                if (slot < 0) continue;                                    // slot owned by another pixel: survive unconditionally
+                rlo[j] = r_lo;
+                rec[j] |= (uint32_t)slot << 20;
+                // upper bound of the exact range (r_lo = r_approx*(1-1.5e-6)).  amin only ever decreases, so a plain read that is
+                // already smaller makes the (same-address, hence serialised) atomic unnecessary for most points of a pixel
+                const uint32_t hi = f2u(r_lo * (1.0f + 3.5e-6f));
+                if (hi < amin[slot]) atomicMin(&amin[slot], hi);
+            }
         }
-    }
-    __syncthreads();
-    // ---- phase 1b: a point survives unless it owns a slot and some point of the tile is provably nearer in the same pixel
+        __syncthreads();
+        // ---- phase 1b: a point survives unless it owns a slot and some point of the tile is provably nearer in the same pixel
+        const uint32_t lane_word = threadIdx.x << 20;
 #pragma unroll
-    for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
-        bool sv[4];
+        for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
+            // the four table reads go out together and nothing branches on them (the slot index is valid whatever the flags say)
+            float am[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const uint32_t rc = rec[j0 + u];
-            const int slot = (int)((((rc >> 11) & 15u) << 6) | (rc & 63u));
-            sv[u] = (rc & 0x40000000u) && (!(rc & 0x80000000u) || !(rlo[j0 + u] > u2f(amin[slot])));
-        }
-        // one LDS atomic per wave and group of four (see k_vote_map_cull)
-        const uint64_t b0 = __builtin_amdgcn_ballot_w64(sv[0]), b1 = __builtin_amdgcn_ballot_w64(sv[1]),
-                       b2 = __builtin_amdgcn_ballot_w64(sv[2]), b3 = __builtin_amdgcn_ballot_w64(sv[3]);
-        const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
-        const uint32_t total = n0 + n1 + n2 + n3;
-        if (!total) continue;
-        uint32_t base = 0;
-        if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&qcount, total);
-        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-        const uint64_t bal[4] = {b0, b1, b2, b3};
-        const uint32_t off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+            for (int u = 0; u < 4; ++u) {
+                am[u] = u2f(amin[rec[j0 + u] >> 20]);
+            }
+            bool sv[4];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            if (!sv[u]) continue;
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-            const uint32_t pos = base + off[u] + below;
-            if (pos < (uint32_t)kBmQueue)
-                queue[pos] = (((uint32_t)(j0 + u) * kBlock + threadIdx.x) << 20) | (rec[j0 + u] & 0xfffffu);
+            for (int u = 0; u < 4; ++u) sv[u] = !(rlo[j0 + u] > am[u]);
+            // one LDS atomic per wave and group of four (see k_vote_map_cull)
+            const uint64_t b0 = __builtin_amdgcn_ballot_w64(sv[0]), b1 = __builtin_amdgcn_ballot_w64(sv[1]),
+                           b2 = __builtin_amdgcn_ballot_w64(sv[2]), b3 = __builtin_amdgcn_ballot_w64(sv[3]);
+            const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
+            const uint32_t total = n0 + n1 + n2 + n3;
+            if (!total) continue;
+            uint32_t base = 0;
+            if ((threadIdx.x & 63u) == 0u) base = atomicAdd(&qcount, total);
+            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+            if (base + total > (uint32_t)kBmQueue) continue;          // overflow, decided on the scalar unit: the whole tile goes exact in phase 2
+            const uint64_t bal[4] = {b0, b1, b2, b3};
+            const uint32_t off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!sv[u]) continue;
+                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
+                queue[base + off[u] + below] = ((rec[j0 + u] & 0xfffffu) | lane_word) | ((uint32_t)((j0 + u) * kBlock) << 20);
+            }
         }
     }
     __syncthreads();
     // ---- phase 2: survivors.  Certain pixel: only the exact range; the others are re-queued densely and get the full exact projection
-    const uint32_t nq = qcount;
-    if (threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled diagnostic
+    const uint32_t nq = full_tile ? qcount : (uint32_t)kBmQueue + 1u;
+    if (full_tile && threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled diagnostic
         atomicAdd(&g_cull_stats[2], (unsigned long long)nq);
         atomicAdd(&g_cull_stats[3], (unsigned long long)nloc);
     }
     const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
     if (__builtin_expect(nq > (uint32_t)kBmQueue, 0)) {      // queue overflow: a superset is always correct (min is idempotent)
         for (uint32_t li = threadIdx.x; li < nloc; li += kBlock)
-            exact_insert<B2L_IDENTITY, 16, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
+            exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
     } else {
         for (uint32_t q = threadIdx.x; q < nq; q += kBlock) {
             const uint32_t e = queue[q];
@@ -909,24 +918,19 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
             if (row == (int)kBmRowUncertain) {
                 const uint32_t up = atomicAdd(&ucount, 1u);
                 if (up < (uint32_t)kBmUQueue) uqueue[up] = (uint16_t)li;
-                else exact_insert<B2L_IDENTITY, 16, 64>(map, i, Tinv, b2l_h, g, vals, tags, imgk);
+                else exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, i, Tinv, b2l_h, g, vals, tags, imgk);
                 continue;
             }
             const uint32_t px = (uint32_t)(row * g.cols + col);
             const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
-            const int slot = ((row & 15) << 6) | (col & 63);
-            uint32_t t = tags[slot];
-            if (t == kEmptyTag) {
-                const uint32_t old = atomicCAS(&tags[slot], kEmptyTag, px);
-                t = (old == kEmptyTag) ? px : old;
-            }
-            if (t == px) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
+            const int slot = table_claim<SLOT_ROWS, 64>(tags, row, col, px);
+            if (slot >= 0) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
             else img_min_u64(imgk + px, v);
         }
         __syncthreads();
         const uint32_t nu = min(ucount, (uint32_t)kBmUQueue);
         for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
-            exact_insert<B2L_IDENTITY, 16, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
+            exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
     }
     __syncthreads();
     for (int s = threadIdx.x; s < kBmSlots; s += kBlock) {
@@ -946,8 +950,11 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
         const unsigned kfg = (unsigned)g_kf_per_block;
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-        if (b2l_identity) k_map_rimg_blockmin<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
-        else k_map_rimg_blockmin<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
+#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img)
+        const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
+        if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true); else LTM_LAUNCH_BM(false, false); }
+        else { if (el3) LTM_LAUNCH_BM(true, true); else LTM_LAUNCH_BM(true, false); }
+#undef LTM_LAUNCH_BM
         return hipGetLastError();
     }
     if (g_map_kernel_variant >= 1) {
