@@ -553,7 +553,7 @@ hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb,
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
 template <bool B2L_IDENTITY, bool EL3>     // EL3: fitted elevation polynomial (Geom::el_fit), see cull_candidates
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8)))
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
                 uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const float* __restrict__ qbound_img,
                 const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img)
@@ -1828,21 +1828,51 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
             {-1, 0, 0}, {1, 0, 0}, {0, -1, 0}, {0, 1, 0}, {0, 0, -1}, {0, 0, 1},
             {-1, -1, 0}, {-1, 1, 0}, {1, -1, 0}, {1, 1, 0}, {-1, 0, -1}, {-1, 0, 1}, {1, 0, -1}, {1, 0, 1}, {0, -1, -1}, {0, -1, 1}, {0, 1, -1}, {0, 1, 1},
             {-1, -1, -1}, {-1, -1, 1}, {-1, 1, -1}, {-1, 1, 1}, {1, -1, -1}, {1, -1, 1}, {1, 1, -1}, {1, 1, 1}};
-        for (int c = 0; c < 27; ++c) {
-            const int x = cx + kOrder[c][0], y = cy + kOrder[c][1], z = cz + kOrder[c][2];
-            if ((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz) continue;
-            const uint64_t key = ((uint64_t)(uint32_t)x * (uint32_t)ny + (uint32_t)y) * (uint32_t)nz + (uint32_t)z;   // == cell_id()
-            uint32_t h = hash64(key) & mask;
-            uint32_t a = 0, b = 0;
-            while (true) {
-                const uint64_t kk = table[h].key;
-                if (kk == key) { a = table[h].start; b = table[h].end; break; }
-                if (kk == kEmptyKey) break;
+        // One cell: its table entry `e` was fetched from the first probe position `h`; continue the linear probe if that slot holds
+        // another cell.  Returns true when the answer is final (early exit above).
+        auto visit = [&](uint64_t key, uint32_t h, HashEntry e) -> bool {
+            while (e.key != key) {
+                if (e.key == kEmptyKey) return false;
                 h = (h + 1) & mask;
+                e = table[h];
             }
-            if (a == b) continue;
-            for (uint32_t j = a; j < b; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
-            if (cnt == k && best[k - 1] < cell2_lo && mean_below_thr()) return true;
+            for (uint32_t j = e.start; j < e.end; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
+            return e.start != e.end && cnt == k && best[k - 1] < cell2_lo && mean_below_thr();
+        };
+        auto cell_key = [&](int c, uint64_t& key) -> bool {
+            const int x = cx + kOrder[c][0], y = cy + kOrder[c][1], z = cz + kOrder[c][2];
+            key = ((uint64_t)(uint32_t)x * (uint32_t)ny + (uint32_t)y) * (uint32_t)nz + (uint32_t)z;   // == cell_id()
+            return !((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz);
+        };
+        {   // the centre cell alone: most queries of a static scene end here
+            uint64_t key;
+            if (cell_key(0, key)) { const uint32_t h = hash64(key) & mask; if (visit(key, h, table[h])) return true; }
+        }
+        // The 26 neighbours in four batches (faces, edges, edges, corners).  The table entries of a batch are requested together
+        // before any of them is used: a query with no neighbours (a changed / dynamic point, a few per wavefront, which the whole
+        // wavefront waits for) pays 4 dependent memory round trips here instead of 26.
+        constexpr int kBatchEnd[4] = {7, 13, 19, 27};
+        int c0 = 1;
+#pragma unroll
+        for (int bt = 0; bt < 4; ++bt) {
+            constexpr int kMaxBatch = 8;
+            uint64_t keys[kMaxBatch];
+            uint32_t hs[kMaxBatch];
+            bool in[kMaxBatch];
+            HashEntry es[kMaxBatch];
+#pragma unroll
+            for (int i = 0; i < kMaxBatch; ++i) {
+                if (c0 + i >= kBatchEnd[bt]) break;
+                in[i] = cell_key(c0 + i, keys[i]);
+                hs[i] = in[i] ? (hash64(keys[i]) & mask) : 0u;       // an out-of-grid cell reads slot 0 and ignores it
+                es[i] = table[hs[i]];
+            }
+#pragma unroll
+            for (int i = 0; i < kMaxBatch; ++i) {
+                if (c0 + i >= kBatchEnd[bt]) break;
+                if (in[i] && visit(keys[i], hs[i], es[i])) return true;
+            }
+            c0 = kBatchEnd[bt];
         }
         // fewer than k neighbours inside the provably-complete radius => the k-th neighbour is >= cell away => "diff"
         if (cnt < k || !(best[k - 1] < cell2_lo)) return false;
