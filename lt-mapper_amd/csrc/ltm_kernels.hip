@@ -802,14 +802,16 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     static_assert(kBmSlots <= kBmSlotsMax, "");
     __shared__ uint64_t vals[kBmSlots];
     __shared__ uint32_t tags[kBmSlots];
-    __shared__ uint32_t amin[kBmSlots];
+    // the pre-filter's minimum table is only alive in phase 1 and the 64-bit (range | index) table only in phase 2: same LDS
+    // (22.6 KB instead of 26.6 KB per workgroup: 7 workgroups per CU instead of 6)
+    uint32_t* const amin = reinterpret_cast<uint32_t*>(vals);
     __shared__ uint32_t queue[kBmQueue];
     __shared__ uint16_t uqueue[kBmUQueue];
     __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     if (!tk.valid) return;
-    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; vals[s] = ~0ull; amin[s] = 0x7f800000u; }
+    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; amin[s] = 0x7f800000u; }
     if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
     __syncthreads();
     const RimgGeom g = make_geom(gg);
@@ -898,6 +900,8 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
             }
         }
     }
+    __syncthreads();
+    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) vals[s] = ~0ull;        // amin is dead from here on
     __syncthreads();
     // ---- phase 2: survivors.  Certain pixel: only the exact range; the others are re-queued densely and get the full exact projection
     const uint32_t nq = full_tile ? qcount : (uint32_t)kBmQueue + 1u;
