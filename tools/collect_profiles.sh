@@ -62,12 +62,12 @@ json.dump(out, open(sys.argv[1], "w"), indent=1)
 PY
 cp "$OUT/pmc_latest.json" "$OUT/${TAG}_pmc.json"
 
-# 4. the default bench line (CPU baseline on) -- after the counter passes, with their result in place, so that the line carries
+# 3. the default bench line (CPU baseline on) -- after the counter passes, with their result in place, so that the line carries
 #    `traffic` and the VALU figures of THIS kernel source (bench.py checks the hash inside pmc_latest.json)
 cp "$OUT/pmc_latest.json" "$ROOT/profiles/pmc_latest.json"
 $BENCH 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
 
-# 3. SQ issue / wait counters of the heaviest kernels, and the VALU issue-rate micro-benchmark (make ubench)
+# 4. SQ issue / wait counters of the heaviest kernels, and the VALU issue-rate micro-benchmark (make ubench)
 (cd "$ROOT" && bash tools/pmc_sq.sh) > "$OUT/${TAG}_pmc_sq.txt" 2>&1
 [ -x "$ROOT/tools/ubench/valu_rate" ] && "$ROOT/tools/ubench/valu_rate" > "$OUT/${TAG}_valu_rate_ubench.txt" 2>&1
 
