@@ -214,6 +214,8 @@ def main():
                     "algorithmic_bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
                     "algorithmic_definition": "16 B x (points of the map tiles the launch reads: whole-tile-culled tiles excluded) + 8 B x R x C per keyframe image "
                                               "(SURVEY 8d: map read + range|index image)",
+                    "frac_note": "can exceed 1: the algorithmic bytes (SURVEY 8d) count one read of the map per keyframe, the kernel fetches a map tile once "
+                                 "per eight keyframes (XCD-local L2 reuse) -- see `traffic` for the measured HBM bytes per launch and `real_bound`",
                     "point_projections_per_s": round(pps, 1),
                     "valu_insts_per_point": vpp,
                     "valu_issue_frac": round(vpp * pps / valu_peak, 4) if vpp else None,
