@@ -471,6 +471,33 @@ def test_vote_sentinel_arithmetic_beyond_9800_m(gpu_ctx, orc):
                 assert want[p0 + 9] == 1 and want[p0 + 10] == 0
 
 
+def test_non_finite_map_points_never_vote_and_change_nothing(gpu_ctx, small_pair):
+    """A NaN / inf coordinate gives a NaN / inf range; `r < rimg` (utility.cpp:134) is false for it, so such a point can never be
+    the arg-min of a pixel in the reference (its pixel index there is undefined behaviour: not compared).  The range-culled vote
+    drops it in phase 1, the exact kernels let it lose every min: either way the labels of the other points are those of the map
+    without it, and its own label stays 0.  Full tiles and the partial tail are both covered (12 000 clean points + sprinkled ones)."""
+    C, _ = small_pair
+    rng = np.random.default_rng(41)
+    clean = np.ascontiguousarray(C["scans"][:12000], dtype=np.float32).copy()
+    clean[:, :3] = (C["poses"][0].reshape(4, 4)[:3, :3] @ clean[:, :3].T).T + C["poses"][0].reshape(4, 4)[:3, 3]   # into the map frame
+    bad = np.tile(clean[:64], (1, 1)).copy()
+    for i, v in enumerate((np.nan, np.inf, -np.inf, 3.0e38)):
+        bad[i::12, i % 3] = v
+        bad[i + 4::12, :3] = v
+    where = np.sort(rng.choice(len(clean) + len(bad), len(bad), replace=False))
+    mixed = np.empty((len(clean) + len(bad), 4), np.float32)
+    is_bad = np.zeros(len(mixed), bool); is_bad[where] = True
+    mixed[is_bad], mixed[~is_bad] = bad, clean
+    g_scans, g_poses = gpu_ctx.upload_scans(C["scans"], C["offsets"]), gpu_ctx.poses(C["poses"], C["inv"])
+    for mode in (0, 1):
+        for alpha in (2.5, 1.5):
+            ref = gpu_ctx.visibility_partition(gpu_ctx.upload(clean), g_scans, g_poses, alpha, 0.1, mode, want_labels=True)[2]
+            got = gpu_ctx.visibility_partition(gpu_ctx.upload(mixed), g_scans, g_poses, alpha, 0.1, mode, want_labels=True)[2]
+            assert (got[~is_bad] == ref).all(), f"mode {mode} alpha {alpha}: non-finite neighbours changed {(got[~is_bad] != ref).sum()} labels"
+            assert not got[is_bad].any(), f"mode {mode} alpha {alpha}: a non-finite point was flagged"
+            assert ref.any(), "the clean map must have flagged points for the comparison to mean something"
+
+
 def test_tile_range_cull_on_a_long_street(gpu_ctx, orc):
     """a 300 m drive: most map tiles are out of reach of any single keyframe and are culled as a whole -- labels must not change"""
     from tools import synth
