@@ -129,7 +129,8 @@ int ltm_scanset_upload_end(ltm_ctx*, ltm_upload up, ltm_scanset* out);
  * buffer owned by the library; the context keeps computing.  ltm_fetch_wait blocks until that copy has completed and may be
  * called from ANY host thread (writer threads) -- it touches only the ticket.  The points are packed XYZI (16 B); for a scan set
  * `offsets` (n_kf + 1 entries, owned by the ticket) delimit the keyframes.  The source handle must stay alive until the wait has
- * returned; ltm_fetch_release (context thread) recycles the pinned buffer. */
+ * returned; ltm_fetch_release recycles the pinned buffer and may also be called from any thread, as soon as the data has been
+ * consumed (page-locking new buffers is what costs time, so hand them back early). */
 typedef struct ltm_fetch ltm_fetch;
 int ltm_cloud_fetch_begin(ltm_ctx*, ltm_cloud, ltm_fetch** out);
 int ltm_scanset_fetch_begin(ltm_ctx*, ltm_scanset, ltm_fetch** out);

@@ -7,6 +7,8 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <chrono>
+#include <mutex>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -42,6 +44,8 @@ struct Pool {
     std::multimap<size_t, void*> free_blocks;
     std::unordered_map<void*, size_t> live;
     size_t bytes_total = 0;
+    size_t n_malloc = 0;            // diagnostics (LTM_POOL_STATS=1 prints them when the context is destroyed)
+    double malloc_s = 0.0;
     static size_t round_up(size_t b)
     {
         if (b < 512) return 512;
@@ -61,7 +65,10 @@ struct Pool {
             return p;
         }
         void* p = nullptr;
+        const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
+        malloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        ++n_malloc;
         if (e != hipSuccess) {
             release_cached();
             e = hipMalloc(&p, want);
@@ -123,6 +130,9 @@ struct ltm_ctx {
     int fast_math = 0;   // set by the create-time self-check of the fast arithmetic forms for this FOV
     unsigned long long selfcheck[3] = {0, 0, 0};
     Pool pool;
+    double pinned_s = 0.0;          // diagnostics (LTM_POOL_STATS): time inside hipHostMalloc, bytes pinned
+    size_t pinned_bytes = 0;
+    std::mutex pinned_mx;           // the pinned blocks are handed back by writer threads (ltm_fetch_release)
     uint64_t next_handle = 1;
     std::unordered_map<uint64_t, Cloud> clouds;
     std::unordered_map<uint64_t, ScanSet> scansets;
@@ -914,21 +924,40 @@ hipStream_t copy_stream(ltm_ctx* c)
     if (!c->copy_stream) LTM_HIP(hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     return c->copy_stream;
 }
+// Pinned staging for uploads and fetches.  Page-locking is the expensive part (hipHostMalloc pins at ~4.5 GB/s: 0.55 s for the
+// 2.5 GB of outputs of a 2x500-keyframe run, on the context thread), so blocks are recycled as soon as a writer thread is done
+// with them (ltm_fetch_release may be called there), and once 768 MB are pinned any free block that is large enough is taken
+// rather than pinning another one of the ideal size.  Tried instead, on the 2x500-keyframe files -> files run (0.75-0.9 s): pinning
+// 3.5x the input ahead of time on a helper thread (the runtime serialises the loader's calls behind the pinning: Step 0 0.23 ->
+// 0.6 s), and no pinning at all -- the writer threads copy into ordinary memory themselves -- which frees the context thread of
+// the 0.5 s but slows it by as much through the concurrent blocking copies (0.95 s).  What would remove the cost is a small
+// fixed ring of pinned chunks that the writers consume chunk-wise; that changes the writer interface and is left for the next round.
 void* pinned_alloc(ltm_ctx* c, size_t bytes)
 {
     if (bytes == 0) bytes = 16;
-    int best = -1;
-    for (size_t i = 0; i < c->pinned.size(); ++i)
-        if (!c->pinned[i].in_use && c->pinned[i].bytes >= bytes && (best < 0 || c->pinned[i].bytes < c->pinned[(size_t)best].bytes)) best = (int)i;
-    if (best >= 0 && c->pinned[(size_t)best].bytes <= 2 * bytes + (1u << 20)) { c->pinned[(size_t)best].in_use = true; return c->pinned[(size_t)best].p; }
+    {
+        std::lock_guard<std::mutex> lk(c->pinned_mx);
+        int best = -1;
+        for (size_t i = 0; i < c->pinned.size(); ++i)
+            if (!c->pinned[i].in_use && c->pinned[i].bytes >= bytes && (best < 0 || c->pinned[i].bytes < c->pinned[(size_t)best].bytes)) best = (int)i;
+        if (best >= 0 && (c->pinned[(size_t)best].bytes <= 2 * bytes + (1u << 20) || c->pinned_bytes >= ((size_t)768 << 20))) {
+            c->pinned[(size_t)best].in_use = true;
+            return c->pinned[(size_t)best].p;
+        }
+    }
     void* p = nullptr;
     const size_t want = (bytes + ((size_t)1 << 20) - 1) & ~(((size_t)1 << 20) - 1);
+    const auto t0 = std::chrono::steady_clock::now();
     if (hipHostMalloc(&p, want, hipHostMallocDefault) != hipSuccess) throw Err{LTM_E_NOMEM, "hipHostMalloc of " + std::to_string(want) + " bytes failed"};
+    std::lock_guard<std::mutex> lk(c->pinned_mx);
+    c->pinned_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->pinned_bytes += want;
     c->pinned.push_back(PinnedBlock{p, want, true});
     return p;
 }
 void pinned_free(ltm_ctx* c, void* p)
 {
+    std::lock_guard<std::mutex> lk(c->pinned_mx);
     for (PinnedBlock& b : c->pinned) if (b.p == p) { b.in_use = false; return; }
 }
 // compute stream -> copy stream ordering: everything submitted so far on the context's stream happens before later copy-stream work
@@ -1034,6 +1063,9 @@ void ltm_destroy(ltm_ctx* c)
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     if (c->live_counts) (void)hipFree(c->live_counts);
+    if (getenv("LTM_POOL_STATS"))
+        fprintf(stderr, "[ltm] device pool: %zu hipMalloc calls, %.1f MB held, %.1f ms inside hipMalloc; pinned host blocks: %zu, %.1f MB, %.1f ms inside hipHostMalloc\n",
+                c->pool.n_malloc, c->pool.bytes_total / 1048576.0, 1e3 * c->pool.malloc_s, c->pinned.size(), c->pinned_bytes / 1048576.0, 1e3 * c->pinned_s);
     c->pool.release_all();
     (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1409,22 +1441,21 @@ int ltm_scanset_fetch_begin(ltm_ctx* c, ltm_scanset h, ltm_fetch** out)
 int ltm_fetch_wait(ltm_fetch* t, const void** host_xyzi, size_t* n_points, const uint64_t** offsets, size_t* n_kf)
 {
     if (!t) return LTM_E_INVALID;
-    if (hipEventSynchronize(t->done) != hipSuccess) return LTM_E_DEVICE;      // thread-safe: touches only this ticket's event
+    if (hipEventSynchronize(t->done) != hipSuccess) return LTM_E_DEVICE;      // thread-safe: touches only this ticket
     if (host_xyzi) *host_xyzi = t->host;
     if (n_points) *n_points = t->n_points;
     if (offsets) *offsets = t->off.empty() ? nullptr : t->off.data();
     if (n_kf) *n_kf = t->off.empty() ? 0 : t->off.size() - 1;
     return LTM_OK;
 }
-int ltm_fetch_release(ltm_ctx* c, ltm_fetch* t)
+int ltm_fetch_release(ltm_ctx* c, ltm_fetch* t)       // any thread: touches the ticket and, under its mutex, the pinned-block list
 {
-    return guarded(c, [&] {
-        LTM_REQUIRE(t, "null ticket");
-        (void)hipEventSynchronize(t->done);
-        (void)hipEventDestroy(t->done);
-        pinned_free(c, t->host);
-        delete t;
-    });
+    if (!c || !t) return LTM_E_INVALID;
+    (void)hipEventSynchronize(t->done);
+    (void)hipEventDestroy(t->done);
+    pinned_free(c, t->host);
+    delete t;
+    return LTM_OK;
 }
 
 // -------------------------------------------------------------------------------- poses

@@ -3,6 +3,7 @@
 // libltm_hip.so.  The four RViz images of Removerter.cpp:580-585 come colour-mapped from the device (ltm_debug_viz_images)
 // through publishDebugImages(); point-cloud publishers (Removerter.cpp:55-71) are visualisation only and absent.
 #pragma once
+#include <atomic>
 #include <memory>
 #include <string>
 #include <utility>
@@ -32,7 +33,9 @@ private:
     std::pair<CloudPtr, CloudPtr> votePartition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode);
     int viz_pass_ = 0;
     // background output writer: fetch tickets in flight + the handles that must outlive them
-    struct PendingFetch { ltm_fetch* ticket; CloudPtr cloud; ScansPtr scans; };
+    // the ticket is handed back (ltm_fetch_release, any thread) by the writer task that consumed it last, so that its pinned buffer
+    // serves the next fetch; whatever is still there when the outputs are finished (errors, empty sets) is released then
+    struct PendingFetch { std::shared_ptr<std::atomic<ltm_fetch*>> ticket; CloudPtr cloud; ScansPtr scans; };
     std::unique_ptr<AsyncWriter> writer_;
     std::vector<PendingFetch> fetches_;
     void finishOutputs();      // waits for every queued file, releases the tickets

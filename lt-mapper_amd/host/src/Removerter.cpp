@@ -39,7 +39,8 @@ void Removerter::finishOutputs()
     if (!writer_) return;
     std::exception_ptr e;
     try { writer_->drain(); } catch (...) { e = std::current_exception(); }
-    for (PendingFetch& f : fetches_) (void)ltm_fetch_release(dev_->ctx, f.ticket);
+    for (PendingFetch& f : fetches_)
+        if (ltm_fetch* t = f.ticket->exchange(nullptr)) (void)ltm_fetch_release(dev_->ctx, t);
     fetches_.clear();
     if (e) std::rethrow_exception(e);
 }
@@ -52,12 +53,15 @@ void Removerter::saveMap(const std::string& file, const CloudPtr& cloud, bool oc
         if (!writer_) writer_.reset(new AsyncWriter((unsigned)std::max(1, kNumOmpCores)));
         ltm_fetch* t = nullptr;
         ltmCheck(dev_->ctx, ltm_cloud_fetch_begin(dev_->ctx, cloud->h, &t), "ltm_cloud_fetch_begin");
-        fetches_.push_back(PendingFetch{t, cloud, nullptr});
-        writer_->submit([t, file, octree_layout] {
+        auto ticket = std::make_shared<std::atomic<ltm_fetch*>>(t);
+        fetches_.push_back(PendingFetch{ticket, cloud, nullptr});
+        ltm_ctx* ctx = dev_->ctx;
+        writer_->submit([t, ticket, ctx, file, octree_layout] {
             const void* pts = nullptr; size_t n = 0;
             if (ltm_fetch_wait(t, &pts, &n, nullptr, nullptr) != LTM_OK) throw std::runtime_error("ltm_fetch_wait failed for " + file);
             std::string err;
             if (!savePCDFileBinary(file, static_cast<const PointType*>(pts), n, octree_layout, &err)) throw std::runtime_error(err);
+            if (ltm_fetch* mine = ticket->exchange(nullptr)) (void)ltm_fetch_release(ctx, mine);      // the pinned buffer goes back to the pool now
         });
         return;
     }
@@ -398,16 +402,21 @@ void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _
         if (!writer_) writer_.reset(new AsyncWriter((unsigned)std::max(1, kNumOmpCores)));
         ltm_fetch* t = nullptr;
         ltmCheck(dev_->ctx, ltm_scanset_fetch_begin(dev_->ctx, _scans->h, &t), "ltm_scanset_fetch_begin");
-        fetches_.push_back(PendingFetch{t, nullptr, _scans});
+        auto ticket = std::make_shared<std::atomic<ltm_fetch*>>(t);
+        fetches_.push_back(PendingFetch{ticket, nullptr, _scans});
         const size_t nk = _scans->numKeyframes();
+        auto remaining = std::make_shared<std::atomic<size_t>>(nk);
+        ltm_ctx* ctx = dev_->ctx;
         for (size_t idx_scan = 0; idx_scan < nk; ++idx_scan) {
             const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(first + idx_scan);
-            writer_->submit([t, file_name, idx_scan, octree_layout] {
+            writer_->submit([t, ticket, remaining, ctx, file_name, idx_scan, octree_layout] {
                 const void* pts = nullptr; size_t n = 0; const uint64_t* off = nullptr; size_t n_kf = 0;
                 if (ltm_fetch_wait(t, &pts, &n, &off, &n_kf) != LTM_OK || idx_scan >= n_kf) throw std::runtime_error("ltm_fetch_wait failed for " + file_name);
                 std::string err;
                 if (!savePCDFileBinary(file_name, static_cast<const PointType*>(pts) + off[idx_scan], (size_t)(off[idx_scan + 1] - off[idx_scan]), octree_layout, &err))
                     throw std::runtime_error(err);
+                if (remaining->fetch_sub(1) == 1)           // the last file of the set: the pinned buffer goes back to the pool
+                    if (ltm_fetch* mine = ticket->exchange(nullptr)) (void)ltm_fetch_release(ctx, mine);
             });
         }
         LTM_INFO(" " << nk << " scans queued for " << _save_dir);

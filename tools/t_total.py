@@ -63,7 +63,9 @@ def main():
         t = {line[i]: float(line[i + 1]) for i in range(len(line) - 1) if line[i].startswith("T_")}
         kfs = [int(x) for x in line[line.index("keyframes") + 1: line.index("keyframes") + 3]]
         out_bytes = sum(os.path.getsize(os.path.join(d, f)) for d, _, fs in os.walk(outdir) for f in fs)
-        runs.append(dict(process_wall_s=round(wall, 3), **{k: round(v, 3) for k, v in t.items()}, keyframes=kfs, output_bytes=out_bytes))
+        diag = [l for l in p.stderr.splitlines() if l.startswith("[ltm]")]         # LTM_POOL_STATS=1: allocator statistics of the run
+        runs.append(dict(process_wall_s=round(wall, 3), **{k: round(v, 3) for k, v in t.items()}, keyframes=kfs, output_bytes=out_bytes,
+                         **({"diagnostics": diag} if diag else {})))
     best = min(runs, key=lambda x: x["T_total"])
     print(json.dumps({"what": "ltm_run files -> files", "keyframes_per_session": args.kf, "sensor": args.sensor, "three_res": args.three_res,
                       "ranks": args.ranks, "input_bytes": in_bytes, "runs": runs, "best": best,
