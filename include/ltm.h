@@ -212,6 +212,11 @@ void ltm_rimg_size(float vfov, float hfov, float res_alpha, int* rows, int* cols
  * division by the FOV constants) against plain IEEE division over all 2^32 binary32 inputs:
  * mismatches3 = {rad2deg, /vfov, /hfov}; the fast forms are used only when all three are zero. */
 int ltm_debug_selfcheck(ltm_ctx*, uint64_t* mismatches3, int* fast_math_enabled);
+/* the elevation polynomial of the bounded-error projection, as fitted when a context with this vertical field of view is created
+ * (host arithmetic only, needs no device): atan(t) ~ t (c[0] + u (c[1] + u (c[2] + u c[3]))), u = t^2, on [0, tan(vfov/2 + 2 deg)];
+ * *max_err_rad = largest error of its binary32 evaluation.  Returns 1 if the kernels use it for this field of view (vfov/2 + 2 deg
+ * <= 45 deg and error <= 1e-6 rad), 0 if they keep the generic polynomial on [0, 1], < 0 on invalid arguments. */
+int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad);
 /* checks the bounded-error projection that the range-culled vote kernel uses to decide which points need the exact
  * arithmetic: counts points (host xyz, n*3 floats; global frame if inv_pose16 is given, else local) whose exact pixel /
  * range fall outside its candidate set / bounds.  Must be 0. */

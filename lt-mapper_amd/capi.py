@@ -91,6 +91,7 @@ SIGNATURES = {
     "ltm_debug_range_image": (_i, [_vp, _u64, _vp, _vp, _f, _vp, _vp]),
     "ltm_debug_viz_images": (_i, [_vp, _u64, _u64, _u64, _sz, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ltm_debug_project": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
+    "ltm_debug_elevation_fit": (_i, [_f, C.POINTER(_f), C.POINTER(C.c_double)]),
     "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
     "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),
     "ltm_debug_cull_stats": (_i, [_vp, _pu64, _pu64, _i]),

@@ -434,6 +434,17 @@ static double fit_elevation_poly(double tmax, float c_out[4])
     return worst;
 }
 
+// the fitted polynomial is used when the field of view clamps everything steeper than vfov/2 + 2 deg <= 45 deg and the fit is at least
+// as good as the generic polynomial on [0, 1] needs to be for the error budget of geom_for (1.8e-6 rad there; 1e-6 asked here)
+static int elevation_fit_for(float vfov, float c4[4], double* err)
+{
+    c4[0] = 1.0f; c4[1] = c4[2] = c4[3] = 0.0f;
+    *err = 0.0;
+    if (!(vfov > 0.0f) || 0.5 * (double)vfov + 2.0 > 45.0) return 0;
+    *err = fit_elevation_poly(std::tan((0.5 * (double)vfov + 2.0) * (3.14159265358979323846 / 180.0)), c4);
+    return *err <= 1.0e-6 ? 1 : 0;
+}
+
 // utility.cpp:222-236 resetRimgSize
 Geom geom_for(const ltm_ctx* c, float alpha)
 {
@@ -1042,10 +1053,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
-        if (c->cfg.vfov > 0.0f && 0.5 * c->cfg.vfov + 2.0 <= 45.0) {
-            c->el_fit_err = fit_elevation_poly(std::tan((0.5 * c->cfg.vfov + 2.0) * (3.14159265358979323846 / 180.0)), c->el_c);
-            c->el_fit = c->el_fit_err <= 1.0e-6;       // the generic polynomial on [0, 1] is good to 1.8e-6 rad: the error budget of geom_for holds
-        }
+        c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
     }
     *out = c;
     return LTM_OK;
@@ -1896,6 +1904,12 @@ int ltm_debug_cull_stats(ltm_ctx* c, uint64_t* survivors, uint64_t* points, int 
         if (survivors) *survivors = v[0];
         if (points) *points = v[1];
     });
+}
+
+int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad)
+{
+    if (!c4 || !max_err_rad || !(vfov_deg > 0.0f) || !(vfov_deg < 180.0f)) return LTM_E_INVALID;
+    try { return elevation_fit_for(vfov_deg, c4, max_err_rad); } catch (...) { return LTM_E_NOMEM; }
 }
 
 int ltm_debug_selfcheck(ltm_ctx* c, uint64_t* mismatches3, int* fast_math_enabled)
