@@ -136,6 +136,20 @@ int ltm_cloud_fetch_begin(ltm_ctx*, ltm_cloud, ltm_fetch** out);
 int ltm_scanset_fetch_begin(ltm_ctx*, ltm_scanset, ltm_fetch** out);
 int ltm_fetch_wait(ltm_fetch*, const void** host_xyzi, size_t* n_points, const uint64_t** offsets, size_t* n_kf);
 int ltm_fetch_release(ltm_ctx*, ltm_fetch*);
+/* Chunked form of the same: nothing the size of an output is page-locked.  The context keeps a small ring of pinned chunks
+ * (8 x 32 MB; LTM_FETCH_SLOTS, LTM_FETCH_CHUNK_MB) and a copier thread that, once the compute stream has reached the point of the
+ * *_fetch_chunks_begin call, moves the points chunk by chunk into free ring slots.  Consumers -- any number of threads per ticket
+ * -- take chunks with ltm_fetch_next_chunk (blocks; 1 = a chunk, 0 = no more, < 0 = error) and hand every one back with
+ * ltm_fetch_chunk_done as soon as they have used it (the copier waits for free slots, the context thread never does).  A cloud
+ * comes in consecutive ranges of points; a scan set in chunks of WHOLE keyframes [first_kf, first_kf + n_kf), whose points start
+ * at offsets[first_kf] - first_point inside the chunk (LTM_E_INVALID from *_begin if one keyframe is larger than a chunk).
+ * ltm_fetch_info gives the totals right away (a writer needs them for its header).  Tickets are served in the order of their
+ * *_begin calls; release them with ltm_fetch_release (any thread) when all chunks are done. */
+int ltm_cloud_fetch_chunks_begin(ltm_ctx*, ltm_cloud, ltm_fetch** out);
+int ltm_scanset_fetch_chunks_begin(ltm_ctx*, ltm_scanset, ltm_fetch** out);
+int ltm_fetch_info(ltm_fetch*, size_t* n_points, const uint64_t** offsets, size_t* n_kf);
+int ltm_fetch_next_chunk(ltm_fetch*, const void** host_xyzi, size_t* first_point, size_t* n_points, size_t* first_kf, size_t* n_kf);
+int ltm_fetch_chunk_done(ltm_fetch*, const void* host_xyzi);
 
 /* -------------------------------------------------------------------- poses ---- */
 /* keyframe_poses_ / keyframe_inverse_poses_ (Session.cpp:102-114).  inv may be NULL: then the

@@ -60,6 +60,11 @@ SIGNATURES = {
     "ltm_scanset_fetch_begin": (_i, [_vp, _u64, C.POINTER(_vp)]),
     "ltm_fetch_wait": (_i, [_vp, C.POINTER(_vp), _psz, C.POINTER(_pu64), _psz]),
     "ltm_fetch_release": (_i, [_vp, _vp]),
+    "ltm_cloud_fetch_chunks_begin": (_i, [_vp, _u64, C.POINTER(_vp)]),
+    "ltm_scanset_fetch_chunks_begin": (_i, [_vp, _u64, C.POINTER(_vp)]),
+    "ltm_fetch_info": (_i, [_vp, _psz, C.POINTER(_pu64), _psz]),
+    "ltm_fetch_next_chunk": (_i, [_vp, C.POINTER(_vp), _psz, _psz, _psz, _psz]),
+    "ltm_fetch_chunk_done": (_i, [_vp, _vp]),
     "ltm_buffer_alloc": (_i, [_vp, _sz, C.POINTER(_vp)]),
     "ltm_buffer_free": (_i, [_vp, _vp]),
     "ltm_buffer_fill": (_i, [_vp, _vp, _i, _sz]),

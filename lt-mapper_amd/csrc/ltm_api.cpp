@@ -8,7 +8,10 @@
 
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
 #include <mutex>
+#include <thread>
 #include <cfloat>
 #include <cmath>
 #include <cstdio>
@@ -118,7 +121,33 @@ struct UploadState { float4* d = nullptr; size_t cap = 0, n = 0; std::vector<uin
 } // namespace
 
 // ticket of an asynchronous device->host fetch (include/ltm.h)
-struct ltm_fetch { void* host = nullptr; size_t bytes = 0, n_points = 0; std::vector<uint64_t> off; hipEvent_t done = nullptr; int device = 0; };
+// Chunked tickets (ltm_*_fetch_chunks_begin): the points travel through a small fixed ring of pinned chunks (FetchRing) filled by
+// the context's copier thread and consumed, chunk by chunk, by writer threads -- nothing the size of an output is ever page-locked.
+struct FetchChunk { void* host; size_t first_point, n_points, first_kf, n_kf; };
+struct FetchRing;
+struct ltm_fetch {
+    void* host = nullptr; size_t bytes = 0, n_points = 0; std::vector<uint64_t> off; hipEvent_t done = nullptr; int device = 0;
+    // chunked form
+    bool chunked = false;
+    const float4* src = nullptr;            // device source, kept alive by the caller until the ticket is released
+    FetchRing* ring = nullptr;
+    std::vector<FetchChunk> plan;           // what the copier thread will produce, in order
+    std::mutex mx;
+    std::condition_variable cv;
+    std::deque<FetchChunk> avail;           // produced, not yet handed to a consumer
+    bool produced_all = false;
+    int error = LTM_OK;
+};
+struct FetchRing {
+    int device = 0;
+    size_t slot_bytes = 0;
+    std::vector<void*> slots, free_slots;
+    std::mutex mx;
+    std::condition_variable cv_free, cv_jobs;
+    std::deque<ltm_fetch*> jobs;
+    bool stop = false;
+    std::thread worker;
+};
 
 struct ltm_ctx {
     ltm_config cfg;
@@ -133,6 +162,7 @@ struct ltm_ctx {
     double pinned_s = 0.0;          // diagnostics (LTM_POOL_STATS): time inside hipHostMalloc, bytes pinned
     size_t pinned_bytes = 0;
     std::mutex pinned_mx;           // the pinned blocks are handed back by writer threads (ltm_fetch_release)
+    FetchRing* ring = nullptr;      // chunked fetches: created by the first one
     uint64_t next_handle = 1;
     std::unordered_map<uint64_t, Cloud> clouds;
     std::unordered_map<uint64_t, ScanSet> scansets;
@@ -1059,6 +1089,8 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     return LTM_OK;
 }
 
+static void destroy_ring(ltm_ctx* c);       // chunked-fetch ring and its copier thread (defined with the fetch entry points)
+
 void ltm_destroy(ltm_ctx* c)
 {
     if (!c) return;
@@ -1068,6 +1100,7 @@ void ltm_destroy(ltm_ctx* c)
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
+    destroy_ring(c);
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     if (c->live_counts) (void)hipFree(c->live_counts);
@@ -1427,6 +1460,117 @@ int ltm_scanset_upload_end(ltm_ctx* c, ltm_upload up, ltm_scanset* out)
     });
 }
 
+// copier thread of a context: takes the chunked tickets in the order they were begun; for each, waits until the compute stream has
+// reached the fetch point, then moves the planned chunks one after the other through free ring slots (D2H into pinned memory on
+// its own stream) and hands them to the ticket's consumers.  The context thread never waits for any of this.
+static void ring_worker(FetchRing* r)
+{
+    (void)hipSetDevice(r->device);
+    hipStream_t stream = nullptr;
+    const bool have_stream = hipStreamCreateWithFlags(&stream, hipStreamNonBlocking) == hipSuccess;
+    for (;;) {
+        ltm_fetch* t = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(r->mx);
+            r->cv_jobs.wait(lk, [&] { return r->stop || !r->jobs.empty(); });
+            if (r->jobs.empty()) break;
+            t = r->jobs.front();
+            r->jobs.pop_front();
+        }
+        int rc = (have_stream && hipEventSynchronize(t->done) == hipSuccess) ? LTM_OK : LTM_E_DEVICE;
+        for (size_t i = 0; i < t->plan.size() && rc == LTM_OK; ++i) {
+            FetchChunk ch = t->plan[i];
+            void* slot = nullptr;
+            {
+                std::unique_lock<std::mutex> lk(r->mx);
+                r->cv_free.wait(lk, [&] { return r->stop || !r->free_slots.empty(); });
+                if (r->free_slots.empty()) { rc = LTM_E_DEVICE; break; }       // shut down under us
+                slot = r->free_slots.back();
+                r->free_slots.pop_back();
+            }
+            if (ch.n_points && (hipMemcpyAsync(slot, t->src + ch.first_point, ch.n_points * sizeof(float4), hipMemcpyDeviceToHost, stream) != hipSuccess ||
+                                hipStreamSynchronize(stream) != hipSuccess)) {
+                std::lock_guard<std::mutex> lk(r->mx);
+                r->free_slots.push_back(slot);
+                rc = LTM_E_DEVICE;
+                break;
+            }
+            ch.host = slot;
+            std::lock_guard<std::mutex> lk(t->mx);
+            t->avail.push_back(ch);
+            t->cv.notify_one();
+        }
+        std::lock_guard<std::mutex> lk(t->mx);      // notify under the lock: ltm_fetch_release may delete the ticket right after
+        t->error = rc;
+        t->produced_all = true;
+        t->cv.notify_all();
+    }
+    if (have_stream) (void)hipStreamDestroy(stream);
+}
+static FetchRing* ensure_ring(ltm_ctx* c)
+{
+    if (c->ring) return c->ring;
+    std::unique_ptr<FetchRing> r(new FetchRing());
+    r->device = c->device;
+    size_t mb = 32, n_slots = 8;
+    if (const char* v = getenv("LTM_FETCH_CHUNK_MB")) mb = (size_t)std::max(1, atoi(v));
+    if (const char* v = getenv("LTM_FETCH_SLOTS")) n_slots = (size_t)std::max(2, atoi(v));
+    r->slot_bytes = mb << 20;
+    const auto t0 = std::chrono::steady_clock::now();
+    for (size_t i = 0; i < n_slots; ++i) {
+        void* p = nullptr;
+        if (hipHostMalloc(&p, r->slot_bytes, hipHostMallocDefault) != hipSuccess) {
+            for (void* q : r->slots) (void)hipHostFree(q);
+            throw Err{LTM_E_NOMEM, "hipHostMalloc of a fetch staging chunk failed"};
+        }
+        r->slots.push_back(p);
+    }
+    c->pinned_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    c->pinned_bytes += n_slots * r->slot_bytes;
+    r->free_slots = r->slots;
+    r->worker = std::thread(ring_worker, r.get());
+    c->ring = r.release();
+    return c->ring;
+}
+static void destroy_ring(ltm_ctx* c)
+{
+    FetchRing* r = c->ring;
+    if (!r) return;
+    { std::lock_guard<std::mutex> lk(r->mx); r->stop = true; }
+    r->cv_jobs.notify_all();
+    r->cv_free.notify_all();
+    if (r->worker.joinable()) r->worker.join();
+    for (void* p : r->slots) (void)hipHostFree(p);
+    delete r;
+    c->ring = nullptr;
+}
+static void fetch_chunks_begin(ltm_ctx* c, const float4* src, size_t n, std::vector<uint64_t> off, ltm_fetch** out)
+{
+    FetchRing* r = ensure_ring(c);
+    const size_t cap = r->slot_bytes / sizeof(float4);
+    std::unique_ptr<ltm_fetch> t(new ltm_fetch());
+    t->chunked = true; t->src = src; t->ring = r;
+    t->n_points = n; t->bytes = n * 16; t->off = std::move(off); t->device = c->device;
+    if (t->off.empty()) {
+        for (size_t first = 0; first < n; first += cap) t->plan.push_back(FetchChunk{nullptr, first, std::min(cap, n - first), 0, 0});
+    } else {      // whole keyframes per chunk, so that every chunk can be written out on its own
+        const size_t n_kf = t->off.size() - 1;
+        for (size_t a = 0; a < n_kf;) {
+            size_t b = a + 1;
+            LTM_REQUIRE(t->off[b] - t->off[a] <= cap, "a keyframe does not fit a fetch staging chunk (LTM_FETCH_CHUNK_MB)");
+            while (b < n_kf && t->off[b + 1] - t->off[a] <= cap) ++b;
+            t->plan.push_back(FetchChunk{nullptr, (size_t)t->off[a], (size_t)(t->off[b] - t->off[a]), a, b - a});
+            a = b;
+        }
+    }
+    LTM_HIP(hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
+    LTM_HIP(hipEventRecord(t->done, c->stream));        // the source is final once the compute stream gets here
+    ltm_fetch* raw = t.release();
+    { std::lock_guard<std::mutex> lk(r->mx); r->jobs.push_back(raw); }
+    r->cv_jobs.notify_one();
+    *out = raw;
+}
+
 static void fetch_begin(ltm_ctx* c, const float4* src, size_t n, std::vector<uint64_t> off, ltm_fetch** out)
 {
     std::unique_ptr<ltm_fetch> t(new ltm_fetch());
@@ -1446,9 +1590,48 @@ int ltm_scanset_fetch_begin(ltm_ctx* c, ltm_scanset h, ltm_fetch** out)
 {
     return guarded(c, [&] { LTM_REQUIRE(out, "null argument"); const ScanSet& s = get_ss(c, h); fetch_begin(c, s.d, s.n_pts, s.off, out); });
 }
-int ltm_fetch_wait(ltm_fetch* t, const void** host_xyzi, size_t* n_points, const uint64_t** offsets, size_t* n_kf)
+int ltm_cloud_fetch_chunks_begin(ltm_ctx* c, ltm_cloud h, ltm_fetch** out)
+{
+    return guarded(c, [&] { LTM_REQUIRE(out, "null argument"); const Cloud cl = get_cloud(c, h); fetch_chunks_begin(c, cl.d, cl.n, {}, out); });
+}
+int ltm_scanset_fetch_chunks_begin(ltm_ctx* c, ltm_scanset h, ltm_fetch** out)
+{
+    return guarded(c, [&] { LTM_REQUIRE(out, "null argument"); const ScanSet& s = get_ss(c, h); fetch_chunks_begin(c, s.d, s.n_pts, s.off, out); });
+}
+int ltm_fetch_info(ltm_fetch* t, size_t* n_points, const uint64_t** offsets, size_t* n_kf)
 {
     if (!t) return LTM_E_INVALID;
+    if (n_points) *n_points = t->n_points;
+    if (offsets) *offsets = t->off.empty() ? nullptr : t->off.data();
+    if (n_kf) *n_kf = t->off.empty() ? 0 : t->off.size() - 1;
+    return LTM_OK;
+}
+int ltm_fetch_next_chunk(ltm_fetch* t, const void** host_xyzi, size_t* first_point, size_t* n_points, size_t* first_kf, size_t* n_kf)
+{
+    if (!t || !t->chunked || !host_xyzi) return LTM_E_INVALID;
+    std::unique_lock<std::mutex> lk(t->mx);
+    t->cv.wait(lk, [&] { return !t->avail.empty() || t->produced_all; });
+    if (t->avail.empty()) return t->error != LTM_OK ? t->error : 0;
+    const FetchChunk ch = t->avail.front();
+    t->avail.pop_front();
+    *host_xyzi = ch.host;
+    if (first_point) *first_point = ch.first_point;
+    if (n_points) *n_points = ch.n_points;
+    if (first_kf) *first_kf = ch.first_kf;
+    if (n_kf) *n_kf = ch.n_kf;
+    return 1;
+}
+int ltm_fetch_chunk_done(ltm_fetch* t, const void* host_xyzi)
+{
+    if (!t || !t->chunked || !host_xyzi) return LTM_E_INVALID;
+    FetchRing* r = t->ring;
+    { std::lock_guard<std::mutex> lk(r->mx); r->free_slots.push_back(const_cast<void*>(host_xyzi)); }
+    r->cv_free.notify_one();
+    return LTM_OK;
+}
+int ltm_fetch_wait(ltm_fetch* t, const void** host_xyzi, size_t* n_points, const uint64_t** offsets, size_t* n_kf)
+{
+    if (!t || t->chunked) return LTM_E_INVALID;
     if (hipEventSynchronize(t->done) != hipSuccess) return LTM_E_DEVICE;      // thread-safe: touches only this ticket
     if (host_xyzi) *host_xyzi = t->host;
     if (n_points) *n_points = t->n_points;
@@ -1459,6 +1642,20 @@ int ltm_fetch_wait(ltm_fetch* t, const void** host_xyzi, size_t* n_points, const
 int ltm_fetch_release(ltm_ctx* c, ltm_fetch* t)       // any thread: touches the ticket and, under its mutex, the pinned-block list
 {
     if (!c || !t) return LTM_E_INVALID;
+    if (t->chunked) {     // the copier thread must be through with the ticket; chunks nobody consumed go back to the ring
+        {
+            std::unique_lock<std::mutex> lk(t->mx);
+            t->cv.wait(lk, [&] { return t->produced_all; });
+        }
+        {
+            std::lock_guard<std::mutex> lk(t->ring->mx);
+            for (const FetchChunk& ch : t->avail) t->ring->free_slots.push_back(ch.host);
+        }
+        t->ring->cv_free.notify_all();
+        (void)hipEventDestroy(t->done);
+        delete t;
+        return LTM_OK;
+    }
     (void)hipEventSynchronize(t->done);
     (void)hipEventDestroy(t->done);
     pinned_free(c, t->host);

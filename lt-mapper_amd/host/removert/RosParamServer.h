@@ -50,5 +50,7 @@ public:
     bool gpu_skip_hd_knn_;         // removert/gpu_skip_hd_knn: skip the visualisation-only HD kNN stage
     int gpu_device_;               // removert/gpu_device
     bool gpu_async_io_;            // removert/gpu_async_io (default true): pipelined loader (decode || H2D) and background output writer; false = the synchronous path
+    bool gpu_fetch_chunked_;       // removert/gpu_fetch_chunked (default true): the background writer takes its data through the library's ring of pinned chunks
+                                   // (ltm_*_fetch_chunks_begin) instead of one page-locked buffer per output; false = the whole-buffer fetches
     int gpu_viz_every_;            // removert/gpu_viz_every: >0 = emit the four RViz images (Removerter.cpp:580-585) of every N-th source keyframe of each vote pass
 };

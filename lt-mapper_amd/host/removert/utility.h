@@ -8,6 +8,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <functional>
+#include <fstream>
 #include <string>
 #include <utility>
 #include <vector>
@@ -41,6 +42,8 @@ bool loadPCDFile(const std::string& path, Cloud& out, std::string* err = nullptr
 // out of octreeDownsampling carry width=1,height=n (utility.cpp:217-218); everything else is width=n,height=1.
 bool savePCDFileBinary(const std::string& path, const Cloud& cloud, bool octree_layout, std::string* err = nullptr);
 bool savePCDFileBinary(const std::string& path, const PointType* pts, size_t n, bool octree_layout, std::string* err = nullptr);
+// the same file written piecewise: opens `path`, writes the header for `n` points and leaves `f` positioned at the first point
+bool openPCDFileBinary(const std::string& path, size_t n, bool octree_layout, std::ofstream* f, std::string* err = nullptr);
 // POINTS of a PCD header without touching the payload (the pipelined loader sizes its device array from these)
 bool readPCDPointCount(const std::string& path, size_t* n_points, std::string* err = nullptr);
 

@@ -52,10 +52,37 @@ void Removerter::saveMap(const std::string& file, const CloudPtr& cloud, bool oc
         // D2H on the copy stream into pinned memory + the file write on a writer thread; the GPU goes on with the next stage
         if (!writer_) writer_.reset(new AsyncWriter((unsigned)std::max(1, kNumOmpCores)));
         ltm_fetch* t = nullptr;
+        ltm_ctx* ctx = dev_->ctx;
+        if (gpu_fetch_chunked_) {
+            // through the library's ring of pinned chunks: the file is written piece by piece as the copier thread delivers them
+            ltmCheck(ctx, ltm_cloud_fetch_chunks_begin(ctx, cloud->h, &t), "ltm_cloud_fetch_chunks_begin");
+            auto ticket = std::make_shared<std::atomic<ltm_fetch*>>(t);
+            fetches_.push_back(PendingFetch{ticket, cloud, nullptr});
+            writer_->submit([t, ticket, ctx, file, octree_layout] {
+                std::exception_ptr failure;
+                std::ofstream f;
+                try {
+                    size_t n = 0;
+                    std::string err;
+                    if (ltm_fetch_info(t, &n, nullptr, nullptr) != LTM_OK) throw std::runtime_error("ltm_fetch_info failed for " + file);
+                    if (!openPCDFileBinary(file, n, octree_layout, &f, &err)) throw std::runtime_error(err);
+                } catch (...) { failure = std::current_exception(); }
+                for (;;) {      // every chunk is taken and handed back even after a failure: the ring must not run dry for the tickets behind
+                    const void* pts = nullptr; size_t cnt = 0;
+                    const int rc = ltm_fetch_next_chunk(t, &pts, nullptr, &cnt, nullptr, nullptr);
+                    if (rc <= 0) { if (rc < 0 && !failure) failure = std::make_exception_ptr(std::runtime_error("ltm_fetch_next_chunk failed for " + file)); break; }
+                    if (!failure) f.write(static_cast<const char*>(pts), (std::streamsize)(cnt * sizeof(PointType)));
+                    (void)ltm_fetch_chunk_done(t, pts);
+                }
+                if (!failure && !f) failure = std::make_exception_ptr(std::runtime_error(file + ": write failed"));
+                if (failure) std::rethrow_exception(failure);
+                if (ltm_fetch* mine = ticket->exchange(nullptr)) (void)ltm_fetch_release(ctx, mine);
+            });
+            return;
+        }
         ltmCheck(dev_->ctx, ltm_cloud_fetch_begin(dev_->ctx, cloud->h, &t), "ltm_cloud_fetch_begin");
         auto ticket = std::make_shared<std::atomic<ltm_fetch*>>(t);
         fetches_.push_back(PendingFetch{ticket, cloud, nullptr});
-        ltm_ctx* ctx = dev_->ctx;
         writer_->submit([t, ticket, ctx, file, octree_layout] {
             const void* pts = nullptr; size_t n = 0;
             if (ltm_fetch_wait(t, &pts, &n, nullptr, nullptr) != LTM_OK) throw std::runtime_error("ltm_fetch_wait failed for " + file);
@@ -401,12 +428,45 @@ void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _
         // one asynchronous D2H of the whole scan set; every file is its own writer task on a slice of the pinned buffer
         if (!writer_) writer_.reset(new AsyncWriter((unsigned)std::max(1, kNumOmpCores)));
         ltm_fetch* t = nullptr;
+        ltm_ctx* ctx = dev_->ctx;
+        const size_t nk = _scans->numKeyframes();
+        // chunked: chunks of whole keyframes come out of the library's pinned ring; `pumps` writer tasks take them as they arrive and
+        // write the files of their chunk.  (LTM_E_INVALID = a keyframe larger than a chunk: the whole-buffer fetch below instead.)
+        if (gpu_fetch_chunked_ && ltm_scanset_fetch_chunks_begin(ctx, _scans->h, &t) == LTM_OK) {
+            auto ticket = std::make_shared<std::atomic<ltm_fetch*>>(t);
+            fetches_.push_back(PendingFetch{ticket, nullptr, _scans});
+            auto names = std::make_shared<std::vector<std::string>>();
+            for (size_t idx_scan = 0; idx_scan < nk; ++idx_scan) names->push_back(_save_dir + "/" + _sess.keyframe_names_.at(first + idx_scan));
+            const size_t pumps = (size_t)std::max(1, kNumOmpCores);
+            auto remaining = std::make_shared<std::atomic<size_t>>(pumps);
+            for (size_t p = 0; p < pumps; ++p)
+                writer_->submit([t, ticket, remaining, ctx, names, octree_layout] {
+                    std::exception_ptr failure;
+                    const uint64_t* off = nullptr; size_t n_kf = 0;
+                    if (ltm_fetch_info(t, nullptr, &off, &n_kf) != LTM_OK || n_kf != names->size())
+                        failure = std::make_exception_ptr(std::runtime_error("ltm_fetch_info failed for " + (names->empty() ? std::string("a scan set") : names->front())));
+                    for (;;) {      // chunks are taken and handed back even after a failure (see saveMap)
+                        const void* pts = nullptr; size_t first_point = 0, cnt = 0, first_kf = 0, kfs = 0;
+                        const int rc = ltm_fetch_next_chunk(t, &pts, &first_point, &cnt, &first_kf, &kfs);
+                        if (rc <= 0) { if (rc < 0 && !failure) failure = std::make_exception_ptr(std::runtime_error("ltm_fetch_next_chunk failed")); break; }
+                        for (size_t k = first_kf; k < first_kf + kfs && !failure; ++k) {
+                            std::string err;
+                            if (!savePCDFileBinary((*names)[k], static_cast<const PointType*>(pts) + (off[k] - first_point), (size_t)(off[k + 1] - off[k]), octree_layout, &err))
+                                failure = std::make_exception_ptr(std::runtime_error(err));
+                        }
+                        (void)ltm_fetch_chunk_done(t, pts);
+                    }
+                    if (failure) std::rethrow_exception(failure);
+                    if (remaining->fetch_sub(1) == 1)           // the last pump: the ticket goes back
+                        if (ltm_fetch* mine = ticket->exchange(nullptr)) (void)ltm_fetch_release(ctx, mine);
+                });
+            LTM_INFO(" " << nk << " scans queued for " << _save_dir);
+            return;
+        }
         ltmCheck(dev_->ctx, ltm_scanset_fetch_begin(dev_->ctx, _scans->h, &t), "ltm_scanset_fetch_begin");
         auto ticket = std::make_shared<std::atomic<ltm_fetch*>>(t);
         fetches_.push_back(PendingFetch{ticket, nullptr, _scans});
-        const size_t nk = _scans->numKeyframes();
         auto remaining = std::make_shared<std::atomic<size_t>>(nk);
-        ltm_ctx* ctx = dev_->ctx;
         for (size_t idx_scan = 0; idx_scan < nk; ++idx_scan) {
             const std::string file_name = _save_dir + "/" + _sess.keyframe_names_.at(first + idx_scan);
             writer_->submit([t, ticket, remaining, ctx, file_name, idx_scan, octree_layout] {

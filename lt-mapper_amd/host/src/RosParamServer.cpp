@@ -138,5 +138,6 @@ RosParamServer::RosParamServer()
     gpu_skip_hd_knn_ = getb("gpu_skip_hd_knn", false);
     gpu_device_ = geti("gpu_device", 0);
     gpu_async_io_ = getb("gpu_async_io", true);
+    gpu_fetch_chunked_ = getb("gpu_fetch_chunked", true);
     gpu_viz_every_ = geti("gpu_viz_every", 0);
 }

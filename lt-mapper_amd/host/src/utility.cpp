@@ -260,16 +260,24 @@ bool readPCDPointCount(const std::string& path, size_t* n_points, std::string* e
     return false;
 }
 
-bool savePCDFileBinary(const std::string& path, const PointType* pts, size_t n, bool octree_layout, std::string* err)
+bool openPCDFileBinary(const std::string& path, size_t n, bool octree_layout, std::ofstream* f, std::string* err)
 {
-    std::ofstream f(path, std::ios::binary | std::ios::trunc);
-    if (!f) { if (err) *err = path + ": cannot open for writing"; return false; }
+    f->open(path, std::ios::binary | std::ios::trunc);
+    if (!*f) { if (err) *err = path + ": cannot open for writing"; return false; }
     const size_t width = octree_layout ? 1 : n, height = octree_layout ? n : 1;
     std::ostringstream h;   // the header pcl::PCDWriter::generateHeader emits for PointXYZI (padding fields stripped)
     h << "# .PCD v0.7 - Point Cloud Data file format\nVERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n"
       << "WIDTH " << width << "\nHEIGHT " << height << "\nVIEWPOINT 0 0 0 1 0 0 0\nPOINTS " << n << "\nDATA binary\n";
     const std::string hs = h.str();
-    f.write(hs.data(), (std::streamsize)hs.size());
+    f->write(hs.data(), (std::streamsize)hs.size());
+    if (!*f) { if (err) *err = path + ": write failed"; return false; }
+    return true;
+}
+
+bool savePCDFileBinary(const std::string& path, const PointType* pts, size_t n, bool octree_layout, std::string* err)
+{
+    std::ofstream f;
+    if (!openPCDFileBinary(path, n, octree_layout, &f, err)) return false;
     if (n) f.write(reinterpret_cast<const char*>(pts), (std::streamsize)(n * sizeof(PointType)));
     if (!f) { if (err) *err = path + ": write failed"; return false; }
     return true;
