@@ -1,6 +1,7 @@
 // host_selftest.cpp -- CPU-only self test of the host plumbing (no GPU, no libltm_hip.so): PCD v0.7 reader/writer
 // (ascii, binary, binary_compressed), pose-line parsing, the YAML-subset parameter reader, keyframe selection quirks and
 // the VoxelGrid restatement.  Built as lt-mapper_amd/host/host_selftest and run by tests/test_host_cpp.py.
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -58,6 +59,34 @@ int main(int argc, char** argv)
         std::string head((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
         CHECK(head.find("WIDTH 1\nHEIGHT 1000\n") != std::string::npos);
         CHECK(head.find("FIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\n") != std::string::npos);
+    }
+    // the piecewise writer of the chunked output path: header first, points in pieces -- byte for byte the one-shot file
+    {
+        for (bool octree_layout : {false, true}) {
+            std::ofstream f;
+            CHECK(openPCDFileBinary(dir + "/pieces.pcd", c.size(), octree_layout, &f, &err));
+            const size_t cuts[4] = {0, 1, 637, c.size()};
+            for (int k = 0; k < 3; ++k) f.write(reinterpret_cast<const char*>(c.data() + cuts[k]), (std::streamsize)((cuts[k + 1] - cuts[k]) * sizeof(PointType)));
+            f.close();
+            std::ifstream a(dir + (octree_layout ? "/b.pcd" : "/a.pcd"), std::ios::binary), b(dir + "/pieces.pcd", std::ios::binary);
+            const std::string sa((std::istreambuf_iterator<char>(a)), std::istreambuf_iterator<char>()), sb((std::istreambuf_iterator<char>(b)), std::istreambuf_iterator<char>());
+            CHECK(!sa.empty() && sa == sb);
+        }
+        std::ofstream f;
+        CHECK(!openPCDFileBinary(dir + "/no/such/dir/x.pcd", 1, false, &f, &err) && !err.empty());
+    }
+    // AsyncWriter: every task runs, drain() re-throws the first failure and the pool stays usable
+    {
+        std::atomic<int> ran{0};
+        AsyncWriter w(3);
+        for (int i = 0; i < 50; ++i) w.submit([&ran, i] { ++ran; if (i == 17) throw std::runtime_error("task 17"); });
+        bool threw = false;
+        try { w.drain(); } catch (const std::exception& e) { threw = std::string(e.what()) == "task 17"; }
+        CHECK(threw && ran == 50);
+        w.submit([&ran] { ++ran; });
+        bool ok_after = true;
+        try { w.drain(); } catch (...) { ok_after = false; }
+        CHECK(ran == 51 && ok_after);      // the failure was reported once and cleared
     }
     // ascii with an extra field and a different field order
     {
