@@ -14,7 +14,13 @@ pytestmark = pytest.mark.gpu
 from fileproto import HDR, parse_keyframes, read_pcd, write_pcd   # noqa: E402
 
 
-def test_ltm_run_file_protocol(tmp_path, orc):
+# the three ways the host gets its outputs to disk: background writer fed through the library's ring of pinned chunks (default),
+# background writer on whole page-locked buffers (gpu_fetch_chunked: false), and the synchronous path (gpu_async_io: false)
+WRITERS = {"chunked": "", "whole_buffer": "  gpu_fetch_chunked: false\n", "synchronous": "  gpu_async_io: false\n"}
+
+
+@pytest.mark.parametrize("writer", list(WRITERS))
+def test_ltm_run_file_protocol(tmp_path, orc, writer):
     from tools import synth
     exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
     assert os.path.exists(exe), "build the host mirror first (make host)"
@@ -59,7 +65,7 @@ def test_ltm_run_file_protocol(tmp_path, orc):
   num_omp_cores: 16
   rimg_color_max: 20.0
   gpu_viz_every: 7      # RViz images of every 7th source keyframe of each vote pass -> <out>/viz/*.ppm
-""")
+""" + WRITERS[writer])
     r = subprocess.run([exe, str(yaml)], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
 
