@@ -32,7 +32,12 @@ Removerter::Removerter(std::shared_ptr<Device> dev) : dev_(std::move(dev)), cent
     central_map_dynamic_save_dir_ = save_pcd_directory_ + "map_dynamic";             fsmkdir(central_map_dynamic_save_dir_);
 }
 
-Removerter::~Removerter() {}
+// After a normal run() there is nothing left to do here.  If run() was left by an exception, writer tasks may still be reading
+// fetched data: let them finish and hand the tickets back before the clouds they read from (fetches_) and the context go away.
+Removerter::~Removerter()
+{
+    try { finishOutputs(); } catch (...) {}
+}
 
 void Removerter::finishOutputs()
 {
