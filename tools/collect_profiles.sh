@@ -65,7 +65,7 @@ cp "$OUT/pmc_latest.json" "$OUT/${TAG}_pmc.json"
 # 3. the default bench line (CPU baseline on) -- after the counter passes, with their result in place, so that the line carries
 #    `traffic` and the VALU figures of THIS kernel source (bench.py checks the hash inside pmc_latest.json)
 cp "$OUT/pmc_latest.json" "$ROOT/profiles/pmc_latest.json"
-$BENCH 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
+$BENCH --cpu-allcore 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
 
 # 4. SQ issue / wait counters of the heaviest kernels, and the VALU issue-rate micro-benchmark (make ubench)
 (cd "$ROOT" && bash tools/pmc_sq.sh) > "$OUT/${TAG}_pmc_sq.txt" 2>&1
