@@ -75,18 +75,19 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_keyframe_sharding_over_gloo_world2_matches_single_process(orc):
+@pytest.mark.parametrize("world", [2, 3])      # 4 keyframes per session: equal blocks (2 + 2) and unequal ones (2 + 1 + 1)
+def test_keyframe_sharding_over_gloo_matches_single_process(orc, world):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
     import time
     results, deadline = [], time.time() + 300
-    while len(results) < 2:
+    while len(results) < world:
         try:
             results.append(q.get(timeout=2))
         except queue.Empty:
