@@ -1,6 +1,6 @@
 """CPU tests of the host logic: the Python Removerter orchestration (product code, lt-mapper_amd/removerter.py) driven by
 oracle-backed stage ops must reproduce the independent C++ oracle pipeline; and the keyframe-sharded exchange
-(lt-mapper_amd/dist.py) over gloo with world_size 2 must reproduce the single-process result bit for bit."""
+(lt-mapper_amd/dist.py) over gloo with world_size 2 and 3 must reproduce the single-process result bit for bit."""
 import os
 import socket
 
