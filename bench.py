@@ -15,18 +15,23 @@ restated on the synthetic `lot` scene (tools/synth.py; no dataset is reachable o
 configs[2]: five chained pair runs 01 -> 02..06 (lt-mapper_amd/cascade.py), 2500 keyframe pairs per step.
 
 Prints ONE JSON line (rank 0).  Besides the contract fields it carries
-  roofline     -- the dominant kernel (k_vote_map_cull): algorithmic bytes per launch (map tiles actually read + images
-                  written) / average launch duration measured with HIP events on the context's stream, against the 8 TB/s
-                  HBM peak; `valu_issue_frac` = VALU lane-instructions issued per second against the vector pipes' nominal peak (what
-                  really bounds this kernel); `traffic` = PMC-measured HBM bytes per launch (profiles/, only if it was
-                  collected for exactly this kernel source);
-  rooflines    -- the same figure for every kernel class of the step;
+  roofline     -- the dominant kernel (k_vote_map_cull).  Its binding resource is VALU ISSUE, not HBM (the ~110 MB map stays in
+                  the 256 MiB Infinity Cache and a tile is re-used from L2 by eight keyframes): `bound` = "valu", `achieved` /
+                  `peak` / `frac` = VALU lane-instructions per second against the vector pipes' nominal peak (SQ_INSTS_VALU from
+                  a separate rocprofv3 --pmc pass, profiles/pmc_latest.json, used only if it was collected for exactly this kernel
+                  source; average launch duration measured live with HIP events on the context's stream).  Beside it:
+                  `hbm_algorithmic` (SURVEY 8d algorithmic bytes per launch / launch duration against 8 TB/s -- can exceed 1,
+                  it is cache-served) and `hbm_measured_frac` (`traffic` = PMC HBM bytes per launch, against 8 TB/s);
+  rooflines    -- per kernel class of the step: algorithmic GB/s against the HBM peak, and (from the same PMC passes, which keep
+                  every kernel incl. rocPRIM's) the measured HBM traffic of the class's kernel group and traffic / algorithmic;
+  t_total      -- files -> files through the C++ host `ltm_run` (SURVEY 8d T_total) for configs[1] and configs[0], measured now;
+  parity_fullsize -- whether the committed full-size (2 x 500 keyframes, 3-res) bitwise comparison with the oracle was made with
+                  exactly the sources this run measures;
   cpu_baseline -- the CPU oracle (a port of the reference; the reference itself cannot be built here) timed on this
                   box on a bounded keyframe sample of the same workload: single thread (the north-star denominator) and
                   all cores; the committed full, unsampled runs are quoted next to it.
 """
 import argparse
-import hashlib
 import json
 import os
 import socket
@@ -77,6 +82,7 @@ def parse_args():
     ap.add_argument("--cpu-stride", type=int, default=50, help="cpu_baseline, single thread: visit every s-th keyframe in per-keyframe loops")
     ap.add_argument("--cpu-stride-allcore", type=int, default=10, help="cpu_baseline, all cores: keyframe stride")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-t-total", action="store_true", help="skip the files -> files measurement through ltm_run (default workload, one GPU)")
     ap.add_argument("--cpu-allcore", action="store_true", help="cpu_baseline: also time the oracle on all host cores now (every keyframe when the box has "
                                                                "many cores: ~3 min on 256); without it the committed measurement is quoted")
     ap.add_argument("--verbose", action="store_true")
@@ -190,47 +196,63 @@ def main():
     valu_peak = N_CU * SIMD_PER_CU * LANES_PER_SIMD * clock_hz      # VALU lane-instructions per second
     pmc = load_pmc(args.workload)
 
+    groups = traffic_groups(pmc, prof, args.steps)
+
     def class_roofline(cls, v):
         if not v["launches"] or v["ms"] <= 0:
             return None
         achieved = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-        return {"class": cls, "kernels": CLASS_KERNELS.get(cls, cls), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
-                "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(v["ms"] / args.steps, 3),
-                "launches_per_step": round(v["launches"] / max(args.steps, 1), 2),
-                "algorithmic_bytes_per_step": round(v["bytes"] / args.steps, 1), "units_per_step": round(v["units"] / args.steps, 1)}
+        r = {"class": cls, "kernels": CLASS_KERNELS.get(cls, cls), "bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS,
+             "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "ms_per_step": round(v["ms"] / args.steps, 3),
+             "launches_per_step": round(v["launches"] / max(args.steps, 1), 2),
+             "algorithmic_bytes_per_step": round(v["bytes"] / args.steps, 1), "units_per_step": round(v["units"] / args.steps, 1)}
+        g = next((g for g in groups if cls in g["classes"]), None)
+        if g:     # measured HBM traffic of the kernels this class runs (shared with the other classes of the group)
+            r.update(traffic_group=g["group"], traffic=g["traffic_bytes_per_step"], traffic_over_algorithmic=g["traffic_over_algorithmic"],
+                     hbm_measured_frac=g["hbm_measured_frac"])
+        return r
 
     # dominant kernel: k_vote_map_cull (profile class "vote_map_cull"; falls back to the exact kernel if culling is disabled)
     cls = "vote_map_cull" if prof.get("vote_map_cull", {}).get("launches") else "vote_map_exact"
     vm = prof.get(cls, dict(ms=0.0, launches=0, units=0.0, bytes=0.0))
     roofline = None
     if vm["launches"]:
-        achieved = vm["bytes"] / (vm["ms"] * 1e-3) / 1e9
+        avg_s = vm["ms"] * 1e-3 / vm["launches"]
+        hbm_alg = vm["bytes"] / (vm["ms"] * 1e-3) / 1e9
         pps = vm["units"] / (vm["ms"] * 1e-3)
         vpp = pmc.get("valu_insts_per_point") if cls == "vote_map_cull" else None
-        roofline = {"bound": "hbm", "kernel": "k_vote_map_cull" if cls == "vote_map_cull" else "k_map_rimg_blockmin",
-                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4),
-                    "traffic": pmc.get("hbm_bytes_per_launch") if cls == "vote_map_cull" else None,
-                    "traffic_source": pmc.get("source"),
+        traffic = pmc.get("hbm_bytes_per_launch") if cls == "vote_map_cull" else None
+        lane_insts = vpp * pps if vpp else None
+        roofline = {"bound": "valu", "kernel": "k_vote_map_cull" if cls == "vote_map_cull" else "k_map_rimg_blockmin",
+                    "achieved": round(lane_insts / 1e12, 3) if lane_insts else None, "peak": round(valu_peak / 1e12, 3), "unit": "T VALU lane-instructions/s",
+                    "frac": round(lane_insts / valu_peak, 4) if lane_insts else None,
+                    "frac_definition": "SQ_INSTS_VALU x 64 lanes per second of kernel time / (256 CU x 4 SIMD x 32 lanes x clock): the fraction of the nominal "
+                                       "VALU issue slots the kernel fills.  null when profiles/pmc_latest.json was not collected for exactly this kernel source",
+                    "frac_of_measured_valu_ceiling": round(lane_insts / (64.0 * VALU_MEASURED_CEILING_WAVE_INSTS), 4) if lane_insts else None,
+                    "traffic": traffic, "traffic_source": pmc.get("source"),
+                    "hbm_measured_frac": round(traffic / avg_s / (HBM_PEAK_GBS * 1e9), 4) if traffic else None,
+                    "hbm_algorithmic": {"achieved": round(hbm_alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4),
+                                        "bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
+                                        "definition": "16 B x (points of the map tiles the launch reads: whole-tile-culled tiles excluded) + 8 B x R x C per keyframe image "
+                                                      "(SURVEY 8d: one map read per keyframe + range|index image)",
+                                        "note": "NOT a bound for this kernel and allowed to exceed 1: SURVEY 8d counts one read of the map per keyframe, the kernel fetches "
+                                                "a map tile once per eight keyframes (XCD-local L2 reuse) out of a map that fits the Infinity Cache -- "
+                                                "compare `traffic`"},
                     "launches_per_step": vm["launches"] // max(args.steps, 1),
                     "avg_launch_ms": round(vm["ms"] / vm["launches"], 4),
-                    "algorithmic_bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
-                    "algorithmic_definition": "16 B x (points of the map tiles the launch reads: whole-tile-culled tiles excluded) + 8 B x R x C per keyframe image "
-                                              "(SURVEY 8d: map read + range|index image)",
-                    "frac_note": "can exceed 1: the algorithmic bytes (SURVEY 8d) count one read of the map per keyframe, the kernel fetches a map tile once "
-                                 "per eight keyframes (XCD-local L2 reuse) -- see `traffic` for the measured HBM bytes per launch and `real_bound`",
                     "point_projections_per_s": round(pps, 1),
                     "valu_insts_per_point": vpp,
-                    "valu_issue_frac": round(vpp * pps / valu_peak, 4) if vpp else None,
-                    "valu_issue_frac_of_measured_ceiling": round(vpp * pps / (64.0 * VALU_MEASURED_CEILING_WAVE_INSTS), 4) if vpp else None,
                     "valu_peak_lane_insts_per_s": valu_peak,
-                    "real_bound": "VALU issue: SQ_INSTS_VALU wave-instructions per second against one wave64 instruction per SIMD per 2 cycles (nominal 2.4 GHz) "
-                                  "and against the ceiling tools/ubench/valu_rate.hip sustains; SQ counters (tools/pmc_sq.sh) show the waves waiting to issue, not "
-                                  "on memory -- the map stays in L2 / Infinity Cache, measured HBM traffic is several times below the algorithmic bytes"}
+                    "why_valu": "SQ counters (tools/pmc_sq.sh, profiles/) show the waves waiting to ISSUE, not on memory; measured HBM traffic is several times "
+                                "below the algorithmic bytes; the ceiling tools/ubench/valu_rate.hip sustains on this chip is ~0.9 of the nominal peak"}
     rooflines = [r for r in (class_roofline(k, v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])) if r]
 
     cpu_baseline = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline and n_sessions == 2:
         cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k, knn_thr, voxel)
+    t_total = None
+    if rank == 0 and world == 1 and not args.no_t_total and args.workload == DEFAULT_WORKLOAD:
+        t_total = run_t_total(sess_t, n_kf)
 
     if rank == 0:
         M_c = len(last.outputs["OriginalNoisyCentralMapGlobal"])
@@ -247,7 +269,8 @@ def main():
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
                        "parallelism": f"keyframe-sharded x{world} (label all-reduce + scan all-gather)" if world > 1 else "single GPU",
                        "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines,
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
+            "t_total": t_total, "parity_fullsize": parity_fullsize_status(),
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
@@ -259,10 +282,81 @@ def main():
 
 
 def kernels_sha():
-    h = hashlib.sha256()
-    for f in ("ltm_kernels.hip", "ltm_device_math.h", "ltm_kernels.h"):
-        h.update(open(os.path.join(ROOT, "lt-mapper_amd", "csrc", f), "rb").read())
-    return h.hexdigest()[:16]
+    from tools import provenance
+    return provenance.kernels_sha()
+
+
+# kernel groups for the measured HBM traffic (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE name kernels, not stages): substrings of kernel names ->
+# the profile classes whose launches those kernels serve.  rocPRIM's sort / scan kernels cannot be told apart by caller, so the sort-based
+# stages share one group and the streaming rest another.
+TRAFFIC_GROUPS = [
+    ("vote_map_cull", ["k_vote_map_cull"], ["vote_map_cull"]),
+    ("map_rimg_blockmin", ["k_map_rimg_blockmin", "k_map_rimg_lds"], ["reproject_map", "vote_map_exact"]),
+    ("knn_query", ["k_knn_query", "k_knn_bin", "k_knn_cell"], ["knn_query"]),
+    ("sort_based (voxel grids, kNN grid build)", ["radix_sort", "merge_sort", "k_voxel", "k_morton", "k_head_flags", "k_segment_starts", "k_bbox", "k_scan_total",
+                                                  "k_cell_keys", "k_hash_build", "k_gather_points", "k_gather_u64", "k_compact", "k_key_"], ["voxel", "voxel_scanset", "voxel_grid_scanset", "knn_build"]),
+    ("streaming rest (scan images, compare, fills, scans + scatters, merges)", [""], ["vote_scan", "vote_compare", "vote_fill", "partition", "reproject_gather", "merge"]),
+]
+
+
+def traffic_groups(pmc, prof, steps):
+    allk = pmc.get("all_kernels")
+    if not allk:
+        return []
+    left = dict(allk)
+    out = []
+    for name, subs, classes in TRAFFIC_GROUPS:
+        mine = [k for k in list(left) if any(sub in k for sub in subs) and "k_selfcheck" not in k]
+        fetch = sum(left[k].get("FETCH_SIZE", {}).get("sum", 0.0) for k in mine)
+        write = sum(left[k].get("WRITE_SIZE", {}).get("sum", 0.0) for k in mine)
+        for k in mine:
+            left.pop(k)
+        traffic = (2.0 * fetch + write) * 1024.0       # per step: the counter passes run --steps 1 --warmup 0
+        alg = sum(prof[c]["bytes"] for c in classes if c in prof) / max(steps, 1)
+        ms = sum(prof[c]["ms"] for c in classes if c in prof) / max(steps, 1)
+        out.append({"group": name, "classes": classes, "kernels_matched": len(mine), "traffic_bytes_per_step": round(traffic, 1),
+                    "algorithmic_bytes_per_step": round(alg, 1), "traffic_over_algorithmic": round(traffic / alg, 3) if alg else None,
+                    "ms_per_step": round(ms, 3), "hbm_measured_frac": round(traffic / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if ms else None})
+    return out
+
+
+def parity_fullsize_status():
+    """is the committed full-size parity record (tools/parity_fullsize.py, tests/test_gpu_fullsize_parity.py) about THESE sources?"""
+    from tools import provenance
+    path = os.path.join(ROOT, "profiles", "parity_fullsize_2x500_3res.json")
+    try:
+        d = json.load(open(path))
+    except Exception:
+        return {"record": None, "matches_sources": False}
+    return {"record": "profiles/parity_fullsize_2x500_3res.json", "outputs_compared": d.get("outputs_compared"), "outputs_differing": d.get("outputs_differing"),
+            "record_product_sha": d.get("product_sha"), "this_product_sha": provenance.product_sha(),
+            "matches_sources": d.get("product_sha") == provenance.product_sha() and d.get("outputs_differing") == 0}
+
+
+def run_t_total(sess_t, n_kf):
+    """SURVEY 8d T_total: the same two sessions written in the reference's on-disk format, then `ltm_run` files -> files for configs[1]
+    (all keyframes, 3-res) and configs[0] (keyframes 0..49, single-res); best of a warm-up + 2 runs each"""
+    import shutil
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from tools import synth, t_total
+    root = tempfile.mkdtemp(prefix="ltm_bench_ttotal_")
+    try:
+        sess = [synth.to_numpy(s) for s in sess_t]
+        c1, dirs = t_total.measure(sess, n_kf, three_res=True, runs=3, root=root)
+        c0, _ = t_total.measure(sess, min(50, n_kf), three_res=False, runs=2, root=root, dirs=dirs)
+
+        def brief(r):
+            b = r["best"]
+            return {"T_total_s": b["T_total"], "T_step0_s": b.get("T_step0"), "T_steps123_s": b.get("T_steps123"), "T_scan_writes_s": b.get("T_scan_writes"),
+                    "keyframes": b["keyframes"], "input_bytes": r["input_bytes"], "output_bytes": b["output_bytes"],
+                    "keyframe_pairs_per_s_incl_io": r["keyframe_pairs_per_s_incl_io"]}
+        return {"what": "lt-mapper_amd/host/ltm_run, files -> files (PCD scan directories + pose files in, 16 maps + 5 x N_c scan files out), page cache warm",
+                "configs[1] 2x500 3-res": brief(c1), "configs[0] 2x50 single-res": brief(c0)}
+    except Exception as e:      # the C++ host missing or failing must not cost the bench line
+        return {"error": repr(e)[:300]}
+    finally:
+        shutil.rmtree(root, ignore_errors=True)
 
 
 def load_pmc(workload):
@@ -277,7 +371,7 @@ def load_pmc(workload):
     if d.get("workload") != workload or d.get("kernels_sha") != kernels_sha():
         return {"source": f"profiles/pmc_latest.json ignored: collected for workload {d.get('workload')} / kernel sources {d.get('kernels_sha')}, "
                           f"this run is {workload} / {kernels_sha()}"}
-    return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "valu_insts_per_point": d.get("valu_insts_per_point"),
+    return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "valu_insts_per_point": d.get("valu_insts_per_point"), "all_kernels": d.get("all_kernels"),
             "source": f"profiles/pmc_latest.json (commit {d.get('commit')}, kernel sources {d.get('kernels_sha')}): separate rocprofv3 --pmc passes, "
                       "(2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; SQ_INSTS_VALU*64 / point-projections"}
 
@@ -323,13 +417,28 @@ def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel
     # That full run takes ~3 minutes on the 256-core GPU box, which the default invocation cannot afford: it is made with --cpu-allcore
     # (tools/collect_profiles.sh does); otherwise the figure of the committed default line of this round is quoted, marked as such.
     allc = None
+    from tools import provenance
+
+    def cpu_model():
+        try:
+            return next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except Exception:
+            return None
     if ncores > 1 and args.cpu_allcore:
         allc = leg(ncores, max(1, min(args.cpu_stride_allcore, n_kf // (4 * ncores))))
+        allc.update(oracle_sha=provenance.oracle_sha(), host_cores=ncores, cpu_model=cpu_model(), workload=getattr(args, "workload", None))
     elif ncores > 1:
+        # quoted, not measured now -- and only if it was measured with THIS oracle on a host of the same shape: a ratio of
+        # a fresh GPU time and a CPU time from another host or another oracle build would mean nothing
         try:
-            prev = json.loads(open(os.path.join(ROOT, "profiles", "r2_final_bench_default.json")).read().strip().splitlines()[-1])
-            if prev["config"]["workload"] == getattr(args, "workload", None):      # the committed line is for the default workload only
-                allc = dict(prev["cpu_baseline"]["all_cores"], quoted_from="profiles/r2_final_bench_default.json (measured on the GPU box with --cpu-allcore; not re-run now)")
+            prev = json.load(open(os.path.join(ROOT, "profiles", "cpu_allcore_latest.json")))
+            same = (prev.get("workload") == getattr(args, "workload", None) and prev.get("oracle_sha") == provenance.oracle_sha() and
+                    prev.get("host_cores") == ncores and prev.get("cpu_model") == cpu_model())
+            if same:
+                allc = dict(prev, quoted_from="profiles/cpu_allcore_latest.json (same oracle sources, same CPU model and core count; measured with --cpu-allcore, not re-run now)")
+            else:
+                allc = {"value": None, "not_quoted": "profiles/cpu_allcore_latest.json was measured with another oracle build / host shape "
+                                                     f"({prev.get('oracle_sha')}, {prev.get('host_cores')} x {prev.get('cpu_model')}); run with --cpu-allcore"}
         except Exception:
             allc = None
     full = {}

@@ -118,7 +118,11 @@ int ltm_buffer_copy(ltm_ctx*, void* dst, const void* src, size_t bytes, int kind
 /* f-1 (Session.cpp:266-302): a scan set assembled from chunks of consecutive keyframes WHILE the host is still
  * decoding the next files.  Each chunk is staged through one of two pinned buffers and copied on a dedicated copy stream, so the
  * host-side packing of chunk i+1 overlaps the DMA of chunk i (and both overlap the decode threads).  capacity_points is an upper
- * bound of the total (the POINTS fields of the PCD headers).  ltm_scanset_upload_chunk returns as soon as `pts` may be reused. */
+ * bound of the total (the POINTS fields of the PCD headers).  ltm_scanset_upload_chunk returns as soon as `pts` may be reused.
+ * Two-stream rule: the device array comes from the context's stream-ordered pool, so ltm_scanset_upload_begin makes the copy stream
+ * wait for everything already queued on the compute stream (a recycled block may still be read by queued kernels), and
+ * ltm_scanset_upload_end waits for the copies before the scan set is handed to the compute stream.  An upload may therefore be
+ * started at any time, not only while the context is idle. */
 typedef uint64_t ltm_upload;
 int ltm_scanset_upload_begin(ltm_ctx*, size_t capacity_points, ltm_upload* up);
 int ltm_scanset_upload_chunk(ltm_ctx*, ltm_upload up, const void* pts, size_t stride_bytes, const uint64_t* kf_sizes, size_t n_kf);
@@ -143,8 +147,15 @@ int ltm_fetch_release(ltm_ctx*, ltm_fetch*);
  * ltm_fetch_chunk_done as soon as they have used it (the copier waits for free slots, the context thread never does).  A cloud
  * comes in consecutive ranges of points; a scan set in chunks of WHOLE keyframes [first_kf, first_kf + n_kf), whose points start
  * at offsets[first_kf] - first_point inside the chunk (LTM_E_INVALID from *_begin if one keyframe is larger than a chunk).
- * ltm_fetch_info gives the totals right away (a writer needs them for its header).  Tickets are served in the order of their
- * *_begin calls; release them with ltm_fetch_release (any thread) when all chunks are done. */
+ * ltm_fetch_info gives the totals right away (a writer needs them for its header).
+ * Contract of the chunked form (the in-tree writer, host/src/Removerter.cpp, is the model):
+ *  - ONE copier thread serves the tickets strictly in the order of their *_begin calls through the shared ring, so tickets must
+ *    also be CONSUMED in that order: a ticket nobody drains (or consumers that all block on a later ticket) stalls every later one;
+ *  - the device source (cloud / scan set handle) must stay alive and unmodified until ltm_fetch_release has returned: the copier
+ *    reads it asynchronously;
+ *  - call ltm_fetch_release (any thread) exactly once, after every consumer thread of the ticket has seen ltm_fetch_next_chunk
+ *    return 0 or an error and has handed back its chunks: release frees the ticket, a thread still inside ltm_fetch_next_chunk
+ *    would touch freed memory. */
 int ltm_cloud_fetch_chunks_begin(ltm_ctx*, ltm_cloud, ltm_fetch** out);
 int ltm_scanset_fetch_chunks_begin(ltm_ctx*, ltm_scanset, ltm_fetch** out);
 int ltm_fetch_info(ltm_fetch*, size_t* n_points, const uint64_t** offsets, size_t* n_kf);
@@ -153,8 +164,14 @@ int ltm_fetch_chunk_done(ltm_fetch*, const void* host_xyzi);
 
 /* -------------------------------------------------------------------- poses ---- */
 /* keyframe_poses_ / keyframe_inverse_poses_ (Session.cpp:102-114).  inv may be NULL: then the
- * inverse is computed in double by cofactor expansion (the reference uses Eigen's inverse()). */
+ * inverse is ltm_inverse4x4 of every pose. */
 int ltm_poses_create(ltm_ctx*, size_t n_kf, const double* poses, const double* inv_or_null, ltm_poses* out);
+/* `Eigen::Matrix4d::inverse()` as the reference uses it for the poses (Session.cpp:109-110) and the extrinsic
+ * (RosParamServer.cpp:29-30): general 4x4 inverse in double with the operation order of Eigen 3.3.7's SSE2 kernel (2x2 block
+ * adjugates; restated).  Row-major in and out, needs no context or device.  The ONE inverse of the
+ * product: ltm_create uses it for the extrinsic, ltm_poses_create for missing inverses, the C++ host for the pose files.
+ * Returns LTM_OK, or LTM_E_INVALID for a null argument or a singular / non-finite matrix (Eigen would return inf / NaN entries). */
+int ltm_inverse4x4(const double* m16, double* inv16);
 int ltm_poses_free(ltm_ctx*, ltm_poses);
 
 /* ------------------------------------------------- the hot path, one call per stage ---- */
@@ -177,6 +194,13 @@ int ltm_voxel_centroid_batch(ltm_ctx*, size_t n, const ltm_cloud* in, const floa
 int ltm_voxel_centroid_shard(ltm_ctx*, ltm_cloud in, float leaf, uint32_t shard, uint32_t n_shards, ltm_cloud* out);
 /* the same applied to every keyframe of a scan set (Session.cpp:362-380 updateScansScanwise) */
 int ltm_voxel_centroid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset* out);
+
+/* pcl::VoxelGrid exactly as the session loader applies it to every scan it reads (Session.cpp:284-289, leaf = downsample_voxel_size),
+ * for all keyframes of a scan set at once: centroids (x, y, z, intensity) per occupied leaf in ascending leaf index, float sums in
+ * input order; a keyframe whose grid would exceed INT32_MAX cells is returned unchanged (PCL's "leaf size is too small" early-out --
+ * the common case for a raw 0.05 m scan).  This is what makes a device-resident cascade hand over the scans the reference would
+ * re-load from scans_updated/ (README.md:115-118; Removerter.cpp:1658-1660). */
+int ltm_voxel_grid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset* out);
 
 /* Visibility vote, keyframes [kf_begin,kf_end) of `scans`/`poses` against `map`:
  *   scan2RangeImg (Removerter.cpp:109-156) + transformGlobalMapToLocal (utility.cpp:64-72) +

@@ -81,12 +81,14 @@ SIGNATURES = {
     "ltm_scanset_free": (_i, [_vp, _u64]),
     "ltm_poses_create": (_i, [_vp, _sz, _vp, _vp, _pu64]),
     "ltm_poses_free": (_i, [_vp, _u64]),
+    "ltm_inverse4x4": (_i, [_vp, _vp]),
     "ltm_preclean": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_merge_to_global": (_i, [_vp, _u64, _u64, _pu64]),
     "ltm_voxel_centroid": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_voxel_centroid_shard": (_i, [_vp, _u64, _f, C.c_uint32, C.c_uint32, _pu64]),
     "ltm_voxel_centroid_batch": (_i, [_vp, _sz, _pu64, C.POINTER(_f), _pu64]),
     "ltm_voxel_centroid_scanset": (_i, [_vp, _u64, _f, _pu64]),
+    "ltm_voxel_grid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
     "ltm_visibility_partition": (_i, [_vp, _u64, _u64, _u64, _f, _f, _i, _pu64, _pu64, _vp]),
@@ -125,6 +127,15 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def inverse4x4(m):
+    """ltm_inverse4x4: the library's Eigen::Matrix4d::inverse() restatement (needs no device)"""
+    a = np.ascontiguousarray(m, dtype=np.float64).reshape(16)
+    out = np.empty(16, dtype=np.float64)
+    if load_library().ltm_inverse4x4(a.ctypes.data, out.ctypes.data) != 0:
+        raise ValueError("singular or non-finite matrix")
+    return out.reshape(4, 4)
 
 
 def _np_pts(a):
@@ -241,8 +252,8 @@ class Context:
         iv = None if inv is None else np.ascontiguousarray(inv, dtype=np.float64).reshape(-1, 16)
         out = _u64()
         self._ck(self.lib.ltm_poses_create(self.h, p.shape[0], p.ctypes.data, None if iv is None else iv.ctypes.data, C.byref(out)))
-        if iv is None:
-            iv = np.stack([np.linalg.inv(m.reshape(4, 4)).reshape(16) for m in p]) if p.shape[0] else p.copy()
+        if iv is None:      # the host copy holds what the library computed for itself (ltm_inverse4x4)
+            iv = np.stack([inverse4x4(m).reshape(16) for m in p]) if p.shape[0] else p.copy()
         return Poses(self, out.value, p.shape[0], p.copy(), iv.copy())
 
     # ---- stages
@@ -286,6 +297,11 @@ class Context:
     def voxel_centroid_scanset(self, scans, leaf):
         out = _u64()
         self._ck(self.lib.ltm_voxel_centroid_scanset(self.h, scans.h, leaf, C.byref(out)))
+        return ScanSet(self, out.value)
+
+    def voxel_grid_scanset(self, scans, leaf):
+        out = _u64()
+        self._ck(self.lib.ltm_voxel_grid_scanset(self.h, scans.h, leaf, C.byref(out)))
         return ScanSet(self, out.value)
 
     def visibility_vote(self, cmap, scans, poses, kf_begin, kf_end, alpha, thr, mode, labels_dev_ptr):

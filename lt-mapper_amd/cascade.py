@@ -1,20 +1,32 @@
 """Lifelong cascade driver (BASELINE.json configs[2]).
 
 The reference leaves the lifelong loop to the user: after a run, point `central_sess_scan_dir` at the produced
-`scans_updated/` (same poses) and run again against the next query session (README.md:115-118, doc/pipeline.png).
-This module does that hand-over on the device: the central session of run j+1 is the `keyframe_scans_updated_` scan set of
-run j with the central poses unchanged; only the new query session is uploaded between runs.
+`scans_updated/` (same poses) and run again against the next query session (README.md:115-118, doc/pipeline.png).  That next
+run RE-LOADS the scans: `Session::loadKeyframes` puts every file through `pcl::VoxelGrid(downsample_voxel_size)`
+(Session.cpp:284-289) and `Removerter::run` through `precleaningKeyframes(2.5)` (Removerter.cpp:1658-1660, Session.cpp:506-533)
+before `makeGlobalMap`.  This module does the same hand-over on the device: the central session of run j+1 is
+`ltm_preclean(ltm_voxel_grid_scanset(keyframe_scans_updated_ of run j, downsample_voxel_size), 2.5)` with the central poses
+unchanged -- bit for bit what `ltm_run` loads from the files of run j (tests/test_gpu_cascade.py) -- and only the new query
+session is uploaded between runs.
 """
 from .removerter import Params, Removerter, Session
 
+kPrecleanRadius = 2.5       # Removerter.cpp:1660
+
+
+def reload_scans(ops, scans, params: Params):
+    """what Session::loadKeyframes + precleaningKeyframes make of a scan set that was written to and read back from scans_updated/"""
+    return ops.preclean(ops.voxel_grid_scanset(scans, params.downsample_voxel_size), kPrecleanRadius)
+
 
 def run_cascade(ops, params: Params, central_scans, central_poses, queries):
-    """queries: list of (scans, poses) handles of sessions 2..K.  Returns the list of Removerter objects (one per pair run);
-    the live map after the last run is runs[-1].outputs['updated_map'], the live scans runs[-1].central_sess_.keyframe_scans_updated_."""
+    """central_scans / queries: (scans, poses) handles as a loader leaves them (VoxelGrid + pre-clean applied), sessions 1 and
+    2..K.  Returns the list of Removerter objects (one per pair run); the live map after the last run is
+    runs[-1].outputs['updated_map'], the live scans runs[-1].central_sess_.keyframe_scans_updated_."""
     runs = []
     for q_scans, q_poses in queries:
         rm = Removerter(ops, params, Session("Central", central_scans, central_poses), Session("Query", q_scans, q_poses))
         rm.run()
         runs.append(rm)
-        central_scans = rm.central_sess_.keyframe_scans_updated_      # "scans_updated/" becomes the next central session
+        central_scans = reload_scans(ops, rm.central_sess_.keyframe_scans_updated_, params)      # "scans_updated/" re-loaded as the next central session
     return runs

@@ -13,6 +13,7 @@
 #include <mutex>
 #include <thread>
 #include <cfloat>
+#include <climits>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -40,9 +41,12 @@ struct Err { int code; std::string msg; };
         if (!(cond)) throw Err{LTM_E_INVALID, std::string(msg)}; \
     } while (0)
 
-// Stream-ordered caching allocator: every kernel and copy of a context is issued on ONE stream, so a
-// block may be handed out again as soon as the host has released it.  hipMalloc/hipFree (which
-// synchronise the device) happen only on first use of a size class and at ltm_destroy().
+// Stream-ordered caching allocator: kernels and copies of a context are issued on ONE stream (c->stream), so a
+// block may be handed out again as soon as the host has released it.  The two users of the second (copy) stream order
+// themselves explicitly: ltm_scanset_upload_begin makes the copy stream wait for the compute stream before the first DMA
+// into a (possibly recycled) block, ltm_scanset_upload_end drains the copy stream; fetches record an event on the compute
+// stream and their sources are kept alive by the caller.  hipMalloc/hipFree (which synchronise the device) happen only on
+// first use of a size class and at ltm_destroy().
 struct Pool {
     std::multimap<size_t, void*> free_blocks;
     std::unordered_map<void*, size_t> live;
@@ -335,25 +339,48 @@ bool mat_is_identity(const double* m16)
 }
 HostMat34 to34(const double* m16) { HostMat34 h; memcpy(h.m, m16, 12 * sizeof(double)); return h; }
 
-// general 4x4 inverse, Gauss-Jordan with partial pivoting in double (stands in for Eigen's inverse())
+// General 4x4 inverse in double with the operation order of Eigen 3.3.7's Matrix4d::inverse() in an SSE2 build -- what the reference
+// calls for every pose (Session.cpp:109-110) and for the extrinsic (RosParamServer.cpp:29-30); restated from knowledge of its
+// structure (PARITY UNPINNED): the 16 doubles of the column-major matrix are read in memory order as the four 2x2
+// blocks A B / C D of N = M^T, the inverse is assembled from the adjugate products A#B and D#C ("divide and conquer" over the
+// blocks), det = |A||D| + |B||C| - trace(A#B D#C), every product and sum rounded on its own (no FMA).  m, inv: row-major.
 bool inverse4x4(const double* m, double* inv)
 {
-    double a[4][8];
-    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) { a[r][k] = m[4 * r + k]; a[r][4 + k] = (r == k) ? 1.0 : 0.0; }
-    for (int col = 0; col < 4; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
-        if (a[piv][col] == 0.0) return false;
-        if (piv != col) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
-        const double d = a[col][col];
-        for (int k = 0; k < 8; ++k) a[col][k] /= d;
-        for (int r = 0; r < 4; ++r) {
-            if (r == col) continue;
-            const double f = a[r][col];
-            if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
+    double A[2][2], B[2][2], C[2][2], D[2][2];
+    for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < 2; ++k) {        // N(r, k) = m(k, r)
+            A[r][k] = m[4 * k + r]; B[r][k] = m[4 * (k + 2) + r];
+            C[r][k] = m[4 * k + r + 2]; D[r][k] = m[4 * (k + 2) + r + 2];
         }
+    const double dA = A[0][0] * A[1][1] - A[0][1] * A[1][0], dB = B[0][0] * B[1][1] - B[0][1] * B[1][0];
+    const double dC = C[0][0] * C[1][1] - C[0][1] * C[1][0], dD = D[0][0] * D[1][1] - D[0][1] * D[1][0];
+    double AB[2][2], DC[2][2];
+    for (int j = 0; j < 2; ++j) {
+        AB[0][j] = B[0][j] * A[1][1] - B[1][j] * A[0][1]; AB[1][j] = B[1][j] * A[0][0] - B[0][j] * A[1][0];
+        DC[0][j] = C[0][j] * D[1][1] - C[1][j] * D[0][1]; DC[1][j] = C[1][j] * D[0][0] - C[0][j] * D[1][0];
     }
-    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = a[r][4 + k];
+    const double tr = (AB[0][0] * DC[0][0] + AB[1][0] * DC[0][1]) + (AB[0][1] * DC[1][0] + AB[1][1] * DC[1][1]);
+    double iA[2][2], iB[2][2], iC[2][2], iD[2][2];
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            iD[i][j] = D[i][j] * dA - (AB[0][j] * C[i][0] + AB[1][j] * C[i][1]);
+            iA[i][j] = A[i][j] * dD - (DC[0][j] * B[i][0] + DC[1][j] * B[i][1]);
+        }
+    for (int i = 0; i < 2; ++i) {
+        iB[i][0] = D[i][0] * AB[1][1] - D[i][1] * AB[1][0]; iB[i][1] = D[i][1] * AB[0][0] - D[i][0] * AB[0][1];
+        iC[i][0] = A[i][0] * DC[1][1] - A[i][1] * DC[1][0]; iC[i][1] = A[i][1] * DC[0][0] - A[i][0] * DC[0][1];
+    }
+    const double det = (dA * dD + dB * dC) - tr;
+    if (det == 0.0 || det != det) return false;      // Eigen would return inf / NaN entries; a singular pose is an error here
+    const double rd = 1.0 / det;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) { iB[i][j] = C[i][j] * dB - iB[i][j]; iC[i][j] = B[i][j] * dC - iC[i][j]; }
+    double R[4][4];      // inverse of N, row-major: the blocks' adjugates times +-1/det
+    auto put = [&](const double X[2][2], int r, int c) {
+        R[r][c] = X[1][1] * rd; R[r][c + 1] = X[0][1] * -rd; R[r + 1][c] = X[1][0] * -rd; R[r + 1][c + 1] = X[0][0] * rd;
+    };
+    put(iA, 0, 0); put(iB, 0, 2); put(iC, 2, 0); put(iD, 2, 2);
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = R[k][r];
     return true;
 }
 
@@ -806,7 +833,16 @@ struct VoxelJob {
     std::unique_ptr<DevBuf> keys, idx, keys2, idx2, heads, pos;
     float4* out = nullptr; size_t nvox = 0;
 };
+void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs);
 void voxel_centroid_batch(ltm_ctx* c, std::vector<VoxelJob>& jobs)
+{
+    try { voxel_centroid_batch_impl(c, jobs); }
+    catch (...) {      // outputs already allocated for earlier jobs go back to the pool (the scratch buffers are RAII)
+        for (VoxelJob& j : jobs) { if (j.out) c->pool.free(j.out); j.out = nullptr; j.nvox = 0; }
+        throw;
+    }
+}
+void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
 {
     const size_t nj = jobs.size();
     if (nj == 0) return;
@@ -861,6 +897,10 @@ void voxel_centroid_batch(ltm_ctx* c, std::vector<VoxelJob>& jobs)
     }
     std::vector<uint32_t> nv(nj);
     d2h(c, nv.data(), counts.p, nj * 4);
+    if (getenv("LTM_VOXEL_LOG"))
+        for (size_t k = 0; k < nj; ++k)
+            fprintf(stderr, "[ltm] voxel batch %zu/%zu: n %zu -> %u voxels, leaf %.3f, depth %u, index bits %u, packed %d\n", k, nj, jobs[k].n, nv[k], jobs[k].leaf,
+                    jobs[k].f.depth, jobs[k].ib, (int)jobs[k].packed);
     // phase C: centroids
     for (size_t k = 0; k < nj; ++k) {
         VoxelJob& j = jobs[k];
@@ -1403,7 +1443,8 @@ int ltm_scanset_upload_begin(ltm_ctx* c, size_t capacity_points, ltm_upload* up)
         UploadState u;
         u.cap = capacity_points;
         u.d = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(capacity_points, 1) * 16));
-        (void)copy_stream(c);
+        try { copy_after_compute(c); }      // the block may be recycled: kernels already queued on the compute stream may still use it
+        catch (...) { c->pool.free(u.d); throw; }
         const uint64_t h = c->next_handle++;
         c->uploads[h] = std::move(u);
         *up = h;
@@ -1564,7 +1605,10 @@ static void fetch_chunks_begin(ltm_ctx* c, const float4* src, size_t n, std::vec
         }
     }
     LTM_HIP(hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
-    LTM_HIP(hipEventRecord(t->done, c->stream));        // the source is final once the compute stream gets here
+    if (hipEventRecord(t->done, c->stream) != hipSuccess) {        // the source is final once the compute stream gets here
+        (void)hipEventDestroy(t->done);
+        throw Err{LTM_E_DEVICE, "hipEventRecord failed for a chunked fetch"};
+    }
     ltm_fetch* raw = t.release();
     { std::lock_guard<std::mutex> lk(r->mx); r->jobs.push_back(raw); }
     r->cv_jobs.notify_one();
@@ -1576,10 +1620,16 @@ static void fetch_begin(ltm_ctx* c, const float4* src, size_t n, std::vector<uin
     std::unique_ptr<ltm_fetch> t(new ltm_fetch());
     t->n_points = n; t->bytes = n * 16; t->off = std::move(off); t->device = c->device;
     t->host = pinned_alloc(c, t->bytes);
-    LTM_HIP(hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
-    copy_after_compute(c);
-    if (n) LTM_HIP(hipMemcpyAsync(t->host, src, t->bytes, hipMemcpyDeviceToHost, copy_stream(c)));
-    LTM_HIP(hipEventRecord(t->done, copy_stream(c)));
+    try {
+        LTM_HIP(hipEventCreateWithFlags(&t->done, hipEventDisableTiming));
+        copy_after_compute(c);
+        if (n) LTM_HIP(hipMemcpyAsync(t->host, src, t->bytes, hipMemcpyDeviceToHost, copy_stream(c)));
+        LTM_HIP(hipEventRecord(t->done, copy_stream(c)));
+    } catch (...) {      // the ticket dies with the unique_ptr: hand the pinned block back and drop the event
+        if (t->done) { (void)hipStreamSynchronize(c->copy_stream); (void)hipEventDestroy(t->done); }
+        pinned_free(c, t->host);
+        throw;
+    }
     *out = t.release();
 }
 int ltm_cloud_fetch_begin(ltm_ctx* c, ltm_cloud h, ltm_fetch** out)
@@ -1693,6 +1743,11 @@ int ltm_poses_create(ltm_ctx* c, size_t n, const double* poses, const double* in
         *out = h;
     });
 }
+int ltm_inverse4x4(const double* m16, double* inv16)
+{
+    if (!m16 || !inv16) return LTM_E_INVALID;
+    return inverse4x4(m16, inv16) ? LTM_OK : LTM_E_INVALID;
+}
 int ltm_poses_free(ltm_ctx* c, ltm_poses h)
 {
     return guarded(c, [&] { Poses& p = get_poses(c, h); c->pool.free(p.pose_dev); c->pool.free(p.inv_dev); c->pool.free(p.approx_dev); c->poses.erase(h); });
@@ -1750,9 +1805,16 @@ int ltm_voxel_centroid_batch(ltm_ctx* c, size_t n, const ltm_cloud* in, const fl
         std::vector<VoxelJob> jobs(n);
         for (size_t k = 0; k < n; ++k) { const Cloud cl = get_cloud(c, in[k]); jobs[k].pts = cl.d; jobs[k].n = cl.n; jobs[k].leaf = leaf[k]; }
         voxel_centroid_batch(c, jobs);
-        for (size_t k = 0; k < n; ++k) {
-            float4* d = jobs[k].out ? jobs[k].out : reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
-            out[k] = new_cloud(c, d, jobs[k].nvox);
+        size_t done = 0;
+        try {
+            for (; done < n; ++done) {
+                float4* d = jobs[done].out ? jobs[done].out : reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+                jobs[done].out = nullptr;
+                out[done] = new_cloud(c, d, jobs[done].nvox);
+            }
+        } catch (...) {      // handles made so far stay valid for the caller to free; the rest of the outputs go back to the pool
+            for (size_t k = done; k < n; ++k) if (jobs[k].out) c->pool.free(jobs[k].out);
+            throw;
         }
     });
 }
@@ -1829,6 +1891,79 @@ int ltm_voxel_centroid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scan
         LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
         float4* o = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nvox, 1) * sizeof(float4)));
         LTM_HIP(voxel_centroids(s.d, idx2.as<uint32_t>(), starts.as<uint32_t>(), nvox, n, o, c->stream));
+        *out = new_scanset(c, o, std::move(off));
+    });
+}
+
+int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
+        const ScanSet& s = get_ss(c, hin);
+        const size_t nk = s.nkf();
+        const size_t n = s.n_pts;
+        LTM_REQUIRE(n < 0xffffffffull, "scan set too large for 32-bit point indices");
+        std::vector<uint64_t> off(nk + 1, 0);
+        if (n == 0 || nk == 0) {
+            *out = new_scanset(c, reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4))), std::move(off));
+            return;
+        }
+        ProfScope ps(c, "voxel_grid_scanset", (double)n, 64.0 * n);
+        DevBuf bb(c, nk * 6 * sizeof(uint32_t));
+        LTM_HIP(bbox_reduce_seg(s.d, s.off_dev, nk, n, bb.as<uint32_t>(), c->stream));
+        std::vector<uint32_t> enc(nk * 6);
+        d2h(c, enc.data(), bb.p, enc.size() * 4);
+        // pcl::VoxelGrid::applyFilter (PCL 1.10 voxel_grid.hpp): inverse leaf size in float, the "leaf size is too small"
+        // test on int64 cell counts, min_b / div_b from floor(min * inv), floor(max * inv)
+        const float inv = 1.0f / leaf;
+        std::vector<VoxelGridFrame> frames(nk);
+        for (size_t k = 0; k < nk; ++k) {
+            VoxelGridFrame& f = frames[k];
+            f.inv = inv; f.passthrough = 1;
+            for (int d = 0; d < 3; ++d) { f.min_b[d] = 0; f.div_b[d] = 1; }
+            if (s.off[k + 1] == s.off[k]) continue;
+            float mn[3], mx[3];
+            int64_t cells = 1;
+            for (int d = 0; d < 3; ++d) {
+                mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]);
+                const float ext = (mx[d] - mn[d]) * inv;
+                cells *= (int64_t)ext + 1;
+            }
+            if (cells > (int64_t)INT32_MAX) continue;           // output = input (the common case for a raw 0.05 m scan)
+            f.passthrough = 0;
+            for (int d = 0; d < 3; ++d) {
+                f.min_b[d] = (int)std::floor(mn[d] * inv);
+                f.div_b[d] = (int)std::floor(mx[d] * inv) - f.min_b[d] + 1;
+            }
+        }
+        unsigned kf_bits = 1;
+        while ((1ull << kf_bits) < nk) ++kf_bits;
+        DevBuf fdev(c, nk * sizeof(VoxelGridFrame));
+        h2d(c, fdev.p, frames.data(), nk * sizeof(VoxelGridFrame));
+        DevBuf keys(c, n * 8), keys2(c, n * 8), idx(c, n * 4), idx2(c, n * 4);
+        LTM_HIP(voxelgrid_keys_seg(s.d, s.off_dev, nk, n, fdev.as<VoxelGridFrame>(), keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
+        const size_t stb = sort_temp_bytes(n);
+        {
+            DevBuf stemp(c, stb);
+            LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, 32 + kf_bits, stemp.p, stb, c->stream));
+        }
+        DevBuf heads(c, n), pos(c, n * 4);
+        LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
+        const size_t tb = scan_temp_bytes(n);
+        DevBuf temp(c, tb);
+        LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+        const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
+        // the sort key leads with the keyframe id, so keyframe k still occupies sorted positions [off[k], off[k+1])
+        DevBuf bout(c, (nk + 1) * 4);
+        LTM_HIP(gather_u32(pos.as<uint32_t>(), s.off_dev, nk + 1, n, (uint32_t)nvox, bout.as<uint32_t>(), c->stream));
+        std::vector<uint32_t> b(nk + 1);
+        d2h(c, b.data(), bout.p, (nk + 1) * 4);
+        for (size_t k = 0; k <= nk; ++k) off[k] = b[k];
+        DevBuf starts(c, nvox * 4);
+        LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
+        float4* o = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nvox, 1) * sizeof(float4)));
+        LTM_HIP(voxelgrid_centroids(s.d, keys2.as<uint64_t>(), idx2.as<uint32_t>(), starts.as<uint32_t>(), fdev.as<VoxelGridFrame>(), nvox, n, o, c->stream));
         *out = new_scanset(c, o, std::move(off));
     });
 }

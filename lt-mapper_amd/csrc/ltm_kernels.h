@@ -120,6 +120,12 @@ hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* key
 hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, uint32_t* bbox, hipStream_t s);
 hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const OctreeFrame* frames_dev,
                            unsigned shift, uint64_t* keys, uint32_t* idx, hipStream_t s);
+// pcl::VoxelGrid of the session loader for every keyframe of a scan set (Session.cpp:284-289): per-keyframe frame computed on the host
+struct VoxelGridFrame { float inv; int min_b[3]; int div_b[3]; int passthrough; };
+hipError_t voxelgrid_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const VoxelGridFrame* frames_dev,
+                              uint64_t* keys, uint32_t* idx, hipStream_t s);
+hipError_t voxelgrid_centroids(const float4* pts, const uint64_t* sorted_keys, const uint32_t* sorted_idx, const uint32_t* starts,
+                               const VoxelGridFrame* frames_dev, size_t n_vox, size_t n, float4* out, hipStream_t s);
 size_t sort_temp_bytes(size_t n);
 hipError_t scan_total_to(const uint8_t* flags, const uint32_t* pos, size_t n, uint32_t* out_dev, hipStream_t s);
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,

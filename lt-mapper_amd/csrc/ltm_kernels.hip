@@ -1439,6 +1439,65 @@ hipError_t morton_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_
     return hipGetLastError();
 }
 
+// pcl::VoxelGrid as the session loader applies it to every scan (Session.cpp:284-289), all keyframes of a scan set in one
+// pass: key = (keyframe << 32) | linear leaf index ijk0 + ijk1*div0 + ijk2*div0*div1, ijk = (int)(floor(p * inv_leaf) - (float)min_b)
+// in binary32.  A keyframe whose grid would overflow int32 ("leaf size too small": the filter returns its input) gets its points'
+// own positions as keys, so that every point is a voxel of its own and keeps its place.
+__global__ void __launch_bounds__(kBlock)
+k_voxelgrid_keys_seg(const float4* __restrict__ pts, const uint64_t* __restrict__ offsets, size_t n_kf, uint64_t n,
+                     const VoxelGridFrame* __restrict__ frames, uint64_t* __restrict__ keys, uint32_t* __restrict__ idx)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    size_t lo = 0, hi = n_kf;
+    while (hi - lo > 1) { const size_t mid = (lo + hi) >> 1; if (offsets[mid] <= i) lo = mid; else hi = mid; }
+    const VoxelGridFrame f = frames[lo];
+    uint32_t leaf;
+    if (f.passthrough) leaf = (uint32_t)(i - offsets[lo]);
+    else {
+        const float4 p = pts[i];
+        const int i0 = (int)(floorf(p.x * f.inv) - (float)f.min_b[0]);
+        const int i1 = (int)(floorf(p.y * f.inv) - (float)f.min_b[1]);
+        const int i2 = (int)(floorf(p.z * f.inv) - (float)f.min_b[2]);
+        leaf = (uint32_t)i0 + (uint32_t)i1 * (uint32_t)f.div_b[0] + (uint32_t)i2 * (uint32_t)f.div_b[0] * (uint32_t)f.div_b[1];
+    }
+    keys[i] = ((uint64_t)lo << 32) | leaf;
+    idx[i] = (uint32_t)i;
+}
+hipError_t voxelgrid_keys_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, const VoxelGridFrame* frames_dev,
+                              uint64_t* keys, uint32_t* idx, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_voxelgrid_keys_seg<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, offsets_dev, n_kf, n, frames_dev, keys, idx);
+    return hipGetLastError();
+}
+// CentroidPoint accumulators of pcl::VoxelGrid: float sums over the voxel's points (input order: the sort is stable), divided by
+// the count; points of a pass-through keyframe are copied bit for bit (0 + x would turn a -0 into +0)
+__global__ void __launch_bounds__(kBlock)
+k_voxelgrid_centroids(const float4* __restrict__ pts, const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ sorted_idx,
+                      const uint32_t* __restrict__ starts, const VoxelGridFrame* __restrict__ frames, size_t n_vox, size_t n, float4* __restrict__ out)
+{
+    const size_t v = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (v >= n_vox) return;
+    const uint32_t a = starts[v];
+    const uint32_t b = (v + 1 < n_vox) ? starts[v + 1] : (uint32_t)n;
+    if (frames[sorted_keys[a] >> 32].passthrough) { out[v] = pts[sorted_idx[a]]; return; }
+    float sx = 0.0f, sy = 0.0f, sz = 0.0f, si = 0.0f;
+    for (uint32_t j = a; j < b; ++j) {
+        const float4 p = pts[sorted_idx[j]];
+        sx = sx + p.x; sy = sy + p.y; sz = sz + p.z; si = si + p.w;
+    }
+    const float cnt = (float)(b - a);
+    out[v] = make_float4(sx / cnt, sy / cnt, sz / cnt, si / cnt);
+}
+hipError_t voxelgrid_centroids(const float4* pts, const uint64_t* sorted_keys, const uint32_t* sorted_idx, const uint32_t* starts,
+                               const VoxelGridFrame* frames_dev, size_t n_vox, size_t n, float4* out, hipStream_t s)
+{
+    if (!n_vox) return hipSuccess;
+    k_voxelgrid_centroids<<<dim3(grid_for(n_vox)), dim3(kBlock), 0, s>>>(pts, sorted_keys, sorted_idx, starts, frames_dev, n_vox, n, out);
+    return hipGetLastError();
+}
+
 // PCL genOctreeKeyforPoint: key = (unsigned)(((double)p - min) / resolution); Morton code with x as the
 // most significant bit of each level triple (child index = x<<2 | y<<1 | z).
 __device__ __forceinline__ uint64_t spread3(uint32_t v)   // 21 bits -> every third bit

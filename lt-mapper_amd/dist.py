@@ -175,6 +175,16 @@ class ShardedOps:
             return LazyScans(self, self.ops.voxel_scanset(s.local, leaf), s.kb, s.ke, s.n)
         return self.ops.voxel_scanset(s, leaf)
 
+    def voxel_grid_scanset(self, s, leaf):      # per-keyframe, like voxel_scanset
+        if isinstance(s, LazyScans):
+            return LazyScans(self, self.ops.voxel_grid_scanset(s.local, leaf), s.kb, s.ke, s.n)
+        return self.ops.voxel_grid_scanset(s, leaf)
+
+    def preclean(self, s, radius):
+        if isinstance(s, LazyScans):
+            return LazyScans(self, self.ops.preclean(s.local, radius), s.kb, s.ke, s.n)
+        return self.ops.preclean(s, radius)
+
     # ---- stages that need every keyframe
     def merge_to_global(self, scans, poses):
         return self.ops.merge_to_global(self.materialize(scans), poses)

@@ -5,6 +5,7 @@
 #include <hip/hip_runtime_api.h>
 #include <rccl/rccl.h>
 
+#include <mutex>
 #include <stdexcept>
 #include <string>
 
@@ -29,7 +30,14 @@ struct RcclGroup
 {
     std::vector<ncclComm_t> comms;
     std::vector<int> devs;
+    std::mutex mx;                 // abort() may come from any rank's thread
+    // an aborted communicator is already released by ncclCommAbort: its slot is nulled there so that it is not destroyed twice
     ~RcclGroup() { for (ncclComm_t c : comms) if (c) ncclCommDestroy(c); }
+    void abortAll()
+    {
+        std::lock_guard<std::mutex> lk(mx);
+        for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+    }
 };
 
 class RcclComm : public Comm
@@ -87,7 +95,7 @@ public:
     }
 
     void barrier() override {}      // every exchange is stream-ordered; the host threads never need to meet
-    void abort() override { for (ncclComm_t c : g_->comms) if (c) (void)ncclCommAbort(c); }
+    void abort() override { g_->abortAll(); }
 };
 
 } // namespace

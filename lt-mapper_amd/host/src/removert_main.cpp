@@ -36,7 +36,12 @@ static int runSharded(int world, bool rccl)
                 errors[(size_t)r] = e.what();
                 std::fprintf(stderr, "ltm_run: rank %d: %s\n", r, e.what());
                 comms[(size_t)r]->abort();
-                if (rccl) std::_Exit(1);          // peers may be parked inside a collective
+                if (rccl) {      // peers may be parked inside a collective on an aborted communicator: no orderly unwinding is possible
+                    std::fprintf(stderr, "ltm_run: rank %d failed; the outputs under %s are INCOMPLETE (the other ranks' writers were cut off)\n", r,
+                                 p.save_pcd_directory_.c_str());
+                    std::fflush(stderr);
+                    std::_Exit(1);
+                }
             }
         });
     for (auto& t : threads) t.join();

@@ -42,26 +42,9 @@ std::pair<int, int> resetRimgSize(const std::pair<float, float> _fov, const floa
     return {rows, cols};
 }
 
-bool inverse4x4(const double* m, double* inv)
-{
-    double a[4][8];
-    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) { a[r][k] = m[4 * r + k]; a[r][4 + k] = (r == k) ? 1.0 : 0.0; }
-    for (int col = 0; col < 4; ++col) {
-        int piv = col;
-        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
-        if (a[piv][col] == 0.0) return false;
-        if (piv != col) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
-        const double d = a[col][col];
-        for (int k = 0; k < 8; ++k) a[col][k] /= d;
-        for (int r = 0; r < 4; ++r) {
-            if (r == col) continue;
-            const double f = a[r][col];
-            if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
-        }
-    }
-    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = a[r][4 + k];
-    return true;
-}
+// Eigen::Matrix4d::inverse() of Session.cpp:109-110 / RosParamServer.cpp:29-30: the library's restatement of Eigen 3.3.7's SSE2
+// kernel (ltm_inverse4x4) -- the one inverse host, library and oracle agree on bit for bit
+bool inverse4x4(const double* m, double* inv) { return ltm_inverse4x4(m, inv) == LTM_OK; }
 
 void parallelFor(size_t n, const std::function<void(size_t)>& f, unsigned threads)
 {

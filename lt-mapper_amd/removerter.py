@@ -49,6 +49,8 @@ class HipOps:
     def voxel_batch(self, clouds, leaf): return self.ctx.voxel_centroid_batch(clouds, [leaf] * len(clouds))   # independent grids, two host round trips in all
     def voxel_shard(self, c, leaf, shard, n_shards): return self.ctx.voxel_centroid_shard(c, leaf, shard, n_shards)
     def voxel_scanset(self, s, leaf): return self.ctx.voxel_centroid_scanset(s, leaf)
+    def voxel_grid_scanset(self, s, leaf): return self.ctx.voxel_grid_scanset(s, leaf)      # the loader's pcl::VoxelGrid, Session.cpp:284-289
+    def preclean(self, s, radius): return self.ctx.preclean(s, radius)                      # Session.cpp:506-533
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
     def reproject(self, cmap, poses, alpha): return self.ctx.reproject(cmap, poses, alpha)
     def knn_partition(self, target, scans, poses, k, thr): return self.ctx.knn_partition(target, scans, poses, k, thr)

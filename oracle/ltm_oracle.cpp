@@ -40,13 +40,30 @@ double now_s()
 /* utility.cpp:53-56 : float rad2deg(float) { return radians * 180.0 / M_PI; }  (double math, float result) */
 inline float rad2deg(float r) { return (float)((double)r * 180.0 / M_PI); }
 
+/* Sensitivity experiments only (tools/numerics_sensitivity.py): with g_atan_perturb_ppm != 0 that fraction of the atan2f results is
+ * moved by one ulp up or down, chosen by a hash of the arguments -- "what if the reference's libm rounded differently".  Off by
+ * default; nothing else in the oracle reads it. */
+unsigned g_atan_perturb_ppm = 0;
+uint64_t g_atan_perturb_seed = 0;
+inline float atan2f_ref(float y, float x)
+{
+    const float a = om_atan2f(y, x);
+    if (__builtin_expect(g_atan_perturb_ppm == 0, 1)) return a;
+    uint32_t by, bx;
+    memcpy(&by, &y, 4); memcpy(&bx, &x, 4);
+    uint64_t h = (((uint64_t)by << 32) | bx) + g_atan_perturb_seed + 0x9e3779b97f4a7c15ull;      /* splitmix64 */
+    h = (h ^ (h >> 30)) * 0xbf58476d1ce4e5b9ull; h = (h ^ (h >> 27)) * 0x94d049bb133111ebull; h ^= h >> 31;
+    if ((h >> 8) % 1000000u >= g_atan_perturb_ppm) return a;
+    return nextafterf(a, (h & 1) ? INFINITY : -INFINITY);
+}
+
 struct Sph { float az, el, r; };
 /* utility.cpp:38-51 */
 inline Sph cart2sph(float x, float y, float z)
 {
     Sph s;
-    s.az = om_atan2f(y, x);
-    s.el = om_atan2f(z, sqrtf(x * x + y * y));
+    s.az = atan2f_ref(y, x);
+    s.el = atan2f_ref(z, sqrtf(x * x + y * y));
     s.r = sqrtf(x * x + y * y + z * z);
     return s;
 }
@@ -535,7 +552,59 @@ void load_session(Sess& s, const float* scans, const uint64_t* off, size_t nkf, 
     s.inv.assign(inv, inv + 16 * nkf);
 }
 
+/* Eigen::Matrix4d::inverse() (Session.cpp:109-110, RosParamServer.cpp:29-30) as Eigen 3.3.7 evaluates it in the reference's
+ * SSE2 build (Eigen/src/LU/arch/Inverse_SSE.h, double specialisation; restated from knowledge of its structure -- PARITY
+ * UNPINNED): the column-major matrix is read in memory order as four 2x2 blocks A B / C D of N = M^T; with X# the adjugate,
+ *   AB = A#B, DC = D#C, det = |A||D| + |B||C| - trace(AB DC),
+ *   inverse blocks = (A|D| - B DC)#, (C|B| - D AB#)#, (B|C| - A DC#)#, (D|A| - C AB)#, each times +-1/det,
+ * every product and sum a separately rounded double operation in the order written (SSE2 has no FMA).  Row-major in/out. */
 int inverse4x4(const double* m, double* inv)
+{
+    double A[2][2], B[2][2], C[2][2], D[2][2];
+    for (int r = 0; r < 2; ++r)
+        for (int k = 0; k < 2; ++k) {
+            A[r][k] = m[4 * k + r]; B[r][k] = m[4 * (k + 2) + r];
+            C[r][k] = m[4 * k + r + 2]; D[r][k] = m[4 * (k + 2) + r + 2];
+        }
+    const double dA = A[0][0] * A[1][1] - A[0][1] * A[1][0], dB = B[0][0] * B[1][1] - B[0][1] * B[1][0];
+    const double dC = C[0][0] * C[1][1] - C[0][1] * C[1][0], dD = D[0][0] * D[1][1] - D[0][1] * D[1][0];
+    double AB[2][2], DC[2][2], iA[2][2], iB[2][2], iC[2][2], iD[2][2];
+    for (int j = 0; j < 2; ++j) {
+        AB[0][j] = B[0][j] * A[1][1] - B[1][j] * A[0][1]; AB[1][j] = B[1][j] * A[0][0] - B[0][j] * A[1][0];
+        DC[0][j] = C[0][j] * D[1][1] - C[1][j] * D[0][1]; DC[1][j] = C[1][j] * D[0][0] - C[0][j] * D[1][0];
+    }
+    const double tr = (AB[0][0] * DC[0][0] + AB[1][0] * DC[0][1]) + (AB[0][1] * DC[1][0] + AB[1][1] * DC[1][1]);
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) {
+            const double cab = AB[0][j] * C[i][0] + AB[1][j] * C[i][1];
+            const double bdc = DC[0][j] * B[i][0] + DC[1][j] * B[i][1];
+            iD[i][j] = D[i][j] * dA - cab;
+            iA[i][j] = A[i][j] * dD - bdc;
+        }
+    for (int i = 0; i < 2; ++i) {
+        iB[i][0] = D[i][0] * AB[1][1] - D[i][1] * AB[1][0]; iB[i][1] = D[i][1] * AB[0][0] - D[i][0] * AB[0][1];
+        iC[i][0] = A[i][0] * DC[1][1] - A[i][1] * DC[1][0]; iC[i][1] = A[i][1] * DC[0][0] - A[i][0] * DC[0][1];
+    }
+    const double d1 = dA * dD, d2 = dB * dC;
+    const double det = (d1 + d2) - tr;
+    if (det == 0.0 || det != det) return -1;
+    const double rd = 1.0 / det, nrd = -rd;
+    for (int i = 0; i < 2; ++i)
+        for (int j = 0; j < 2; ++j) { iB[i][j] = C[i][j] * dB - iB[i][j]; iC[i][j] = B[i][j] * dC - iC[i][j]; }
+    const double (*blk[4])[2] = {iA, iB, iC, iD};
+    const int at[4][2] = {{0, 0}, {0, 2}, {2, 0}, {2, 2}};
+    for (int q = 0; q < 4; ++q) {
+        const double (*X)[2] = blk[q];
+        const int r = at[q][0], c = at[q][1];       /* (r, c) of N^-1 is element (c, r) of M^-1 */
+        inv[4 * c + r] = X[1][1] * rd; inv[4 * (c + 1) + r] = X[0][1] * nrd;
+        inv[4 * c + r + 1] = X[1][0] * nrd; inv[4 * (c + 1) + r + 1] = X[0][0] * rd;
+    }
+    return 0;
+}
+
+/* the same inverse by cofactor expansion (what rounds 1-2 of this oracle used) and by Gauss-Jordan elimination with partial
+ * pivoting: only for tests/test_numerics_sensitivity.py, which measures what the last bits of the inverse can move */
+int inverse4x4_cofactor(const double* m, double* inv)
 {
     double a[16];
     a[0] = m[5] * m[10] * m[15] - m[5] * m[11] * m[14] - m[9] * m[6] * m[15] + m[9] * m[7] * m[14] + m[13] * m[6] * m[11] - m[13] * m[7] * m[10];
@@ -558,6 +627,27 @@ int inverse4x4(const double* m, double* inv)
     if (det == 0.0) return -1;
     det = 1.0 / det;
     for (int i = 0; i < 16; ++i) inv[i] = a[i] * det;
+    return 0;
+}
+
+int inverse4x4_gauss_jordan(const double* m, double* inv)
+{
+    double a[4][8];
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) { a[r][k] = m[4 * r + k]; a[r][4 + k] = (r == k) ? 1.0 : 0.0; }
+    for (int col = 0; col < 4; ++col) {
+        int piv = col;
+        for (int r = col + 1; r < 4; ++r) if (std::fabs(a[r][col]) > std::fabs(a[piv][col])) piv = r;
+        if (a[piv][col] == 0.0) return -1;
+        if (piv != col) for (int k = 0; k < 8; ++k) std::swap(a[piv][k], a[col][k]);
+        const double d = a[col][col];
+        for (int k = 0; k < 8; ++k) a[col][k] /= d;
+        for (int r = 0; r < 4; ++r) {
+            if (r == col) continue;
+            const double f = a[r][col];
+            if (f != 0.0) for (int k = 0; k < 8; ++k) a[r][k] -= f * a[col][k];
+        }
+    }
+    for (int r = 0; r < 4; ++r) for (int k = 0; k < 4; ++k) inv[4 * r + k] = a[r][4 + k];
     return 0;
 }
 
@@ -591,6 +681,11 @@ void orc_transform(const double* T, const float* in, float* out, size_t n)
     for (size_t i = 0; i < n; ++i) b[i] = xform(T, a[i]);
 }
 int orc_inverse4x4(const double* m, double* inv) { return inverse4x4(m, inv); }
+void orc_set_atan2f_perturbation(unsigned ppm, uint64_t seed) { g_atan_perturb_ppm = ppm; g_atan_perturb_seed = seed; }
+int orc_inverse4x4_variant(const double* m, double* inv, int variant)
+{
+    return variant == 1 ? inverse4x4_cofactor(m, inv) : variant == 2 ? inverse4x4_gauss_jordan(m, inv) : inverse4x4(m, inv);
+}
 
 void orc_range_image(const float* pts, size_t n, const double* T1, const double* T2, float vfov, float hfov,
                      int R, int C, float* rimg, int32_t* ptidx)

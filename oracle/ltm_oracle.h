@@ -35,10 +35,16 @@ void  orc_cart2sph(const float* xyz, float* az_el_r);
 void  orc_rimg_size(float vfov, float hfov, float alpha, int* rows, int* cols);
 void  orc_pixel(const float* xyz, float vfov, float hfov, int rows, int cols, int* row, int* col, float* range);
 
+/* sensitivity experiments only: move `ppm` per million of all atan2f results by +-1 ulp (hash-chosen); 0 = off (default) */
+void  orc_set_atan2f_perturbation(unsigned ppm, uint64_t seed);
+
 /* ---- transforms (utility.cpp:64-72,160-202; PCL transformPointCloud<double>) ---- */
 void orc_transform(const double* T, const float* in, float* out, size_t n);
-/* general 4x4 inverse in double (cofactor expansion); stands in for Eigen's Matrix4d::inverse(), Session.cpp:110 */
+/* Eigen::Matrix4d::inverse() of Session.cpp:110 / RosParamServer.cpp:30: general 4x4 inverse in double in the operation order of
+ * Eigen 3.3.7's SSE2 kernel (2x2 block adjugates; restated from knowledge, parity unpinned) */
 int  orc_inverse4x4(const double* m, double* inv);
+/* variant 0 = the above, 1 = cofactor expansion, 2 = Gauss-Jordan with partial pivoting (sensitivity test only) */
+int  orc_inverse4x4_variant(const double* m, double* inv, int variant);
 
 /* ---- range images (utility.cpp:92-142, Removerter.cpp:109-156) ----
  * T1/T2 may be NULL (no transform).  ptidx may be NULL (scan image). */

@@ -42,6 +42,7 @@ def lib():
         L.orc_voxel_grid.restype = _sz
         L.orc_pipeline_run.restype = _vp
         L.orc_inverse4x4.restype = _i
+        L.orc_inverse4x4_variant.restype = _i
         _lib = L
     return _lib
 
@@ -96,11 +97,23 @@ def transform(T, pts):
     return out
 
 
-def inverse4x4(m):
+def inverse4x4(m, variant=0):
+    """variant 0: Eigen 3.3.7 SSE2 operation order (the oracle's inverse); 1: cofactor expansion; 2: Gauss-Jordan (sensitivity test)"""
     a = _m(m, 1); out = np.empty_like(a)
-    rc = lib().orc_inverse4x4(_p(a), _p(out))
+    rc = lib().orc_inverse4x4_variant(_p(a), _p(out), C.c_int(int(variant)))
     assert rc == 0
     return out.reshape(4, 4)
+
+
+def set_atan2f_perturbation(ppm, seed=0):
+    """sensitivity experiments only: move `ppm` per million of the oracle's atan2f results by one ulp; 0 switches it off"""
+    lib().orc_set_atan2f_perturbation(C.c_uint(int(ppm)), C.c_uint64(int(seed)))
+
+
+def inverse_poses(poses, variant=0):
+    """(n, 16) row-major poses -> (n, 16) inverses, as Session::loadSessionInfo computes them (Session.cpp:109-110)"""
+    p = np.ascontiguousarray(poses, dtype=np.float64).reshape(-1, 16)
+    return np.array([inverse4x4(m, variant).reshape(16) for m in p]).reshape(-1, 16)
 
 
 def range_image(pts, vfov, hfov, rows, cols, T1=None, T2=None, want_idx=True):

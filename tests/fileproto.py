@@ -92,7 +92,7 @@ def yaml_text(root, dirs, outdir, start_idx, end_idx, res_list=(2.5,), voxel=0.0
 
 def host_load(orc, S, kfs, voxel=0.05, roundtrip_ascii=()):
     """Session::loadKeyframes + precleaningKeyframes on the selected keyframes: per-scan pcl::VoxelGrid (oracle restatement, A.6),
-    near-range pre-clean; inverse poses as numpy computes them (the reference: Eigen)"""
+    near-range pre-clean; inverse poses by the oracle's restatement of Eigen's Matrix4d::inverse() (the host uses the library's: same bits)"""
     pts, off = [], [0]
     for k in kfs:
         a, b = int(S["offsets"][k]), int(S["offsets"][k + 1])
@@ -102,7 +102,7 @@ def host_load(orc, S, kfs, voxel=0.05, roundtrip_ascii=()):
         p = orc.preclean(orc.voxel_grid(raw, voxel), 2.5)
         pts.append(p); off.append(off[-1] + len(p))
     poses = S["poses"].reshape(-1, 16)[kfs].copy()
-    inv = np.array([np.linalg.inv(p.reshape(4, 4)).reshape(16) for p in poses])
+    inv = orc.inverse_poses(poses)      # Session.cpp:109-110: the oracle's own Eigen restatement; the host uses the library's
     return dict(scans=np.concatenate(pts), offsets=np.array(off, np.uint64), poses=poses, inv=inv)
 
 
@@ -113,7 +113,7 @@ def query_keyframes_in_roi(central, c_kf, query, n_q):
     return [k for k in range(n_q) if np.sqrt(((c_pos - q_pos[k]) ** 2).sum(1)).min() <= 10.0]
 
 
-def compare_output_tree(outdir, ref, central_names, assert_clouds_equal, xyz_tol=1e-4):
+def compare_output_tree(outdir, ref, central_names, assert_clouds_equal, xyz_tol=0.0):
     """every map file and the five per-keyframe directories of `outdir` against an oracle PipelineResult"""
     for fname in MAP_FILES:
         want = ref.cloud(fname)

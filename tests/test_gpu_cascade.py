@@ -1,0 +1,113 @@
+"""Lifelong cascade (BASELINE configs[2]): the device-resident hand-over of lt-mapper_amd/cascade.py must be the
+reference's file hand-over -- `scans_updated/` written, re-loaded through Session::loadKeyframes (pcl::VoxelGrid,
+Session.cpp:284-289) and precleaningKeyframes(2.5) (Removerter.cpp:1658-1660) -- bit for bit.
+
+  * ltm_voxel_grid_scanset against the oracle's restatement of pcl::VoxelGrid (gridded, pass-through and empty keyframes);
+  * three sessions of the os1-64 sensor chained 01 -> 02 -> 03 twice: through files with `ltm_run` (C++ host: CPU VoxelGrid in
+    the loader, tools/cascade_yaml.py between the runs) and on the device with run_cascade (Python host, device VoxelGrid):
+    every map and every per-keyframe scan file of BOTH runs must be identical.
+The file cascade itself is compared with the oracle in test_gpu_cli.py; the small in-memory chain in test_gpu_pipeline.py."""
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT, assert_clouds_equal
+
+pytestmark = pytest.mark.gpu
+
+
+def test_voxel_grid_scanset_matches_pcl_voxelgrid_restatement(gpu_ctx, orc):
+    rng = np.random.default_rng(11)
+    kfs = []
+    kfs.append(np.c_[rng.uniform(-3, 3, (5000, 3)), rng.uniform(0, 255, 5000)])                    # dense, small extent: gridded at 0.05
+    kfs.append(np.c_[rng.uniform(-100, 100, (4000, 2)), rng.uniform(-2, 20, 4000), rng.uniform(0, 255, 4000)])   # 4000 x 4000 x 440 cells: int32 overflow, returned unchanged
+    kfs.append(np.zeros((0, 4)))                                                                    # empty keyframe
+    lattice = np.c_[rng.integers(-40, 40, (3000, 3)) * 0.05, rng.uniform(0, 1, 3000)]             # points exactly on leaf boundaries
+    lattice[:5, :3] = [[-0.0, 0.0, -0.0], [0.0, -0.0, 0.0], [-0.0, -0.0, -0.0], [0.05, -0.05, 0.0], [-0.05, 0.05, -0.0]]
+    kfs.append(lattice)
+    wide = np.c_[rng.uniform(-60, 60, (3000, 2)), rng.uniform(-1, 9, 3000), rng.uniform(0, 255, 3000)]
+    wide[:3, :3] = [[-0.0, 1.0, 2.0], [3.0, -0.0, 1.0], [5.0, 6.0, -0.0]]                           # signed zeros must survive the pass-through
+    kfs.append(wide)                                                                                # 2400 x 2400 x 200 = 1.15e9 cells: just below the limit -> gridded
+    kfs.append(np.c_[rng.uniform(-1, 1, (1, 3)), [7.0]])                                            # single point
+    kfs = [k.astype(np.float32) for k in kfs]
+    off = np.cumsum([0] + [len(k) for k in kfs]).astype(np.uint64)
+    for leaf in (0.05, 0.4):
+        got = gpu_ctx.voxel_grid_scanset(gpu_ctx.upload_scans(np.concatenate(kfs), off), leaf)
+        g_pts, g_off = got.download()
+        passthrough = 0
+        for k, pts in enumerate(kfs):
+            want = orc.voxel_grid(pts, leaf)
+            assert_clouds_equal(g_pts[int(g_off[k]):int(g_off[k + 1])], want, f"leaf {leaf} keyframe {k}")
+            passthrough += len(want) == len(pts) and len(pts) > 1
+        assert passthrough >= (1 if leaf == 0.05 else 0)
+
+
+def _roi(central_poses, query_poses):
+    """Session::parseKeyframesInROI (Session.cpp:230-263): query keyframes within 10 m of any central pose"""
+    c = central_poses.reshape(-1, 4, 4)[:, :3, 3]
+    q = query_poses.reshape(-1, 4, 4)[:, :3, 3]
+    return [k for k in range(len(q)) if np.sqrt(((c - q[k]) ** 2).sum(1)).min() <= 10.0]
+
+
+def test_device_cascade_equals_file_cascade_three_os1_64_sessions(tmp_path, ltm):
+    import torch
+    import fileproto as fp
+    from ltmapper_amd.cascade import run_cascade
+    from ltmapper_amd.removerter import HipOps, Params
+    from tools import synth
+    from tools.cascade_yaml import next_yaml
+    exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
+    assert os.path.exists(exe), "build the host mirror first (make host)"
+    n_kf = 90            # sessions start 37 m apart along the same loop: 01 and 03 come within 10 m of each other from keyframe ~64 on
+    dev = "cuda" if torch.cuda.is_available() else "cpu"
+    S = [synth.to_numpy(synth.make_session(s, n_kf, "os1-64", device=dev)) for s in (1, 2, 3)]
+    dirs = fp.write_session_dirs(tmp_path, S, tags=("01", "02", "03"))
+    out1, out2 = tmp_path / "out1", tmp_path / "out2"
+    y1 = tmp_path / "run1.yaml"
+    y1.write_text(fp.yaml_text(tmp_path, dirs, out1, 0, n_kf - 1))
+    r = subprocess.run([exe, str(y1)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    y2 = tmp_path / "run2.yaml"
+    y2.write_text(next_yaml(y1.read_text(), f"{dirs[2]}/", f"{tmp_path}/03/poses.txt", f"{out2}/"))
+    r = subprocess.run([exe, str(y2)], capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+
+    # ---- the same chain on the device: load like Session::loadKeyframes + precleaningKeyframes, hand over with run_cascade
+    ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    P = Params()
+
+    def load(T, kfs):
+        pts = [T["scans"][int(T["offsets"][k]):int(T["offsets"][k + 1])] for k in kfs]
+        off = np.cumsum([0] + [len(p) for p in pts]).astype(np.uint64)
+        scans = ctx.preclean(ctx.voxel_grid_scanset(ctx.upload_scans(np.concatenate(pts), off), P.downsample_voxel_size), 2.5)
+        return scans, ctx.poses(T["poses"].reshape(-1, 16)[kfs])       # inverse poses by the library, as the C++ host
+
+    c_kf = list(range(n_kf))
+    q2, q3 = _roi(S[0]["poses"], S[1]["poses"]), _roi(S[0]["poses"], S[2]["poses"])
+    assert len(q2) >= 20 and len(q3) >= 10, (len(q2), len(q3))
+    c_scans, c_poses = load(S[0], c_kf)
+    runs = run_cascade(HipOps(ctx), P, c_scans, c_poses, [load(S[1], q2), load(S[2], q3)])
+    names = [S[0]["names"][k] for k in c_kf]
+    gridded = 0
+    for rm, out in zip(runs, (out1, out2)):
+        for fname in fp.MAP_FILES:
+            got, path = rm.outputs.get(fname), os.path.join(str(out), fname + ".pcd")
+            if got is None or (fname == "strong_nd_map" and len(got) == 0):
+                assert not os.path.exists(path), f"{out.name}/{fname}: on disk but not on the device"
+                continue
+            assert_clouds_equal(got.download(), fp.read_pcd(path)[1], f"{out.name}/{fname}")
+        for d, ss in rm.scan_outputs().items():
+            g_pts, g_off = ss.download()
+            assert sorted(os.listdir(out / d)) == names
+            for j, nm in enumerate(names):
+                assert_clouds_equal(g_pts[int(g_off[j]):int(g_off[j + 1])], fp.read_pcd(str(out / d / nm))[1], f"{out.name}/{d}/{nm}")
+    # the hand-over really went through the grid for some keyframes (otherwise this test would not see a wrong VoxelGrid)
+    upd = runs[0].central_sess_.keyframe_scans_updated_
+    n_before = np.diff(upd.download()[1].astype(np.int64))
+    n_after = np.diff(ctx.voxel_grid_scanset(upd, P.downsample_voxel_size).download()[1].astype(np.int64))
+    gridded = int((n_after < n_before).sum())
+    print(f"cascade hand-over: {gridded} of {n_kf} scans_updated keyframes are thinned by the loader's VoxelGrid, {int((n_after == n_before).sum())} pass through")
+    assert len(runs[1].outputs["updated_map"]) > 100_000
+    ctx.close()

@@ -87,15 +87,15 @@ def test_ltm_run_file_protocol(tmp_path, orc, writer):
             p = orc.preclean(orc.voxel_grid(raw, 0.05), 2.5)   # pcl::VoxelGrid of the loader: oracle restatement (A.6)
             pts.append(p); off.append(off[-1] + len(p))
         poses = S["poses"].reshape(-1, 16)[kfs].copy()
-        # the pose file holds 12 numbers per line; the inverse is whatever the host computes (Gauss-Jordan here, Eigen in the reference)
-        inv = np.array([np.linalg.inv(p.reshape(4, 4)).reshape(16) for p in poses])
+        # the pose file holds 12 numbers per line; the inverse is computed by the host (ltm_inverse4x4) and by the oracle, each with its own restatement of Eigen's kernel
+        inv = orc.inverse_poses(poses)      # Session.cpp:109-110: the oracle's own Eigen restatement; the host uses the library's
         return dict(scans=np.concatenate(pts), offsets=np.array(off, np.uint64), poses=poses, inv=inv)
 
     C, Q = load(sess[0], c_kf), load(sess[1], q_kf)
     ref = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C, Q)
 
-    def close(a, b, what):   # inverse poses differ in the last bits between numpy and the host => XYZ tolerance of the north star
-        assert_clouds_equal(a, b, what, xyz_tol=1e-4)
+    def close(a, b, what):   # host (ltm_inverse4x4) and oracle (orc_inverse4x4) restate the same Eigen kernel: the file path is bitwise
+        assert_clouds_equal(a, b, what, xyz_tol=0.0)
 
     files = {"OriginalNoisyCentralMapGlobal": "OriginalNoisyCentralMapGlobal", "OriginalNoisyQueryMapGlobal": "OriginalNoisyQueryMapGlobal",
              "central_sess_high_dyn": "central_sess_high_dyn", "query_sess_high_dyn": "query_sess_high_dyn",
@@ -142,7 +142,7 @@ def test_ltm_run_file_protocol(tmp_path, orc, writer):
                        ("diff", orc.colormap(scan_r - map_r, 0.0, 0.5)), ("ptidx", orc.colormap(map_i, 0.0, float(len(cmap0))))):
         got = read_ppm(str(outdir / "viz" / f"000_000000_{name}.ppm"))
         bad = (got != want).any(axis=2).mean()
-        assert bad <= (0.0 if name == "scan" else 5e-3), f"viz {name}: {bad:.4%} of the pixels differ"   # inverse-pose last bits may move a few map pixels
+        assert bad == 0.0, f"viz {name}: {bad:.4%} of the pixels differ"
 
     # ---- the reference's fine-grained methods (calcDescrepancyAndParseDynamicPointIdxForEachScan, getStaticIdxFromDynamicIdx,
     # parsePointcloudSubsetUsingPtIdx, scan2RangeImg) kept as thin wrappers must reproduce the batch partition
@@ -172,7 +172,7 @@ def test_ltm_run_file_protocol(tmp_path, orc, writer):
         pts2.append(q); off2.append(off2[-1] + len(q))
     poses2 = sess[0]["poses"].reshape(-1, 16)[c_kf].copy()
     C2 = dict(scans=np.concatenate(pts2), offsets=np.array(off2, np.uint64), poses=poses2,
-              inv=np.array([np.linalg.inv(p.reshape(4, 4)).reshape(16) for p in poses2]))
+              inv=orc.inverse_poses(poses2))
     c2_pos = poses2.reshape(-1, 4, 4)[:, :3, 3]
     q3_pos = sess[1]["poses"].reshape(-1, 4, 4)[:, :3, 3]
     q3_kf = [k for k in range(n_kf) if np.sqrt(((c2_pos - q3_pos[k]) ** 2).sum(1)).min() <= 10.0]

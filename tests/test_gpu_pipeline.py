@@ -181,7 +181,8 @@ def test_sharded_ops_logical_ranks_sharing_the_gpu(orc, small_pair, world):
 
 
 def test_cascade_feeds_updated_scans_forward(ltm, orc):
-    """configs[2] in miniature: 01 -> (02, 03); run j+1 must see exactly the scans_updated of run j as its central session"""
+    """configs[2] in miniature: 01 -> (02, 03); run j+1 must see the scans_updated of run j as the reference's loader would re-read them:
+    pcl::VoxelGrid(downsample_voxel_size) per scan (Session.cpp:284-289), then precleaningKeyframes(2.5) (Removerter.cpp:1658-1660)"""
     from ltmapper_amd.cascade import run_cascade
     from ltmapper_amd.removerter import HipOps, Params
     from tools import synth
@@ -191,10 +192,15 @@ def test_cascade_feeds_updated_scans_forward(ltm, orc):
     c_scans, c_poses = up(S[0])
     runs = run_cascade(HipOps(ctx), Params(), c_scans, c_poses, [up(S[1]), up(S[2])])
     assert len(runs) == 2
-    # oracle: run 1, then run 2 with central := scans_updated of run 1 (same central poses)
+    # oracle: run 1, then run 2 with central := scans_updated of run 1 through VoxelGrid + pre-clean (same central poses)
     ref1 = orc.pipeline_run(orc.make_params(), S[0], S[1])
     upd_pts, upd_off = ref1.scanset("scans_updated")
-    C2 = dict(scans=upd_pts, offsets=upd_off, poses=S[0]["poses"], inv=S[0]["inv"])
+    re_pts, re_off = [], [0]
+    for k in range(len(upd_off) - 1):
+        p = orc.preclean(orc.voxel_grid(upd_pts[int(upd_off[k]):int(upd_off[k + 1])], 0.05), 2.5)
+        re_pts.append(p); re_off.append(re_off[-1] + len(p))
+    assert re_off[-1] < int(upd_off[-1]), "the re-load is expected to thin the scans (otherwise this test cannot see a missing VoxelGrid / pre-clean)"
+    C2 = dict(scans=np.concatenate(re_pts), offsets=np.array(re_off, np.uint64), poses=S[0]["poses"], inv=S[0]["inv"])
     ref2 = orc.pipeline_run(orc.make_params(), C2, S[2])
     _compare(runs[0], ref1)
     _compare(runs[1], ref2)

@@ -130,3 +130,34 @@ def test_bench_launches_itself_under_torchrun_for_several_gpus():
                        text=True, timeout=300, env=env)
     assert r.returncode != 0
     assert (r.stdout + r.stderr).count("AssertionError: bench.py needs a GPU") == 2, (r.stdout + r.stderr)[-1500:]
+
+
+def test_bench_roofline_helpers_on_a_synthetic_profile():
+    """bench.py's traffic grouping (PMC kernel names -> profile classes) and the parity-record check, without a GPU"""
+    import importlib
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, root)
+    bench = importlib.import_module("bench")
+    kib = 1024.0
+    pmc = {"all_kernels": {
+        "void ltm::k_vote_map_cull<true, true>": {"FETCH_SIZE": {"sum": 1000 * kib, "dispatches": 21}, "WRITE_SIZE": {"sum": 100 * kib, "dispatches": 21}},
+        "rocprim::radix_sort_onesweep<u64>": {"FETCH_SIZE": {"sum": 300 * kib, "dispatches": 64}, "WRITE_SIZE": {"sum": 300 * kib, "dispatches": 64}},
+        "ltm::k_voxel_centroids_packed": {"FETCH_SIZE": {"sum": 100 * kib, "dispatches": 64}, "WRITE_SIZE": {"sum": 10 * kib, "dispatches": 64}},
+        "void ltm::k_knn_query_scans<true, 2>": {"FETCH_SIZE": {"sum": 50 * kib, "dispatches": 5}, "WRITE_SIZE": {"sum": 5 * kib, "dispatches": 5}},
+        "ltm::k_compare_flag": {"FETCH_SIZE": {"sum": 7 * kib, "dispatches": 24}, "WRITE_SIZE": {"sum": 1 * kib, "dispatches": 24}},
+        "ltm::k_selfcheck": {"FETCH_SIZE": {"sum": 1e9, "dispatches": 1}, "WRITE_SIZE": {"sum": 0, "dispatches": 1}}}}
+    prof = {"vote_map_cull": dict(ms=70.0, launches=21, units=1e9, bytes=2.0 * 1024 * 1024 * 1024), "voxel": dict(ms=20.0, launches=30, units=1e8, bytes=1e9),
+            "knn_query": dict(ms=10.0, launches=5, units=1e8, bytes=1e8), "vote_compare": dict(ms=2.0, launches=24, units=1e8, bytes=1e7)}
+    groups = {g["group"]: g for g in bench.traffic_groups(pmc, prof, steps=1)}
+    g = groups["vote_map_cull"]
+    assert g["traffic_bytes_per_step"] == (2 * 1000 + 100) * kib * 1024 and g["kernels_matched"] == 1
+    assert abs(g["traffic_over_algorithmic"] - (2100 * kib * 1024) / (2.0 * 1024 ** 3)) < 1e-3
+    sort = next(v for k, v in groups.items() if k.startswith("sort_based"))
+    assert sort["kernels_matched"] == 2 and sort["traffic_bytes_per_step"] == (2 * 400 + 310) * kib * 1024
+    rest = next(v for k, v in groups.items() if k.startswith("streaming rest"))
+    assert rest["kernels_matched"] == 1, "the create-time self-check is not part of a step"
+    assert bench.traffic_groups({}, prof, 1) == []
+    st = bench.parity_fullsize_status()
+    assert set(st) >= {"record", "matches_sources"}

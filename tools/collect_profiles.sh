@@ -39,8 +39,16 @@ agg = collections.defaultdict(lambda: collections.defaultdict(lambda: {"sum": 0.
 for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
     for f in glob.glob(f"/tmp/prof_{c}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            k = r["Kernel_Name"].split("(")[0]
-            if "ltm::" not in k or r["Counter_Name"] != c: continue
+            k = r["Kernel_Name"]
+            # every kernel of the step is kept, rocPRIM's included (the sort passes had no traffic evidence); the synthetic
+            # generator's torch kernels (at::native, torch's own rocprim build 400001) run outside the timed region
+            if r["Counter_Name"] != c or "at::native" in k or "ROCPRIM_400001" in k or "rocclr" in k or "Cijk_" in k: continue
+            if "rocprim" in k:       # template soup: keep the algorithm and the key/value types
+                algo = next((a for a in ("radix_sort_onesweep", "radix_sort_histogram", "radix_sort", "merge_sort_block_merge", "merge_sort_block_sort", "merge_sort",
+                                         "lookback_scan_state", "scan", "transform", "partition", "select") if a in k), "other")
+                k = "rocprim::" + algo + ("<u64,u32>" if "unsigned long, unsigned int" in k else "<u64>" if "unsigned long" in k else "")
+            else:
+                k = k.split("(")[0]
             e = agg[k][c]; e["sum"] += float(r["Counter_Value"]); e["dispatches"] += 1
 dom = next((k for k in agg if "k_vote_map_cull" in k), None)
 out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU, one pass each, on `python bench.py --steps 1 --warmup 0 --no-cpu-baseline`; "
@@ -66,6 +74,13 @@ cp "$OUT/pmc_latest.json" "$OUT/${TAG}_pmc.json"
 #    `traffic` and the VALU figures of THIS kernel source (bench.py checks the hash inside pmc_latest.json)
 cp "$OUT/pmc_latest.json" "$ROOT/profiles/pmc_latest.json"
 $BENCH --cpu-allcore 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_default.json"
+python3 - "$OUT/${TAG}_bench_default.json" "$OUT/cpu_allcore_latest.json" <<'PY'
+import json, sys
+d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+a = (d.get("cpu_baseline") or {}).get("all_cores")
+if a and a.get("value"):
+    json.dump(a, open(sys.argv[2], "w"), indent=1)
+PY
 
 # 4. SQ issue / wait counters of the heaviest kernels, and the VALU issue-rate micro-benchmark (make ubench)
 (cd "$ROOT" && bash tools/pmc_sq.sh) > "$OUT/${TAG}_pmc_sq.txt" 2>&1

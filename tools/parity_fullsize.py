@@ -1,12 +1,18 @@
 #!/usr/bin/env python3
-"""Full-size parity of BASELINE configs[1]: the GPU pipeline (through the C ABI) against the CPU oracle on the SAME 2 x 500
-keyframe session pair, 3-res selfRemovert -- every map and every per-keyframe scan set compared bitwise.
+"""Full-size parity of the BASELINE configurations: the GPU pipeline (through the C ABI) against the CPU oracle on the SAME
+session pair at the configuration's REAL sensor size -- every map and every per-keyframe scan set compared bitwise.
 
-    python tools/parity_fullsize.py [--kf 500] [--threads N] > profiles/<name>.json
+    python tools/parity_fullsize.py --config 1 [--kf 500] [--threads N] > profiles/<name>.json
 
-The oracle needs ~49 min single-threaded for this workload, far beyond a test; with the GPU box's 256 host cores (OpenMP over
-keyframes, same serial arg-min semantics per keyframe; the label union is order-free) it takes about three minutes.  TEST
-INFRASTRUCTURE: the oracle is the checker here, never the thing measured."""
+  --config 1   configs[1]: lot, os1-64 (64 x 1024), 2 x 500 keyframes, 3-res selfRemovert          (~200 s of oracle on 256 cores)
+  --config 3   configs[3]: street, hdl-64e (64 x 1900), 2 x 200 keyframes, single-res, whole pipeline
+  --config 4   configs[4]: street, mls-128x8192 (1 M rays), 2 x 20 keyframes at 2 m, voxel 0.1, k = 2, thr 0.04
+
+The oracle needs ~49 min single-threaded for configs[1], far beyond a test; with the GPU box's 256 host cores (OpenMP over
+keyframes, same serial arg-min semantics per keyframe; the label union is order-free) it takes about three minutes --
+tests/test_gpu_fullsize_parity.py runs it on every box with >= 64 cores.  The record is stamped with hashes of the product and
+oracle sources so that bench.py can say whether it belongs to the kernels it measures.  TEST INFRASTRUCTURE: the oracle is the
+checker here, never the thing measured."""
 import argparse
 import json
 import os
@@ -17,30 +23,37 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
+CONFIGS = {
+    # name: (scene, sensor, default keyframes, spacing, 3-res, voxel, k, thr)
+    1: ("lot", "os1-64", 500, 1.0, True, 0.05, 2, 0.01),
+    3: ("street", "hdl-64e", 200, 1.0, False, 0.05, 2, 0.01),
+    4: ("street", "mls", 20, 2.0, False, 0.1, 2, 0.04),
+}
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--kf", type=int, default=500)
-    ap.add_argument("--threads", type=int, default=os.cpu_count() or 1)
-    ap.add_argument("--sensor", default="os1-64")
-    args = ap.parse_args()
+
+def run_parity(config=1, kf=None, threads=None, device="cuda:0"):
+    """returns the report dict; report["outputs_differing"] == 0 means bitwise parity of all outputs"""
     import numpy as np
     import torch
     import ltmapper_amd  # noqa: F401
     from ltmapper_amd import capi
     from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
     from oracle import oracle_py as orc
-    from tools import synth
-    from test_gpu_pipeline import MAPS, SCANS
-    res = (2.5, 2.0, 1.5)
-    sess_t = [synth.make_session(s, args.kf, args.sensor, device="cuda:0") for s in (1, 2)]
+    from tools import provenance, synth
+    from test_gpu_pipeline import MAPS
+    scene, sensor, kf_default, spacing, three_res, voxel, k, thr = CONFIGS[config]
+    kf = kf or kf_default
+    threads = threads or (os.cpu_count() or 1)
+    res = (2.5, 2.0, 1.5) if three_res else (2.5,)
+    sess_t = [synth.make_session(s, kf, sensor, device=device, scene=scene, kf_spacing=spacing) for s in (1, 2)]
     torch.cuda.synchronize()
     ctx = capi.Context(vfov=50.0, hfov=360.0, device=0)
     loaded = []
     for S in sess_t:
         scans = ctx.preclean(ctx.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64)), 2.5)
         loaded.append((scans, ctx.poses(S["poses"], S["inv"])))
-    P = Params(gpu_use_self_removert=True, remove_resolution_list=list(res))
+    P = Params(gpu_use_self_removert=three_res, remove_resolution_list=list(res), num_nn_points_within=k, dist_nn_points_within=thr,
+               downsample_voxel_size=voxel)
     t0 = time.perf_counter()
     rm = Removerter(HipOps(ctx), P, Session("Central", *loaded[0]), Session("Query", *loaded[1]))
     rm.run()
@@ -52,7 +65,7 @@ def main():
         pts, off = scans.download()
         cpu.append(dict(scans=pts, offsets=off, poses=S["poses"], inv=S["inv"]))
     t0 = time.perf_counter()
-    ref = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01, use_self_removert=True, res_list=res, threads=args.threads), cpu[0], cpu[1])
+    ref = orc.pipeline_run(orc.make_params(k=k, knn_thr=thr, voxel=voxel, use_self_removert=three_res, res_list=res, threads=threads), cpu[0], cpu[1])
     t_cpu = time.perf_counter() - t0
     report, bad = {}, 0
     for name in MAPS:
@@ -71,10 +84,29 @@ def main():
         ok = bool((g_off == w_off).all()) and g_pts.shape == w_pts.shape and bool((g_pts.view(np.uint32) == w_pts.view(np.uint32)).all())
         report[name] = {"points": int(len(w_pts)), "keyframes": int(len(w_off) - 1), "identical": ok}
         bad += 0 if ok else 1
-    print(json.dumps({"what": "GPU (C ABI) vs CPU oracle, every output of Removerter::run() compared bitwise", "workload": f"lot 2x{args.kf} {args.sensor} 3-res",
-                      "scan_points": [int(c["offsets"][-1]) for c in cpu], "gpu_run_s": round(t_gpu, 3), "oracle_run_s": round(t_cpu, 1),
-                      "oracle_threads": args.threads, "outputs_compared": len(report), "outputs_differing": bad, "outputs": report}, indent=1))
-    sys.exit(1 if bad else 0)
+    ref.free()
+    ctx.close()
+    try:
+        commit = open(os.path.join(ROOT, ".commit_for_profiles")).read().strip()
+    except OSError:
+        commit = None
+    return {"what": "GPU (C ABI) vs CPU oracle, every output of Removerter::run() compared bitwise",
+            "config": f"BASELINE configs[{config}]", "workload": f"{scene} 2x{kf} {sensor} {'3-res' if three_res else 'single-res'} voxel {voxel} k {k} thr {thr}",
+            "scan_points": [int(c["offsets"][-1]) for c in cpu], "gpu_run_s": round(t_gpu, 3), "oracle_run_s": round(t_cpu, 1),
+            "oracle_threads": threads, "outputs_compared": len(report), "outputs_differing": bad,
+            "product_sha": provenance.product_sha(), "kernels_sha": provenance.kernels_sha(), "oracle_sha": provenance.oracle_sha(), "commit": commit,
+            "outputs": report}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
+    ap.add_argument("--kf", type=int, default=None)
+    ap.add_argument("--threads", type=int, default=None)
+    args = ap.parse_args()
+    rep = run_parity(args.config, args.kf, args.threads)
+    print(json.dumps(rep, indent=1))
+    sys.exit(1 if rep["outputs_differing"] else 0)
 
 
 if __name__ == "__main__":
