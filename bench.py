@@ -68,7 +68,8 @@ CLASS_KERNELS = {
     "vote_scan": "k_scan_rimg + k_image_max", "vote_compare": "k_compare_flag", "vote_fill": "k_fill_u64",
     "partition": "rocprim scan + k_partition_scatter", "voxel": "bbox + Morton keys + rocprim radix sort + k_voxel_centroids",
     "voxel_scanset": "per-keyframe bbox + composite keys + rocprim radix sort + k_voxel_centroids",
-    "knn_build": "k_cell_keys + rocprim radix sort + k_hash_build", "knn_query": "k_knn_query_scans / k_knn_query_cloud",
+    "knn_build": "k_cell_keys + rocprim radix sort + k_hash_build + k_knn_bucket_build + k_knn_bitmap_build",
+    "knn_query": "k_knn_fast (phase 1: 64-byte cell buckets + occupancy bitmap) / k_knn_query_cloud", "knn_query_p2": "rocprim scan + k_knn_queue_scatter + k_knn_slow (phase 2: exact search of the undecided queries)",
     "reproject_gather": "rocprim scan + k_reproject_gather", "merge": "k_transform_scans",
 }
 
@@ -145,11 +146,12 @@ def main():
         scans = ctx.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64))
         return ctx.preclean(scans, 2.5), ctx.poses(S["poses"], S["inv"])     # precleaningKeyframes(2.5), Removerter.cpp:1660
 
+    from ltmapper_amd.dist import CommMeter, ShardedOps, scaling_model
+    meter = None
     if world > 1:
-        from ltmapper_amd.dist import ShardedOps
         ops = ShardedOps(HipOps(ctx), dist, rank, world)
     else:
-        ops = HipOps(ctx)
+        ops = meter = CommMeter(HipOps(ctx))      # single GPU: note what the sharded pipeline would exchange (a few dictionary updates per stage)
 
     loaded = [load(S) for S in sess_t]   # loading + pre-clean are Step 0 plumbing, outside the timed region
 
@@ -175,6 +177,8 @@ def main():
     barrier()
     ctx.profile_reset()
     ctx.profile_enable(True)
+    if meter:
+        meter.reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = one_step()
@@ -271,6 +275,8 @@ def main():
                        "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
             "t_total": t_total, "parity_fullsize": parity_fullsize_status(),
+            "scaling_model": scaling_model({k: v["ms"] / args.steps for k, v in prof.items()}, ms_per_step,
+                                           {k: (v[0] / args.steps, v[1] / args.steps) for k, v in meter.events.items()}) if meter else None,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
@@ -292,7 +298,7 @@ def kernels_sha():
 TRAFFIC_GROUPS = [
     ("vote_map_cull", ["k_vote_map_cull"], ["vote_map_cull"]),
     ("map_rimg_blockmin", ["k_map_rimg_blockmin", "k_map_rimg_lds"], ["reproject_map", "vote_map_exact"]),
-    ("knn_query", ["k_knn_query", "k_knn_bin", "k_knn_cell"], ["knn_query"]),
+    ("knn_query", ["k_knn_query", "k_knn_fast", "k_knn_slow", "k_knn_queue"], ["knn_query", "knn_query_p2"]),
     ("sort_based (voxel grids, kNN grid build)", ["radix_sort", "merge_sort", "k_voxel", "k_morton", "k_head_flags", "k_segment_starts", "k_bbox", "k_scan_total",
                                                   "k_cell_keys", "k_hash_build", "k_gather_points", "k_gather_u64", "k_compact", "k_key_"], ["voxel", "voxel_scanset", "voxel_grid_scanset", "knn_build"]),
     ("streaming rest (scan images, compare, fills, scans + scatters, merges)", [""], ["vote_scan", "vote_compare", "vote_fill", "partition", "reproject_gather", "merge"]),

@@ -255,6 +255,11 @@ int ltm_debug_selfcheck(ltm_ctx*, uint64_t* mismatches3, int* fast_math_enabled)
  * *max_err_rad = largest error of its binary32 evaluation.  Returns 1 if the kernels use it for this field of view (vfov/2 + 2 deg
  * <= 45 deg and error <= 1e-6 rad), 0 if they keep the generic polynomial on [0, 1], < 0 on invalid arguments. */
 int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad);
+/* the voxel grid's sort key (host arithmetic only, needs no device): for a cloud with bounding box [mn, mx] and leaf size `leaf`, the
+ * octree frame (depth, lattice origin) and the mask of the interleaved Morton-code bits (x = bit 3L+2, y = 3L+1, z = 3L of level L)
+ * that the radix sort looks at -- the others are functions of more significant bits for every key inside the box and are left out
+ * (fewer passes; order and equality of codes are unchanged).  Returns the number of kept bits, or < 0. */
+int ltm_debug_voxel_key_bits(const float* mn3, const float* mx3, float leaf, uint64_t* kept_mask, unsigned* depth, double* frame_min3);
 /* checks the bounded-error projection that the range-culled vote kernel uses to decide which points need the exact
  * arithmetic: counts points (host xyz, n*3 floats; global frame if inv_pose16 is given, else local) whose exact pixel /
  * range fall outside its candidate set / bounds.  Must be 0. */

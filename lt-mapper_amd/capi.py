@@ -99,6 +99,7 @@ SIGNATURES = {
     "ltm_debug_viz_images": (_i, [_vp, _u64, _u64, _u64, _sz, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ltm_debug_project": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
     "ltm_debug_elevation_fit": (_i, [_f, C.POINTER(_f), C.POINTER(C.c_double)]),
+    "ltm_debug_voxel_key_bits": (_i, [C.POINTER(_f), C.POINTER(_f), _f, _pu64, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
     "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),
     "ltm_debug_cull_stats": (_i, [_vp, _pu64, _pu64, _i]),
@@ -127,6 +128,16 @@ def load_library(path=None):
     if path is None:
         _lib = lib
     return lib
+
+
+def voxel_key_bits(mn, mx, leaf):
+    """ltm_debug_voxel_key_bits: (kept bit count, kept mask, octree depth, lattice origin) of the voxel grid's sort key"""
+    a = (_f * 3)(*[float(v) for v in mn]); b = (_f * 3)(*[float(v) for v in mx])
+    mask, depth, fmin = _u64(), C.c_uint(), (C.c_double * 3)()
+    n = load_library().ltm_debug_voxel_key_bits(a, b, float(leaf), C.byref(mask), C.byref(depth), fmin)
+    if n < 0:
+        raise ValueError("unsupported box / leaf")
+    return n, mask.value, depth.value, np.array(list(fmin))
 
 
 def inverse4x4(m):

@@ -74,8 +74,11 @@ struct Pool {
         void* p = nullptr;
         const auto t0 = std::chrono::steady_clock::now();
         hipError_t e = hipMalloc(&p, want);
-        malloc_s += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        const double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        malloc_s += dt;
         ++n_malloc;
+        static const bool trace = getenv("LTM_POOL_TRACE") != nullptr;
+        if (trace) fprintf(stderr, "[ltm] pool: hipMalloc #%zu of %.1f MB took %.2f ms (held %.1f MB)\n", n_malloc, want / 1048576.0, 1e3 * dt, bytes_total / 1048576.0);
         if (e != hipSuccess) {
             release_cached();
             e = hipMalloc(&p, want);
@@ -184,6 +187,15 @@ struct ltm_ctx {
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
     int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
+    int occlusion_cull = 1;                     // LTM_OCCLUSION=0: the exact-image kernel runs every (tile, keyframe) pair (A/B switch)
+    size_t occlusion_min_pairs = (size_t)1 << 21;   // LTM_OCCLUSION_MIN_PAIRS: smaller launches are not worth the two extra passes (2 M pairs = 4096 tiles x 512 keyframes)
+    float occlusion_r_near = 60.0f;             // LTM_OCCLUSION_RNEAR [m]: tiles nearer than this are projected first and serve as occluders
+    uint64_t occl_pairs = 0, occl_near = 0, occl_far_live = 0;      // statistics (LTM_OCCLUSION_STATS): pairs seen, in the first shell, projected in all
+    void* occl_scratch = nullptr; size_t occl_scratch_bytes = 0;
+    int voxel_key_compress = 1;                 // LTM_VOXEL_KEYBITS=0: sort over all 3*depth Morton bits (A/B switch)
+    int knn_two_phase = 1;                      // LTM_KNN_FAST=0: the one-kernel exact search for every query (A/B switch)
+    int knn_stats_on = 0;                       // LTM_KNN_STATS=1: count the queries phase 1 leaves undecided (one host round trip per call)
+    uint64_t knn_undecided = 0, knn_queries = 0;
     float cull_eps_scale = 0.0f;                // LTM_CULL_EPS_SCALE: pixels of distrust per (pixel per degree); 0 = the validated default of geom_for
     float cull_eps_floor = 1.0e-3f;             // LTM_CULL_EPS_FLOOR: the band is never narrower than this [pixels]
     int el_fit = 0;                             // fitted elevation polynomial usable (vfov/2 + 2 deg <= 45 deg and error <= 1e-6 rad)
@@ -627,6 +639,58 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
     return buf;
 }
 
+// Exact arg-min images of keyframes [kb, kb + nb) (reprojection, ND votes, RViz images): on a large map behind an occlusion cull
+// (ltm_kernels.hip: near pairs first, a coarse maximum of the partial image, far pairs that nearer returns cover completely are dropped).
+// The image is bit-identical to the plain launch; below `occlusion_min_pairs` (tile, keyframe) pairs the plain launch is used.
+void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, size_t nb, const Geom& g, uint64_t* img)
+{
+    if (!map.n || !nb) return;
+    const size_t n_tiles = (map.n + 4095) / 4096, n_pairs = n_tiles * nb;
+    const bool occl = c->occlusion_cull && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
+    if (!occl) {
+        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream));
+        return;
+    }
+    const size_t rbs = ((size_t)g.rows + 7) / 8, cbs = ((size_t)g.cols + 7) / 8;
+    // scratch of the cull lives with the context (grown on demand): the stage runs dozens of times per step with the same sizes, and
+    // taking it from the pool every time changes which blocks the stages around it find there
+    const size_t tbytes = scan_temp_bytes(n_pairs);
+    const size_t need = n_tiles * 24 + n_pairs * (1 + 1 + 4 + 4) + 64 + nb * rbs * cbs * 4 + tbytes + 8 * 256;
+    if (c->occl_scratch_bytes < need) {
+        if (c->occl_scratch) { sync(c); c->pool.free(c->occl_scratch); }
+        c->occl_scratch = c->pool.alloc(need + need / 4);
+        c->occl_scratch_bytes = need + need / 4;
+    }
+    char* base = static_cast<char*>(c->occl_scratch);
+    auto carve = [&](size_t bytes) { char* p = base; base += (bytes + 255) & ~(size_t)255; return p; };
+    float* tb = reinterpret_cast<float*>(carve(n_tiles * 24));
+    uint8_t* done = reinterpret_cast<uint8_t*>(carve(n_pairs));
+    uint8_t* flags = reinterpret_cast<uint8_t*>(carve(n_pairs));
+    uint32_t* pos = reinterpret_cast<uint32_t*>(carve(n_pairs * 4));
+    uint32_t* list = reinterpret_cast<uint32_t*>(carve(n_pairs * 4));
+    uint32_t* count = reinterpret_cast<uint32_t*>(carve(64));
+    uint32_t* cmax = reinterpret_cast<uint32_t*>(carve(nb * rbs * cbs * 4));
+    void* temp = carve(tbytes);
+    LTM_HIP(tile_bounds(map.d, map.n, tb, c->stream));
+    LTM_HIP(hipMemsetAsync(done, 0, n_pairs, c->stream));
+    float r_lo = 0.0f, r_hi = c->occlusion_r_near;
+    size_t n_done = 0, n_proj = 0;
+    for (int shell = 0; shell < 12; ++shell) {
+        const bool last = shell == 11 || r_hi > 1.0e4f;
+        if (last) r_hi = 3.0e38f;
+        LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream));
+        uint32_t n_live = 0;
+        d2h(c, &n_live, count, 4);
+        LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, c->stream));
+        n_proj += n_live;
+        if (shell == 0) c->occl_near += n_live;
+        if (last) break;
+        r_lo = r_hi; r_hi *= 2.0f;
+    }
+    (void)n_done;
+    c->occl_pairs += n_pairs; c->occl_far_live += n_proj;
+}
+
 void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss, const Poses& ps, size_t kf_begin, size_t kf_end, float alpha, float thr,
              int mode, uint8_t* labels_dev)
 {
@@ -668,8 +732,10 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
                 pts = 0.0; bytes = 0.0;      // added by prof_collect
             }
             ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, bytes);
-            LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, cull ? qbound : nullptr,
-                                          mode == 0 ? tb.as<float>() : nullptr, smax, thr, mode, map_img.as<uint64_t>(), c->stream));
+            if (cull) {
+                LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, qbound, tb.as<float>(), smax, thr, mode,
+                                              map_img.as<uint64_t>(), c->stream));
+            } else exact_map_images(c, map, ps, kb, nb, g, map_img.as<uint64_t>());
         }
         {
             ProfScope p(c, "vote_compare", (double)(nb * npx), (double)(nb * npx) * 12 + (double)nb * map.n / 8.0);
@@ -725,6 +791,50 @@ bool octree_frame_from_bbox(const float mn[3], const float mx[3], float leaf, Oc
     return true;
 }
 
+// Which bits of the Morton code can the cloud's points tell apart?  (KeyCompress, ltm_kernels.h.)  Per axis the keys lie in
+// [klo, khi] = the keys of the bounding box's corners (the key is monotone in the coordinate).  Bit L of an axis is a function of that
+// axis' higher bits -- and therefore of more significant bits of the interleaved code -- iff the keys' prefixes k >> (L + 1) take at most
+// two (consecutive) values and, within each, bit L is constant: one prefix: klo >> L == khi >> L; two: bit L of klo is 1 (the low
+// prefix's keys run from klo to the end of its block: all in the upper half) and bit L of khi is 0.  Dropping such bits keeps both the
+// order and the equality of codes, so the sorted sequence and the voxel boundaries are those of the full code.
+KeyCompress key_compress_for(const float mn[3], const float mx[3], const OctreeFrame& f, bool enable)
+{
+    const unsigned depth = f.depth;
+    uint64_t kept = 0;
+    const double lo3[3] = {f.minx, f.miny, f.minz};
+    for (int a = 0; a < 3; ++a) {
+        const uint32_t klo = (uint32_t)(((double)mn[a] - lo3[a]) / f.res), khi = (uint32_t)(((double)mx[a] - lo3[a]) / f.res);
+        for (unsigned L = 0; L < depth; ++L) {
+            bool drop = false;
+            if (enable && klo <= khi) {
+                const uint64_t pl = (uint64_t)klo >> (L + 1), ph = (uint64_t)khi >> (L + 1);
+                if (pl == ph) drop = (klo >> L) == (khi >> L);
+                else if (ph == pl + 1) drop = ((klo >> L) & 1u) == 1u && ((khi >> L) & 1u) == 0u;
+            }
+            if (!drop) kept |= 1ull << (3 * L + (2 - a));        // x is the most significant bit of a level triple
+        }
+    }
+    KeyCompress kc{};
+    unsigned out = 0;
+    for (unsigned b = 0; b < 3 * depth;) {
+        if (!((kept >> b) & 1ull)) { ++b; continue; }
+        unsigned e = b;
+        while (e < 3 * depth && ((kept >> e) & 1ull)) ++e;
+        if (kc.n_runs == kMaxKeyRuns) {          // cannot happen with <= 63 bits and runs separated by dropped bits of 3 axes, but stay safe: no compression
+            KeyCompress id{};
+            id.n_runs = 1; id.bits = 3 * depth; id.src[0] = 0; id.dst[0] = 0; id.mask[0] = (3 * depth >= 64) ? ~0ull : ((1ull << (3 * depth)) - 1);
+            return id;
+        }
+        kc.src[kc.n_runs] = (unsigned char)b; kc.dst[kc.n_runs] = (unsigned char)out; kc.mask[kc.n_runs] = ((e - b) >= 64) ? ~0ull : ((1ull << (e - b)) - 1);
+        ++kc.n_runs;
+        out += e - b;
+        b = e;
+    }
+    kc.bits = std::max(out, 1u);
+    if (kc.n_runs == 0) { kc.n_runs = 1; kc.src[0] = 0; kc.dst[0] = 0; kc.mask[0] = 0; }      // a single voxel: every code equal
+    return kc;
+}
+
 void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3])
 {
     DevBuf bb(c, 6 * sizeof(uint32_t));
@@ -753,14 +863,15 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
     bbox_of(c, pts, n_in, mn, mx);
     OctreeFrame f;
     if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
-    const unsigned mbits = 3 * f.depth;
     unsigned ib = 1;
     while (ib < 32 && ((size_t)1 << ib) < n_in) ++ib;
-    const bool packed = c->voxel_packed_sort && mbits + ib <= 64;
+    const bool packed = c->voxel_packed_sort && 3 * f.depth + ib <= 64;
+    const KeyCompress kc = key_compress_for(mn, mx, f, packed && c->voxel_key_compress);
+    const unsigned mbits = packed ? kc.bits : 3 * f.depth;        // code bits the sort has to look at
     const unsigned kshift = packed ? ib : 0;                       // Morton code = key >> kshift
     size_t n = n_in;
     DevBuf keys(c, n * 8), idx(c, packed ? 8 : n * 4);
-    if (packed) LTM_HIP(morton_keys_packed(pts, n, f, ib, keys.as<uint64_t>(), c->stream));
+    if (packed) LTM_HIP(morton_keys_packed(pts, n, f, kc, ib, keys.as<uint64_t>(), c->stream));
     else LTM_HIP(morton_keys(pts, n, f, keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
     if (n_shards > 1) {
         const unsigned shift = mbits > 12 ? mbits - 12 : 0;
@@ -869,15 +980,16 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
         float mn[3], mx[3];
         for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]); }
         if (!octree_frame_from_bbox(mn, mx, j.leaf, &j.f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
-        j.mbits = 3 * j.f.depth;
         while (j.ib < 32 && ((size_t)1 << j.ib) < j.n) ++j.ib;
-        j.packed = c->voxel_packed_sort && j.mbits + j.ib <= 64;
+        j.packed = c->voxel_packed_sort && 3 * j.f.depth + j.ib <= 64;
+        const KeyCompress kc = key_compress_for(mn, mx, j.f, j.packed && c->voxel_key_compress);
+        j.mbits = j.packed ? kc.bits : 3 * j.f.depth;
         j.kshift = j.packed ? j.ib : 0;
         const size_t n = j.n;
         j.keys.reset(new DevBuf(c, n * 8)); j.idx.reset(new DevBuf(c, j.packed ? 8 : n * 4));
         j.keys2.reset(new DevBuf(c, n * 8)); j.idx2.reset(new DevBuf(c, j.packed ? 8 : n * 4));
         if (j.packed) {
-            LTM_HIP(morton_keys_packed(j.pts, n, j.f, j.ib, j.keys->as<uint64_t>(), c->stream));
+            LTM_HIP(morton_keys_packed(j.pts, n, j.f, kc, j.ib, j.keys->as<uint64_t>(), c->stream));
             const size_t stb = sort_keys_temp_bytes(n);
             DevBuf stemp(c, stb);
             LTM_HIP(sort_keys_u64(j.keys->as<uint64_t>(), j.keys2->as<uint64_t>(), n, j.ib, j.ib + j.mbits, stemp.p, stb, c->stream));
@@ -899,8 +1011,8 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
     d2h(c, nv.data(), counts.p, nj * 4);
     if (getenv("LTM_VOXEL_LOG"))
         for (size_t k = 0; k < nj; ++k)
-            fprintf(stderr, "[ltm] voxel batch %zu/%zu: n %zu -> %u voxels, leaf %.3f, depth %u, index bits %u, packed %d\n", k, nj, jobs[k].n, nv[k], jobs[k].leaf,
-                    jobs[k].f.depth, jobs[k].ib, (int)jobs[k].packed);
+            fprintf(stderr, "[ltm] voxel batch %zu/%zu: n %zu -> %u voxels, leaf %.3f, depth %u, code bits sorted %u, index bits %u, packed %d\n", k, nj, jobs[k].n, nv[k],
+                    jobs[k].leaf, jobs[k].f.depth, jobs[k].mbits, jobs[k].ib, (int)jobs[k].packed);
     // phase C: centroids
     for (size_t k = 0; k < nj; ++k) {
         VoxelJob& j = jobs[k];
@@ -919,8 +1031,10 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
 struct KnnIndex {
     ltm_ctx* c;
     float4* sorted = nullptr; HashEntry* table = nullptr; uint32_t mask = 0; KnnGrid g{}; float cell2_lo = 0; size_t Mt = 0;
+    void* buckets = nullptr; uint32_t n_buckets = 0;      // phase-1 table of the two-phase query (k <= 4), see ltm_kernels.hip
+    uint32_t* bitmap = nullptr;                           // occupancy bitmap of the grid (phase 2 skips empty cells), may stay null
     explicit KnnIndex(ltm_ctx* c_) : c(c_) {}
-    ~KnnIndex() { c->pool.free(sorted); c->pool.free(table); }
+    ~KnnIndex() { c->pool.free(sorted); c->pool.free(table); c->pool.free(buckets); c->pool.free(bitmap); }
     void build(const Cloud& target, int k, float thr)
     {
         Mt = target.n;
@@ -968,6 +1082,19 @@ struct KnnIndex {
         table = reinterpret_cast<HashEntry*>(c->pool.alloc(tsize * sizeof(HashEntry)));
         LTM_HIP(fill_u64(reinterpret_cast<uint64_t*>(table), ~0ull, tsize * 2, c->stream));
         LTM_HIP(hash_build(keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, Mt, table, mask, c->stream));
+        if (k <= 4 && c->knn_two_phase) {
+            // 64-byte buckets at a load factor of ~0.55: with two candidate places ~97 % of the cells get one (the others are served by phase 2)
+            n_buckets = (uint32_t)std::min<size_t>(std::max<size_t>(1024, ncell + ncell * 4 / 5), 0x7fffffffu);
+            buckets = c->pool.alloc((size_t)n_buckets * 64);
+            LTM_HIP(hipMemsetAsync(buckets, 0xff, (size_t)n_buckets * 64, c->stream));
+            LTM_HIP(knn_bucket_build(sorted, keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, Mt, g, buckets, n_buckets, c->stream));
+            if (ncells <= 2147483648.0 && c->knn_two_phase != 2) {      // LTM_KNN_FAST=2: buckets only (A/B)
+                const size_t words = ((size_t)ncells + 31) / 32 + 1;
+                bitmap = reinterpret_cast<uint32_t*>(c->pool.alloc(words * 4));
+                LTM_HIP(hipMemsetAsync(bitmap, 0, words * 4, c->stream));
+                LTM_HIP(knn_bitmap_build(keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, g, bitmap, c->stream));
+            }
+        }
     }
 };
 
@@ -1121,6 +1248,12 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         c->fast_math = (c->selfcheck[0] == 0 && c->selfcheck[1] == 0 && c->selfcheck[2] == 0) ? 1 : 0;
         if (const char* v = getenv("LTM_FAST_MATH")) c->fast_math = c->fast_math && atoi(v);
         if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
+        if (const char* v = getenv("LTM_KNN_FAST")) c->knn_two_phase = atoi(v);
+        if (const char* v = getenv("LTM_VOXEL_KEYBITS")) c->voxel_key_compress = atoi(v);
+        if (const char* v = getenv("LTM_OCCLUSION")) c->occlusion_cull = atoi(v);
+        if (const char* v = getenv("LTM_OCCLUSION_MIN_PAIRS")) c->occlusion_min_pairs = (size_t)atoll(v);
+        if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) c->occlusion_r_near = (float)atof(v);
+        if (const char* v = getenv("LTM_KNN_STATS")) c->knn_stats_on = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
         c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
@@ -1144,6 +1277,13 @@ void ltm_destroy(ltm_ctx* c)
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     if (c->live_counts) (void)hipFree(c->live_counts);
+    if (getenv("LTM_OCCLUSION_STATS") && c->occl_pairs)
+        fprintf(stderr, "[ltm] occlusion cull of the exact-image kernel: %llu (tile, keyframe) pairs, %.2f %% in the first shell, %.2f %% projected in all, %.2f %% dropped\n",
+                (unsigned long long)c->occl_pairs, 100.0 * c->occl_near / c->occl_pairs, 100.0 * c->occl_far_live / c->occl_pairs,
+                100.0 * (c->occl_pairs - c->occl_far_live) / c->occl_pairs);
+    if (c->knn_stats_on && c->knn_queries)
+        fprintf(stderr, "[ltm] kNN two-phase: %llu of %llu scan queries left undecided by the bucket test (%.2f %%)\n", (unsigned long long)c->knn_undecided,
+                (unsigned long long)c->knn_queries, 100.0 * (double)c->knn_undecided / (double)c->knn_queries);
     if (getenv("LTM_POOL_STATS"))
         fprintf(stderr, "[ltm] device pool: %zu hipMalloc calls, %.1f MB held, %.1f ms inside hipMalloc; pinned host blocks: %zu, %.1f MB, %.1f ms inside hipHostMalloc\n",
                 c->pool.n_malloc, c->pool.bytes_total / 1048576.0, 1e3 * c->pool.malloc_s, c->pinned.size(), c->pinned_bytes / 1048576.0, 1e3 * c->pinned_s);
@@ -2027,7 +2167,7 @@ int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, siz
                 LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
                 {
                     ProfScope ps(c, "reproject_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
-                    LTM_HIP(map_range_images(map.d, map.n, p.inv_dev, p.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream));
+                    exact_map_images(c, map, p, kb, nb, g, img.as<uint64_t>());
                 }
                 ProfScope ps(c, "reproject_gather", (double)(nb * npx), (double)(nb * npx) * 12);
                 LTM_HIP(exclusive_scan_img_valid(img.as<uint64_t>(), pos.as<uint32_t>(), nb * npx, temp.p, tb, c->stream));
@@ -2069,10 +2209,30 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
         index.build(target, k, thr);
         const uint64_t first = s.off[kf_begin], n = s.off[kf_end] - first;
         DevBuf flag(c, std::max<size_t>(n, 1)), local(c, std::max<size_t>(n, 1) * 16);
-        {
+        uint64_t longest = 0;
+        for (size_t kk = kf_begin; kk < kf_end; ++kk) longest = std::max<uint64_t>(longest, s.off[kk + 1] - s.off[kk]);
+        if (index.buckets && n && n < 0xffffffffull) {
+            {
+                ProfScope ps(c, "knn_query", (double)n, (double)n * (16.0 + 16.0 * k + 1.0));
+                LTM_HIP(knn_two_phase_fast(s.d, s.off_dev, kf_begin, kf_end, first, n, longest, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.g, index.buckets,
+                                           index.n_buckets, k, thr, flag.as<uint8_t>(), local.as<float4>(), c->stream));
+            }
+            DevBuf pos(c, n * 4), queue(c, n * 4), count(c, 4);
+            const size_t tb = scan_temp_bytes(n);
+            DevBuf temp(c, tb);
+            {
+                ProfScope ps(c, "knn_query_p2", 0.0, 0.0);      // compaction + exact search of the undecided queries: its bytes are part of knn_query's algorithmic figure
+                LTM_HIP(knn_two_phase_exact(s.d, s.off_dev, kf_begin, kf_end, first, n, p.pose_dev, c->B2L, c->b2l_identity, index.sorted, index.Mt, index.g, index.table,
+                                            index.mask, index.bitmap, k, thr, index.cell2_lo, flag.as<uint8_t>(), pos.as<uint32_t>(), queue.as<uint32_t>(), count.as<uint32_t>(), temp.p, tb,
+                                            c->stream));
+            }
+            if (c->knn_stats_on) {
+                uint32_t und = 0;
+                d2h(c, &und, count.p, 4);
+                c->knn_undecided += und; c->knn_queries += n;
+            }
+        } else {
             ProfScope ps(c, "knn_query", (double)n, (double)n * (16.0 + 16.0 * k + 1.0));
-            uint64_t longest = 0;
-            for (size_t k = kf_begin; k < kf_end; ++k) longest = std::max<uint64_t>(longest, s.off[k + 1] - s.off[k]);
             LTM_HIP(knn_query_scans(s.d, s.off_dev, kf_begin, kf_end, first, n, longest, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.sorted,
                                     index.Mt, index.g, index.table, index.mask, k, thr, index.cell2_lo, flag.as<uint8_t>(), local.as<float4>(), c->stream));
         }
@@ -2236,6 +2396,20 @@ int ltm_debug_cull_stats(ltm_ctx* c, uint64_t* survivors, uint64_t* points, int 
         if (survivors) *survivors = v[0];
         if (points) *points = v[1];
     });
+}
+
+int ltm_debug_voxel_key_bits(const float* mn3, const float* mx3, float leaf, uint64_t* kept_mask, unsigned* depth, double* frame_min3)
+{
+    if (!mn3 || !mx3 || !kept_mask || !(leaf > 0.0f)) return LTM_E_INVALID;
+    OctreeFrame f;
+    if (!octree_frame_from_bbox(mn3, mx3, leaf, &f)) return LTM_E_UNSUPPORTED;
+    const KeyCompress kc = key_compress_for(mn3, mx3, f, true);
+    uint64_t m = 0;
+    for (int r = 0; r < kc.n_runs; ++r) m |= kc.mask[r] << kc.src[r];
+    *kept_mask = m;
+    if (depth) *depth = f.depth;
+    if (frame_min3) { frame_min3[0] = f.minx; frame_min3[1] = f.miny; frame_min3[2] = f.minz; }
+    return (int)kc.bits;
 }
 
 int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad)

@@ -46,6 +46,13 @@ void set_tile_cull(int v);
 // inv_poses_dev: 12 doubles per keyframe (3x4 row-major).  b2l: 12 doubles, b2l_identity skips the arithmetic.
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                             HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
+// occlusion cull of the exact-image kernel on large maps (see ltm_kernels.hip): pair t = tile * nb + keyframe.  flags: n_tiles * nb bytes,
+// done: n_tiles * nb zeroed bytes, pos / list: n_tiles * nb uint32, count: one uint32, cmax: nb * ceil(rows/8) * ceil(cols/8) uint32, temp: scan_temp_bytes(n_tiles * nb)
+hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
+                                 const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
+                                 void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
+                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s);
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
 hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
                             uint8_t* labels, hipStream_t s);
@@ -131,8 +138,14 @@ hipError_t scan_total_to(const uint8_t* flags, const uint32_t* pos, size_t n, ui
 hipError_t sort_pairs_u64(const uint64_t* keys_in, uint64_t* keys_out, const uint32_t* val_in, uint32_t* val_out, size_t n,
                           unsigned end_bit, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t head_flags(const uint64_t* keys, size_t n, uint8_t* heads, hipStream_t s, unsigned shift = 0);   // compares keys >> shift
-// packed voxel path: (Morton << idx_bits) | index in one word, keys-only sort over the Morton bits
-hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, unsigned idx_bits, uint64_t* keys, hipStream_t s);
+// Order-preserving compression of the Morton code: bit positions that are a FUNCTION OF MORE SIGNIFICANT BITS for every key the
+// cloud can produce never decide a comparison and are left out (fewer radix passes).  With the octree box centred on the data, an
+// axis whose extent is well below the cube's side has its second, third ... bits tied to its top bit (z of a 10 m high map in a
+// 205 m cube: 4 of 12 bits).  The kept positions are given as up to kMaxKeyRuns runs of consecutive bits: out |= ((code >> src) & mask) << dst.
+static constexpr int kMaxKeyRuns = 24;
+struct KeyCompress { int n_runs; unsigned bits; unsigned char src[kMaxKeyRuns], dst[kMaxKeyRuns]; uint64_t mask[kMaxKeyRuns]; };
+// packed voxel path: (compressed Morton << idx_bits) | index in one word, keys-only sort over the code bits
+hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, KeyCompress kc, unsigned idx_bits, uint64_t* keys, hipStream_t s);
 size_t sort_keys_temp_bytes(size_t n);
 hipError_t sort_keys_u64(const uint64_t* keys_in, uint64_t* keys_out, size_t n, unsigned begin_bit, unsigned end_bit, void* temp,
                          size_t temp_bytes, hipStream_t s);
@@ -163,6 +176,21 @@ hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, siz
                            const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity,
                            const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask,
                            int k, float thr, float cell2_lo, uint8_t* coexist, float4* local_out, hipStream_t s);
+// two-phase form for k <= 4 (see ltm_kernels.hip): 64-byte buckets of quantised cell points decide "certainly coexist", the rest is
+// compacted and searched exactly.  buckets: n_buckets x 64 bytes, initialised to 0xff; pos / queue: n_pts uint32 each; count: one uint32
+hipError_t knn_bucket_build(const float4* sorted_target, const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, size_t n_pts, KnnGrid g,
+                            void* buckets, uint32_t n_buckets, hipStream_t s);
+// occupancy bitmap of the grid (one bit per cell, cell_id order): ceil(nx*ny*nz / 32) zeroed uint32 words; lets the exact search skip empty cells
+hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, KnnGrid g, uint32_t* bitmap, hipStream_t s);
+// phase 1: local_out for every query, coexist[i] = 1 (certainly coexist) / 0 (certainly diff: outside the grid) / 2 (undecided)
+hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
+                              const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity, KnnGrid g, const void* buckets,
+                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s);
+// phase 2: the undecided queries are compacted (scan + scatter) and searched exactly; *count = their number
+hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
+                               const double* poses_dev, HostMat34 b2l, int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g,
+                               const HashEntry* table, uint32_t table_mask, const uint32_t* bitmap, int k, float thr, float cell2_lo, uint8_t* coexist, uint32_t* pos,
+                               uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g,
                            const HashEntry* table, uint32_t table_mask, int k, float thr, float cell2_lo,
                            uint8_t* near, hipStream_t s);

@@ -725,8 +725,8 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
     const unsigned kfg = (unsigned)g_kf_per_block;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
     const float* tb = (g_tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
-#define LTM_LAUNCH_CULL(ID, E) k_vote_map_cull<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
     const bool el3 = g.el_fit != 0 && g_cull_variant != 1;       // LTM_CULL_VARIANT=1: generic elevation polynomial (A/B)
+#define LTM_LAUNCH_CULL(ID, E) k_vote_map_cull<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
     if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL(false, true); else LTM_LAUNCH_CULL(false, false); }
     else { if (el3) LTM_LAUNCH_CULL(true, true); else LTM_LAUNCH_CULL(true, false); }
 #undef LTM_LAUNCH_CULL
@@ -793,10 +793,11 @@ static constexpr int kBmQueue = 2048;     // survivor queue capacity (~11 % of 4
 static constexpr uint32_t kBmRowUncertain = 511u;
 static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain survivors (~1 % of the tile); beyond it they are handled in place
 
+// pairs != null: workgroup b processes the (tile, keyframe) pair pairs[b] = tile * nb + keyframe (occlusion-culled launch, see exact_images_occlusion_*)
 template <bool B2L_IDENTITY, bool EL3, int SLOT_ROWS = 16>
 __global__ void __launch_bounds__(kBlock)
 k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img)
+                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs)
 {
     constexpr int kBmSlots = SLOT_ROWS * 64;
     static_assert(kBmSlots <= kBmSlotsMax, "");
@@ -809,7 +810,17 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     __shared__ uint16_t uqueue[kBmUQueue];
     __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
-    const TileKf tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
+    TileKf tk;
+    if (pairs) {
+        // the list is sorted by (tile, keyframe); workgroup b runs on XCD b % 8 (see tile_kf_of_block), so XCD x walks the x-th eighth of
+        // the list front to back: consecutive workgroups of one XCD share a tile and it is served from that XCD's L2, as in the plain launch
+        const uint32_t seg = (n_pairs + 7u) >> 3, at = (blockIdx.x & 7u) * seg + (blockIdx.x >> 3);
+        if ((blockIdx.x >> 3) >= seg || at >= n_pairs) return;
+        const uint32_t pr = pairs[at];
+        tk.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr / nb)); tk.kfb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr % nb)); tk.valid = true;
+    } else {
+        tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
+    }
     if (!tk.valid) return;
     for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; amin[s] = 0x7f800000u; }
     if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
@@ -954,7 +965,7 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
         const unsigned kfg = (unsigned)g_kf_per_block;
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img)
+#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u)
         const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
         if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true); else LTM_LAUNCH_BM(false, false); }
         else { if (el3) LTM_LAUNCH_BM(true, true); else LTM_LAUNCH_BM(true, false); }
@@ -972,6 +983,143 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
     dim3 grid(grid_for(M), (unsigned)nb);
     if (b2l_identity) k_map_rimg<true><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
     else k_map_rimg<false><<<grid, dim3(kBlock), 0, s>>>(map, M, inv_poses_dev, kb, b2l, g, map_img);
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Occlusion cull for the exact arg-min image on LARGE maps (KITTI scale: 45 M points = 11 000 tiles, 2000 keyframes).  There nearly every
+// (tile, keyframe) pair is far from the sensor, subtends a pixel or two, and loses to nearer returns -- yet k_map_rimg_blockmin ran
+// its ~130 instructions per point for all of them (reproject_map 484 of 887 ms per step).  Now, per batch of keyframes:
+//   1. the pairs are visited in SHELLS of sensor-to-tile distance (r_near, 2 r_near, 4 r_near, ...); the first shell is projected as it
+//      is (list-driven k_map_rimg_blockmin);
+//   2. before every later shell a coarse image holds, per 8 x 8 pixel block, the LARGEST range of the image built so far (an empty
+//      pixel counts as 10000);
+//   3. a pair of that shell is dropped iff every coarse block its bounding sphere can touch is covered by returns strictly nearer
+//      than the sphere's nearest point: none of its points can then be the arg-min of any pixel (ties need an equal range, excluded
+//      by the strict comparison with margins), so the final image is bit-identical; the others are projected and become occluders of
+//      the shells behind them (a facade 80 m away hides what a single near / far split at 60 m could not).
+// The sphere's pixel rectangle is conservative: centre direction from the float transform (1e-5 rad), angular radius asin(rho / d)
+// enlarged, +-1 pixel, rows clamped like the reference clamps elevations; spheres that straddle the +-180 deg seam, reach above 80 deg
+// of elevation, are nearer than two radii or touch more than 64 blocks are simply kept.
+struct SphereRect { int r0, r1, c0, c1; float d_lo; bool cullable; };
+__device__ __forceinline__ SphereRect sphere_rect(const RimgGeom& g, const float* __restrict__ ap, const float* __restrict__ tb)
+{
+    SphereRect o; o.cullable = false; o.r0 = o.r1 = o.c0 = o.c1 = 0; o.d_lo = 0.0f;
+    const float smin = ap[15];
+    if (!(smin > 0.999f)) return o;                                   // not (nearly) a rigid pose: angles are not preserved
+    const float cx = 0.5f * (tb[0] + tb[3]), cy = 0.5f * (tb[1] + tb[4]), cz = 0.5f * (tb[2] + tb[5]);
+    const float hx = 0.5f * (tb[3] - tb[0]), hy = 0.5f * (tb[4] - tb[1]), hz = 0.5f * (tb[5] - tb[2]);
+    const float rho = __builtin_sqrtf(hx * hx + hy * hy + hz * hz) * 1.001f + 2.0e-3f;
+    bool ok;
+    const float3 l = xform_approx(ap, make_float4(cx, cy, cz, 0.0f), ok);
+    const float d = __builtin_sqrtf(l.x * l.x + l.y * l.y + l.z * l.z);
+    if (!ok || !(d > 2.0f * rho) || !(d < 8.0e3f)) return o;         // NaN-safe; beyond 8 km the 10000-sentinel arithmetic starts to matter
+    const float ratio = rho / d;                                      // <= 0.5
+    const float alpha = asinf(ratio) * 1.01f + 2.0e-4f;
+    const float rxy = __builtin_sqrtf(l.x * l.x + l.y * l.y);
+    const float el0 = atan2f(l.z, rxy), az0 = atan2f(l.y, l.x);
+    if (!(fabsf(el0) + alpha < 1.39f)) return o;                      // 80 deg
+    const float sa = sinf(alpha) / cosf(fabsf(el0) + alpha);
+    if (!(sa < 0.95f)) return o;
+    const float daz = asinf(sa) * 1.01f + 2.0e-4f;
+    if (!(az0 - daz > -3.1415f && az0 + daz < 3.1415f)) return o;     // would wrap around the seam
+    const float r2d = 57.29577951308232f;
+    // same (monotone) pixel mapping as pixel_row_col, evaluated in plain float with a pixel of margin on either side
+    const float row_hi_el = g.frows * (1.0f - ((el0 + alpha) * r2d + g.half_v) / g.vfov), row_lo_el = g.frows * (1.0f - ((el0 - alpha) * r2d + g.half_v) / g.vfov);
+    const float col_lo = g.fcols * (((az0 - daz) * r2d + g.half_h) / g.hfov), col_hi = g.fcols * (((az0 + daz) * r2d + g.half_h) / g.hfov);
+    o.r0 = (int)fminf(fmaxf(floorf(row_hi_el) - 1.0f, 0.0f), g.row_max);
+    o.r1 = (int)fminf(fmaxf(ceilf(row_lo_el) + 1.0f, 0.0f), g.row_max);
+    o.c0 = (int)fminf(fmaxf(floorf(col_lo) - 1.0f, 0.0f), g.col_max);
+    o.c1 = (int)fminf(fmaxf(ceilf(col_hi) + 1.0f, 0.0f), g.col_max);
+    o.d_lo = (d - rho) * 0.9995f - 2.0e-3f;                            // below the exact float range of every point of the tile
+    o.cullable = o.d_lo > 0.0f;
+    return o;
+}
+
+// One distance shell of the occlusion-culled launch: flags[tile * nb + kfb] = 1 iff the pair has not been projected yet, the tile's
+// bounding box comes within [r_lo, r_hi) of the sensor (pairs that cannot be culled at all count as distance 0) and -- once a coarse
+// maximum of the image built so far exists -- the tile is not hidden behind it.  done[] remembers projected / dropped pairs.
+__global__ void __launch_bounds__(kBlock)
+k_pair_shell_select(const float* __restrict__ approx_poses, uint32_t kb, uint32_t nb, const float* __restrict__ tile_bounds, uint32_t n_tiles, Geom gg,
+                    float r_lo, float r_hi, const uint32_t* __restrict__ cmax, uint32_t rbs, uint32_t cbs, uint8_t* __restrict__ done, uint8_t* __restrict__ flags)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_tiles * nb) return;
+    if (done[t]) { flags[t] = 0; return; }
+    const uint32_t tile = t / nb, kfb = t % nb;
+    const float* ap = approx_poses + 16 * (size_t)(kb + kfb);
+    const float* tb = tile_bounds + 6 * (size_t)tile;
+    float d2 = 0.0f;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) { const float c = ap[9 + d]; const float e = fmaxf(fmaxf(tb[d] - c, c - tb[3 + d]), 0.0f); d2 = __builtin_fmaf(e, e, d2); }
+    const RimgGeom g = make_geom(gg);
+    const SphereRect sr = sphere_rect(g, ap, tb);
+    if (!sr.cullable || !(d2 == d2)) d2 = 0.0f;                        // NaN bounds / unusable pose / too near: first shell, never dropped
+    if (!(d2 >= r_lo * r_lo && d2 < r_hi * r_hi)) { flags[t] = 0; return; }
+    bool live = true;
+    if (cmax && sr.cullable) {
+        const int rb0 = sr.r0 >> 3, rb1 = sr.r1 >> 3, cb0 = sr.c0 >> 3, cb1 = sr.c1 >> 3;
+        if ((rb1 - rb0 + 1) * (cb1 - cb0 + 1) <= 64) {
+            uint32_t m = 0;
+            for (int rb = rb0; rb <= rb1; ++rb)
+                for (int cb = cb0; cb <= cb1; ++cb) m = max(m, cmax[((size_t)kfb * rbs + rb) * cbs + cb]);
+            live = !(u2f(m) < sr.d_lo);
+        }
+    }
+    done[t] = 1;
+    flags[t] = live ? 1 : 0;
+}
+// cmax[kfb][rb][cb] = largest range bits of the pixels of the 8 x 8 block (positive floats order like their bits; empty = 10000)
+__global__ void __launch_bounds__(kBlock)
+k_coarse_max(const uint64_t* __restrict__ img, uint32_t rows, uint32_t cols, uint32_t rbs, uint32_t cbs, uint32_t nb, uint32_t* __restrict__ cmax)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= nb * rbs * cbs) return;
+    const uint32_t cb = t % cbs, rb = (t / cbs) % rbs, kfb = t / (cbs * rbs);
+    const uint64_t* __restrict__ im = img + (size_t)kfb * rows * cols;
+    uint32_t m = 0;
+    for (uint32_t r = rb * 8; r < min(rows, rb * 8 + 8); ++r)
+        for (uint32_t cc = cb * 8; cc < min(cols, cb * 8 + 8); ++cc) m = max(m, (uint32_t)(im[(size_t)r * cols + cc] >> 32));
+    cmax[t] = m;
+}
+struct FlagIs { uint8_t v; __host__ __device__ uint32_t operator()(uint8_t f) const { return f == v ? 1u : 0u; } };
+__global__ void __launch_bounds__(kBlock)
+k_pair_list_scatter(const uint8_t* __restrict__ flags, uint8_t v, const uint32_t* __restrict__ pos, uint32_t n, uint32_t* __restrict__ list, uint32_t* __restrict__ count)
+{
+    const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n) return;
+    const bool on = flags[t] == v;
+    if (on) list[pos[t]] = t;
+    if (t == n - 1) *count = pos[t] + (on ? 1u : 0u);
+}
+
+// one shell: [r_lo, r_hi) of sensor-to-tile distance; img = the image built so far (ignored for the first shell: use_cmax = 0)
+hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
+                                 const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
+                                 void* temp, size_t temp_bytes, hipStream_t s)
+{
+    const uint32_t n = (uint32_t)(n_tiles * nb);
+    const uint32_t rbs = (uint32_t)(g.rows + 7) / 8, cbs = (uint32_t)(g.cols + 7) / 8;
+    if (use_cmax) k_coarse_max<<<dim3(grid_for((size_t)nb * rbs * cbs)), dim3(kBlock), 0, s>>>(img, (uint32_t)g.rows, (uint32_t)g.cols, rbs, cbs, (uint32_t)nb, cmax);
+    k_pair_shell_select<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(approx_poses_dev, (uint32_t)kb, (uint32_t)nb, tile_bounds_dev, (uint32_t)n_tiles, g, r_lo, r_hi,
+                                                                use_cmax ? cmax : nullptr, rbs, cbs, done, flags);
+    auto it = rocprim::make_transform_iterator(flags, FlagIs{1});
+    hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    k_pair_list_scatter<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(flags, 1, pos, n, list, count);
+    return hipGetLastError();
+}
+// k_map_rimg_blockmin over an explicit list of n_pairs (tile * nb + keyframe) pairs
+hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
+                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s)
+{
+    if (!n_pairs) return hipSuccess;
+    dim3 grid((unsigned)(((n_pairs + 7) / 8) * 8));
+#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs)
+    const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
+    if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true); else LTM_LAUNCH_BMP(false, false); }
+    else { if (el3) LTM_LAUNCH_BMP(true, true); else LTM_LAUNCH_BMP(true, false); }
+#undef LTM_LAUNCH_BMP
     return hipGetLastError();
 }
 
@@ -1531,7 +1679,7 @@ hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* key
 // packed form: (Morton code << idx_bits) | point index in ONE 64-bit word, so that the sort moves 8 B per element instead of
 // 12 B (keys-only radix sort over the Morton bits; it is stable, so equal codes keep their ascending point indices)
 __global__ void __launch_bounds__(kBlock)
-k_morton_keys_packed(const float4* __restrict__ pts, size_t n, OctreeFrame f, unsigned idx_bits, uint64_t* __restrict__ keys)
+k_morton_keys_packed(const float4* __restrict__ pts, size_t n, OctreeFrame f, KeyCompress kc, unsigned idx_bits, uint64_t* __restrict__ keys)
 {
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
@@ -1539,12 +1687,15 @@ k_morton_keys_packed(const float4* __restrict__ pts, size_t n, OctreeFrame f, un
     const uint32_t kx = (uint32_t)(((double)p.x - f.minx) / f.res);
     const uint32_t ky = (uint32_t)(((double)p.y - f.miny) / f.res);
     const uint32_t kz = (uint32_t)(((double)p.z - f.minz) / f.res);
-    keys[i] = ((((spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz))) << idx_bits) | (uint64_t)i;
+    const uint64_t code = (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+    uint64_t c = 0;
+    for (int r = 0; r < kc.n_runs; ++r) c |= ((code >> kc.src[r]) & kc.mask[r]) << kc.dst[r];      // uniform trip count, scalar operands
+    keys[i] = (c << idx_bits) | (uint64_t)i;
 }
-hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, unsigned idx_bits, uint64_t* keys, hipStream_t s)
+hipError_t morton_keys_packed(const float4* pts, size_t n, OctreeFrame f, KeyCompress kc, unsigned idx_bits, uint64_t* keys, hipStream_t s)
 {
     if (!n) return hipSuccess;
-    k_morton_keys_packed<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, f, idx_bits, keys);
+    k_morton_keys_packed<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(pts, n, f, kc, idx_bits, keys);
     return hipGetLastError();
 }
 // number of set flags given the exclusive scan `pos` of `flags` (n > 0), written to *out on the device: lets several counts of a
@@ -1835,7 +1986,8 @@ static constexpr int kMaxK = 16;
 // registers and are maintained by a branch-free insertion network.  KT == 0: any k <= kMaxK, indexed array.
 template <int KT>
 __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const float4* __restrict__ tgt, size_t Mt, const KnnGrid& g,
-                                         const HashEntry* __restrict__ table, uint32_t mask, int k_param, float thr, float cell2_lo)
+                                         const HashEntry* __restrict__ table, uint32_t mask, int k_param, float thr, float cell2_lo,
+                                         const uint32_t* __restrict__ bitmap = nullptr)
 {
     if (Mt == 0) return false;                        // reference: undefined; defined here as "far"
     const int k = KT ? KT : (int)min((size_t)k_param, Mt);      // pcl::KdTreeFLANN::nearestKSearch clamps k
@@ -1902,10 +2054,14 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
             for (uint32_t j = e.start; j < e.end; ++j) { const float4 t = tgt[j]; push(sqdist_l2simple(qx, qy, qz, t.x, t.y, t.z)); }
             return e.start != e.end && cnt == k && best[k - 1] < cell2_lo && mean_below_thr();
         };
+        // in the grid and -- when the occupancy bitmap exists -- holding at least one target point (an empty cell has no table entry: the
+        // probe would run into an empty slot and contribute nothing)
         auto cell_key = [&](int c, uint64_t& key) -> bool {
             const int x = cx + kOrder[c][0], y = cy + kOrder[c][1], z = cz + kOrder[c][2];
             key = ((uint64_t)(uint32_t)x * (uint32_t)ny + (uint32_t)y) * (uint32_t)nz + (uint32_t)z;   // == cell_id()
-            return !((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz);
+            const bool in = !((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz);
+            if (!bitmap || !in) return in;
+            return ((bitmap[key >> 5] >> (key & 31u)) & 1u) != 0u;
         };
         {   // the centre cell alone: most queries of a static scene end here
             uint64_t key;
@@ -1989,6 +2145,258 @@ hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, siz
         case 3: launch(b2l_tag, std::integral_constant<int, 3>{}); break;
         case 4: launch(b2l_tag, std::integral_constant<int, 4>{}); break;
         default: launch(b2l_tag, std::integral_constant<int, 0>{}); break;
+        }
+    };
+    if (b2l_identity) by_kt(std::true_type{}); else by_kt(std::false_type{});
+    return hipGetLastError();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Two-phase kNN query (k <= 4).  Round 2's kernel moved 8.5x its algorithmic bytes: every query probed a 16-byte hash entry in one
+// cache line and then gathered the ~9 points of its cell from two or three others, three dependent round trips, and the few
+// queries of a wavefront that end "diff" (27 cells) held the other lanes back.  Now:
+//   phase 1 (k_knn_fast, every query): ONE 64-byte bucket per occupied cell holds up to nine of the cell's points QUANTISED to 16 bit
+//     per axis inside the cell (2-choice hashing: the bucket is at one of two places).  From it the query gets an UPPER bound of its
+//     squared distance to each of those points; if the k smallest bounds already satisfy the predicate of Session.cpp:590-599 with
+//     a margin, the query is "coexist" whatever else is in the target -- the k nearest neighbours can only be nearer, and the
+//     sum is rounded monotonically.  Everything else is left UNDECIDED (flag 2).
+//   phase 2 (k_knn_slow, the undecided queries, compacted): the exact search of knn_near, on dense wavefronts.
+// The quantised points only ever say "certainly coexist"; every other answer comes from the exact arithmetic, so the flags are
+// those of the exact kernel (LTM_KNN_FAST=0 runs it alone; tests compare both with the oracle).
+// Error budget of the bound: quantisation cell / 2^17 per axis (1.1e-6 m at the yaml cell of 0.1416 m), the query's own offset in its
+// cell is computed in double and rounded once to float (1e-8 m), the float evaluation of d~ adds < 1e-7 m, so
+// |d - d~| <= sqrt(3) cell / 2^17 + 2e-7 =: slack (computed on the host, 2.1e-6 m at yaml values, with 5 % on top); FLANN's float
+// evaluation of d^2 (Sterbenz-exact differences, three roundings) is within 3e-7 relative of the true value.
+// ub = (d~ + slack)^2 (1 + 3e-6), test: sum ub < k thr (1 - 1e-5).
+struct __attribute__((aligned(64))) KnnBucketRaw { uint32_t w[16]; };      // w[0..1] cell key, then 27 x u16 (x y z of 9 points), u8 count, u8 pad
+static_assert(sizeof(KnnBucketRaw) == 64, "");
+static constexpr int kBucketPts = 9;
+
+__device__ __forceinline__ uint32_t hash64b(uint64_t k)      // second hash function of the 2-choice table
+{
+    uint32_t x = (uint32_t)(k >> 32) ^ ((uint32_t)k * 0x85ebca6bu) ^ 0x27d4eb2fu;
+    x ^= x >> 15; x *= 0x2c1b3c6du; x ^= x >> 12; x *= 0x297a2d39u; x ^= x >> 15;
+    return x;
+}
+__device__ __forceinline__ uint32_t bucket_of(uint32_t h, uint32_t n_buckets) { return (uint32_t)(((uint64_t)h * n_buckets) >> 32); }
+
+__global__ void __launch_bounds__(kBlock)
+k_knn_bucket_build(const float4* __restrict__ tgt, const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ starts, size_t n_cells,
+                   size_t n_pts, KnnGrid g, KnnBucketRaw* __restrict__ buckets, uint32_t n_buckets)
+{
+    const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_cells) return;
+    const uint32_t a = starts[u];
+    const uint32_t b = (u + 1 < n_cells) ? starts[u + 1] : (uint32_t)n_pts;
+    const uint64_t key = sorted_keys[a];
+    uint32_t slot = bucket_of(hash64(key), n_buckets);
+    unsigned long long* kp = reinterpret_cast<unsigned long long*>(&buckets[slot].w[0]);
+    if (atomicCAS(kp, (unsigned long long)kEmptyKey, (unsigned long long)key) != kEmptyKey) {
+        slot = bucket_of(hash64b(key), n_buckets);
+        kp = reinterpret_cast<unsigned long long*>(&buckets[slot].w[0]);
+        if (atomicCAS(kp, (unsigned long long)kEmptyKey, (unsigned long long)key) != kEmptyKey) return;      // both taken: this cell's queries go to phase 2
+    }
+    const uint32_t n = b - a, cnt = min(n, (uint32_t)kBucketPts);
+    uint16_t q[3 * kBucketPts];
+#pragma unroll
+    for (int s = 0; s < kBucketPts; ++s) {
+        // more points than fit: evenly spread over the cell's run (the target is a voxel-grid output in octree order: spatially spread)
+        const uint32_t j = a + ((uint32_t)s < cnt ? (cnt > 1 ? (uint32_t)(((uint64_t)s * (n - 1)) / (cnt - 1)) : 0u) : 0u);
+        const float4 p = tgt[j];
+        const double t[3] = {((double)p.x - g.ox) * g.inv_cell, ((double)p.y - g.oy) * g.inv_cell, ((double)p.z - g.oz) * g.inv_cell};
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+            const double fr = t[d] - floor(t[d]);
+            q[3 * s + d] = (uint16_t)min(65535, max(0, (int)(fr * 65536.0)));
+        }
+    }
+    uint32_t* w = buckets[slot].w;
+#pragma unroll
+    for (int i = 0; i < 13; ++i) w[2 + i] = (uint32_t)q[2 * i] | ((uint32_t)q[2 * i + 1] << 16);
+    w[15] = (uint32_t)q[26] | (cnt << 16);
+}
+hipError_t knn_bucket_build(const float4* sorted_target, const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, size_t n_pts, KnnGrid g,
+                            void* buckets, uint32_t n_buckets, hipStream_t s)
+{
+    if (!n_cells) return hipSuccess;
+    k_knn_bucket_build<<<dim3(grid_for(n_cells)), dim3(kBlock), 0, s>>>(sorted_target, sorted_keys, starts, n_cells, n_pts, g,
+                                                                     reinterpret_cast<KnnBucketRaw*>(buckets), n_buckets);
+    return hipGetLastError();
+}
+
+// Occupancy bitmap of the grid, one bit per cell (cell_id order: z fastest): the exact search tests it before it probes the hash table,
+// so the empty cells among the 27 -- most of them around the sparse, far-from-the-trajectory points that make up the bulk of the
+// "diff" answers -- cost a bit test in a 5 MB array (120 x 80 x 12 m lot at the yaml cell size) instead of a 64-byte line of the table each.
+// Not built above 2^31 cells (then every cell is probed, as before).
+__global__ void __launch_bounds__(kBlock)
+k_knn_bitmap_build(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ starts, size_t n_cells, uint32_t* __restrict__ bitmap)
+{
+    const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (u >= n_cells) return;
+    const uint64_t b = sorted_keys[starts[u]];
+    atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
+}
+hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, KnnGrid g, uint32_t* bitmap, hipStream_t s)
+{
+    (void)g;
+    if (!n_cells) return hipSuccess;
+    k_knn_bitmap_build<<<dim3(grid_for(n_cells)), dim3(kBlock), 0, s>>>(sorted_keys, starts, n_cells, bitmap);
+    return hipGetLastError();
+}
+
+// phase-1 verdict from the query's own cell: 1 = certainly coexist (bucket), 0 = certainly diff (outside the grid), 2 = undecided
+template <int KT>
+__device__ __forceinline__ int knn_bucket_coexist(float qx, float qy, float qz, const KnnGrid& g, const KnnBucketRaw* __restrict__ buckets, uint32_t n_buckets,
+                                                   float cell_m, float dist_slack, float k_thr_lo)
+{
+    const double tx = ((double)qx - g.ox) * g.inv_cell, ty = ((double)qy - g.oy) * g.inv_cell, tz = ((double)qz - g.oz) * g.inv_cell;
+    const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
+    // outside the grid (NaN included): the occupied cells are 1 .. n-2 on every axis, so no target point is within a cell edge of such a
+    // query: fewer than k neighbours inside the provably-complete radius, "diff" exactly as knn_near decides it
+    if (!(fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz)) return 0;
+    const uint64_t key = ((uint64_t)(uint32_t)(int)fx * (uint32_t)g.ny + (uint32_t)(int)fy) * (uint32_t)g.nz + (uint32_t)(int)fz;   // == cell_id()
+    const float ux = (float)(tx - fx), uy = (float)(ty - fy), uz = (float)(tz - fz);
+    const uint4* bp = reinterpret_cast<const uint4*>(buckets + bucket_of(hash64(key), n_buckets));
+    uint4 v0 = bp[0];
+    if ((((uint64_t)v0.y << 32) | v0.x) != key) {
+        bp = reinterpret_cast<const uint4*>(buckets + bucket_of(hash64b(key), n_buckets));
+        v0 = bp[0];
+        if ((((uint64_t)v0.y << 32) | v0.x) != key) return 2;
+    }
+    const uint4 v1 = bp[1], v2 = bp[2], v3 = bp[3];
+    const uint32_t w[14] = {v0.z, v0.w, v1.x, v1.y, v1.z, v1.w, v2.x, v2.y, v2.z, v2.w, v3.x, v3.y, v3.z, v3.w};
+    const uint32_t cnt = w[13] >> 16;
+    if (cnt < (uint32_t)KT) return 2;
+    float best[KT];
+#pragma unroll
+    for (int j = 0; j < KT; ++j) best[j] = __builtin_inff();
+#pragma unroll
+    for (int s = 0; s < kBucketPts; ++s) {
+        auto h = [&](int i) { return (float)((i & 1) ? (w[i >> 1] >> 16) : (w[i >> 1] & 0xffffu)); };
+        const float dx = ux - (h(3 * s) + 0.5f) * (1.0f / 65536.0f), dy = uy - (h(3 * s + 1) + 0.5f) * (1.0f / 65536.0f),
+                    dz = uz - (h(3 * s + 2) + 0.5f) * (1.0f / 65536.0f);
+        float d = __builtin_fmaf(dz, dz, __builtin_fmaf(dy, dy, dx * dx));      // squared distance in cell units
+        d = ((uint32_t)s < cnt) ? d : __builtin_inff();
+#pragma unroll
+        for (int j = KT - 1; j >= 0; --j) {
+            if (j > 0) best[j] = (d < best[j - 1]) ? best[j - 1] : fminf(best[j], d);
+            else best[0] = fminf(best[0], d);
+        }
+    }
+    float sum = 0.0f;
+#pragma unroll
+    for (int j = 0; j < KT; ++j) {
+        const float dm = __builtin_sqrtf(best[j]) * cell_m + dist_slack;         // metres, upper bound of the true distance
+        sum += dm * dm * (1.0f + 3.0e-6f);
+    }
+    return sum < k_thr_lo ? 1 : 2;
+}
+
+template <bool B2L_IDENTITY, int KT>
+__global__ void __launch_bounds__(kBlock)
+k_knn_fast(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, uint64_t first_pt,
+           const double* __restrict__ poses, const double* __restrict__ inv_poses, HostMat34 b2l_h, KnnGrid g,
+           const KnnBucketRaw* __restrict__ buckets, uint32_t n_buckets, float cell_m, float dist_slack, float k_thr_lo,
+           uint8_t* __restrict__ coexist, float4* __restrict__ local_out)
+{
+    const size_t kf = kb + blockIdx.y;
+    const uint64_t a = offsets[kf], local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= offsets[kf + 1] - a) return;
+    const uint64_t gi = a + local, i = gi - first_pt;
+    const float4 p4 = scans[gi];
+    float3 p = make_float3(p4.x, p4.y, p4.z);
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);      // Session.cpp:545 / :618 (quirk Q7)
+    const float3 gp = xform(load_mat(poses + 12 * kf), p);
+    float3 l = xform(load_mat(inv_poses + 12 * kf), gp);                               // :603-604
+    if (B2L_IDENTITY) l = xform_identity(l); else l = xform(to_dev(b2l_h), l);
+    local_out[i] = make_float4(l.x, l.y, l.z, p4.w);
+    coexist[i] = (uint8_t)knn_bucket_coexist<KT>(gp.x, gp.y, gp.z, g, buckets, n_buckets, cell_m, dist_slack, k_thr_lo);      // 2 = undecided
+}
+
+// queue[pos[i]] = i for the undecided queries (pos = exclusive scan of flag == 2); *count = their number
+__global__ void __launch_bounds__(kBlock)
+k_knn_queue_scatter(const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint64_t n, uint32_t* __restrict__ queue, uint32_t* __restrict__ count)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool und = flag[i] == 2;
+    if (und) queue[pos[i]] = (uint32_t)i;
+    if (i == n - 1) *count = pos[i] + (und ? 1u : 0u);
+}
+
+template <bool B2L_IDENTITY, int KT>
+__global__ void __launch_bounds__(kBlock)
+k_knn_slow(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
+           const double* __restrict__ poses, HostMat34 b2l_h, const float4* __restrict__ tgt, size_t Mt, KnnGrid g,
+           const HashEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ bitmap, int k, float thr, float cell2_lo,
+           const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count, uint8_t* __restrict__ coexist)
+{
+    const uint32_t n = *count;
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const uint32_t i = queue[q];
+        const uint64_t gi = first_pt + i;
+        const size_t kf = find_kf(offsets, kb, ke, gi);
+        const float4 p4 = scans[gi];
+        float3 p = make_float3(p4.x, p4.y, p4.z);
+        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+        const float3 gp = xform(load_mat(poses + 12 * kf), p);
+        coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo, bitmap) ? 1 : 0;
+    }
+}
+
+struct FlagUndecided { __host__ __device__ uint32_t operator()(uint8_t v) const { return v == 2 ? 1u : 0u; } };
+
+hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
+                              const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity, KnnGrid g, const void* buckets,
+                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s)
+{
+    if (!n_pts || !max_kf_pts) return hipSuccess;
+    if (k < 1 || k > 4) return hipErrorInvalidValue;
+    const float cell_m = (float)(1.0 / g.inv_cell);
+    const float dist_slack = (float)((1.7320508075688772 * (1.0 / g.inv_cell) / 131072.0) * 1.05 + 2.0e-7);
+    const float k_thr_lo = (float)((double)k * (double)thr * (1.0 - 1.0e-5));
+    const KnnBucketRaw* bk = reinterpret_cast<const KnnBucketRaw*>(buckets);
+    auto fast = [&](auto b2l_tag, auto kt_tag) {
+        for (size_t k0 = kb; k0 < ke; k0 += 65535) {
+            const size_t k1 = std::min(ke, k0 + 65535);
+            k_knn_fast<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(grid_for(max_kf_pts), (unsigned)(k1 - k0)), dim3(kBlock), 0, s>>>(
+                scans, offsets_dev, k0, first_pt, poses_dev, inv_poses_dev, b2l, g, bk, n_buckets, cell_m, dist_slack, k_thr_lo, coexist, local_out);
+        }
+    };
+    auto by_kt = [&](auto b2l_tag) {
+        switch (k) {
+        case 1: fast(b2l_tag, std::integral_constant<int, 1>{}); break;
+        case 2: fast(b2l_tag, std::integral_constant<int, 2>{}); break;
+        case 3: fast(b2l_tag, std::integral_constant<int, 3>{}); break;
+        default: fast(b2l_tag, std::integral_constant<int, 4>{}); break;
+        }
+    };
+    if (b2l_identity) by_kt(std::true_type{}); else by_kt(std::false_type{});
+    return hipGetLastError();
+}
+
+hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
+                               const double* poses_dev, HostMat34 b2l, int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g,
+                               const HashEntry* table, uint32_t table_mask, const uint32_t* bitmap, int k, float thr, float cell2_lo, uint8_t* coexist, uint32_t* pos,
+                               uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n_pts) return hipSuccess;
+    if (k < 1 || k > 4 || Mt < (size_t)k) return hipErrorInvalidValue;
+    auto it = rocprim::make_transform_iterator(coexist, FlagUndecided());
+    hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, n_pts, rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    k_knn_queue_scatter<<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(coexist, pos, n_pts, queue, count);
+    const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n_pts), 4096);
+    auto slow = [&](auto b2l_tag, auto kt_tag) {
+        k_knn_slow<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(blocks), dim3(kBlock), 0, s>>>(
+            scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, bitmap, k, thr, cell2_lo, queue, count, coexist);
+    };
+    auto by_kt = [&](auto b2l_tag) {
+        switch (k) {
+        case 1: slow(b2l_tag, std::integral_constant<int, 1>{}); break;
+        case 2: slow(b2l_tag, std::integral_constant<int, 2>{}); break;
+        case 3: slow(b2l_tag, std::integral_constant<int, 3>{}); break;
+        default: slow(b2l_tag, std::integral_constant<int, 4>{}); break;
         }
     };
     if (b2l_identity) by_kt(std::true_type{}); else by_kt(std::false_type{});

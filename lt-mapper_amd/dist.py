@@ -188,3 +188,94 @@ class ShardedOps:
     # ---- stages that need every keyframe
     def merge_to_global(self, scans, poses):
         return self.ops.merge_to_global(self.materialize(scans), poses)
+
+
+class CommMeter:
+    """What the keyframe-sharded pipeline WOULD exchange, recorded on a single-GPU run: wraps the plain stage operations and notes, for every
+    stage that ShardedOps follows with a collective, the payload that collective moves (bench.py puts the totals next to the measured
+    replicated / sharded kernel time, so that N-GPU scaling can be modelled from measured parts while no multi-GPU node is reachable).
+      label_allreduce   one MAX all-reduce of M bytes per vote pass (ShardedOps.vote_partition)
+      scans_allgather   all-gather of a rank-local scan set when a stage needs every keyframe (merge_to_global of reprojected / kNN-split scans)
+      voxel_allgather   all-gather of the centroid lists of a sharded voxel grid (clouds >= ShardedOps.VOXEL_SHARD_MIN points)"""
+
+    def __init__(self, ops):
+        self.ops = ops
+        self.events = {"label_allreduce": [0, 0], "scans_allgather": [0, 0], "voxel_allgather": [0, 0]}      # [count, payload bytes]
+        self._local = set()           # ids of scan sets that would be rank-local (LazyScans) under ShardedOps
+
+    def __getattr__(self, name):
+        return getattr(self.ops, name)
+
+    def reset(self):
+        for v in self.events.values():
+            v[0] = v[1] = 0
+        self._local.clear()
+
+    def _note(self, kind, nbytes):
+        self.events[kind][0] += 1
+        self.events[kind][1] += int(nbytes)
+
+    def _mark(self, s):
+        self._local.add(id(s))
+        return s
+
+    def vote_partition(self, cmap, scans, poses, alpha, thr, mode):
+        self._note("label_allreduce", self.ops.size(cmap))
+        return self.ops.vote_partition(cmap, scans, poses, alpha, thr, mode)
+
+    def reproject(self, cmap, poses, alpha): return self._mark(self.ops.reproject(cmap, poses, alpha))
+
+    def knn_partition(self, target, scans, poses, k, thr):
+        co, di = self.ops.knn_partition(target, scans, poses, k, thr)
+        return self._mark(co), self._mark(di)
+
+    def zip_concat(self, a, b, c): return self._mark(self.ops.zip_concat(a, b, c))
+    def voxel_scanset(self, s, leaf): return self._mark(self.ops.voxel_scanset(s, leaf))
+    def voxel_grid_scanset(self, s, leaf): return self._mark(self.ops.voxel_grid_scanset(s, leaf)) if id(s) in self._local else self.ops.voxel_grid_scanset(s, leaf)
+    def preclean(self, s, radius): return self._mark(self.ops.preclean(s, radius)) if id(s) in self._local else self.ops.preclean(s, radius)
+
+    def merge_to_global(self, scans, poses):
+        if id(scans) in self._local:
+            n_kf, n_pts = scans.info()
+            self._note("scans_allgather", 16 * n_pts + 8 * (n_kf + 2))
+        return self.ops.merge_to_global(scans, poses)
+
+    def voxel(self, c, leaf):
+        out = self.ops.voxel(c, leaf)
+        if self.ops.size(c) >= ShardedOps.VOXEL_SHARD_MIN:
+            self._note("voxel_allgather", 16 * self.ops.size(out))
+        return out
+
+    def voxel_batch(self, clouds, leaf):
+        outs = self.ops.voxel_batch(clouds, leaf)
+        for c, o in zip(clouds, outs):
+            if self.ops.size(c) >= ShardedOps.VOXEL_SHARD_MIN:
+                self._note("voxel_allgather", 16 * self.ops.size(o))
+        return outs
+
+
+# kernel classes (ltm_profile_read) whose work divides by the number of ranks under keyframe sharding; everything else is replicated
+SHARDED_CLASSES = ("vote_map_cull", "vote_map_exact", "vote_scan", "vote_compare", "vote_fill", "reproject_map", "reproject_gather", "knn_query",
+                   "knn_query_p2", "voxel_scanset", "voxel_grid_scanset")
+
+
+def scaling_model(class_ms_per_step, step_ms, events_per_step, ranks=(2, 4, 8), link_gbs=150.0, latency_us=25.0):
+    """strong-scaling estimate of ONE pair run from single-GPU measurements: T(N) = replicated + sharded / N + collectives(N), with the kernel
+    time of the sharded classes measured with HIP events, replicated = the rest of the step (replicated kernels + host gaps), and ring
+    collectives at `link_gbs` per direction and `latency_us` each (assumptions, stated in the output: no multi-GPU node was reachable)"""
+    sharded = sum(v for k, v in class_ms_per_step.items() if k in SHARDED_CLASSES)
+    # voxel grids large enough to be sharded (>= VOXEL_SHARD_MIN points): their sort divides too; approximated by the payload they return
+    replicated = max(step_ms - sharded, 0.0)
+    out = {"replicated_ms": round(replicated, 3), "sharded_ms": round(sharded, 3), "comm_events_per_step": {k: {"count": v[0], "payload_bytes": v[1]} for k, v in events_per_step.items()},
+           "comm_bytes_per_step": int(sum(v[1] for v in events_per_step.values())),
+           "assumptions": {"ring_bandwidth_GB_s_per_direction": link_gbs, "latency_us_per_collective": latency_us,
+                           "all_reduce_bytes_on_the_wire_per_rank": "2 (N-1)/N x payload", "all_gather": "(N-1)/N x payload"},
+           "status": "MODEL from single-GPU measurements -- unmeasured on multi-GPU hardware", "ranks": {}}
+    for n in ranks:
+        comm_ms = 0.0
+        for kind, (cnt, nbytes) in events_per_step.items():
+            factor = 2.0 * (n - 1) / n if kind == "label_allreduce" else (n - 1) / n
+            comm_ms += 1e3 * factor * nbytes / (link_gbs * 1e9) + cnt * latency_us * 1e-3 * (2 if kind == "scans_allgather" else 1)
+        t = replicated + sharded / n + comm_ms
+        out["ranks"][str(n)] = {"comm_ms": round(comm_ms, 3), "step_ms": round(t, 3), "speedup": round(step_ms / t, 3)}
+    return out

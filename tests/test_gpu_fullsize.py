@@ -124,3 +124,68 @@ def test_tile_cull_equals_no_tile_cull_on_kitti_scale_street(ltm):
     assert out[1].sum() > 100 and (out[1] == out[0]).all()
     assert (out[1] == out["exact"]).all(), "culled vote differs from the exact-image vote on the street scene"
     print(f"tile cull: {dt[1] * 1e3:.1f} ms vs {dt[0] * 1e3:.1f} ms without, exact-image vote {dt['exact'] * 1e3:.1f} ms")
+
+
+def test_two_phase_knn_equals_exact_search_at_full_size(ltm, full):
+    """phase 1 of the kNN query (quantised 64-byte cell buckets) may only ever say "certainly coexist": with it switched off
+    (LTM_KNN_FAST=0, the exact search for every query) both outputs must be the same scan sets, 200 keyframes of session 02 against
+    the 6.8 M-point map of session 01, at the yaml parameters and at the MLS ones (larger cell)"""
+    import torch
+    from tools import synth
+    Q = synth.make_session(2, 200, "os1-64", device="cuda:0")
+    torch.cuda.synchronize()
+    out = {}
+    for fast in (1, 0):
+        ctx = _ctx(ltm, LTM_KNN_FAST=fast, LTM_KNN_STATS=1)
+        _, _, cmap = _load(ctx, full)
+        q_scans, q_poses, _ = _load(ctx, Q)
+        for k, thr in ((2, 0.01), (3, 0.04), (1, 0.003)):
+            co, di = ctx.knn_partition(cmap, q_scans, q_poses, k, thr)
+            out[(fast, k, thr)] = (co.download(), di.download())
+        ctx.close()
+    for k, thr in ((2, 0.01), (3, 0.04), (1, 0.003)):
+        (a_co, a_di), (b_co, b_di) = out[(1, k, thr)], out[(0, k, thr)]
+        assert len(a_co[0]) > 1000 and len(a_di[0]) > 1000, "degenerate: one of the two classes is empty"
+        for (ap, ao), (bp, bo) in ((a_co, b_co), (a_di, b_di)):
+            assert (ao == bo).all() and (ap.view(np.uint32) == bp.view(np.uint32)).all(), f"k={k} thr={thr}: two-phase and exact kNN split differ"
+
+
+def test_voxel_sort_on_compressed_keys_equals_full_keys_at_full_size(ltm, full):
+    """the voxel grid's radix sort leaves out Morton bits that cannot decide a comparison inside the cloud's bounding box (fewer passes):
+    same centroids, same order as the sort over all 3 * depth bits -- the 22 M-point merge of a session and its 0.05 / 0.4 m grids"""
+    out = {}
+    for comp in (1, 0):
+        ctx = _ctx(ltm, LTM_VOXEL_KEYBITS=comp)
+        scans, poses, cmap = _load(ctx, full)
+        coarse = ctx.voxel_centroid(cmap, 0.4)
+        again = ctx.voxel_centroid_batch([cmap, coarse], [0.05, 1.0])
+        out[comp] = [cmap.download(), coarse.download(), again[0].download(), again[1].download()]
+        ctx.close()
+    for a, b in zip(out[1], out[0]):
+        assert a.shape == b.shape and len(a) > 1000 and (a.view(np.uint32) == b.view(np.uint32)).all()
+
+
+def test_occlusion_culled_exact_images_equal_plain_launch_on_street_scene(ltm):
+    """large-map path of the exact-image kernel (near pairs first, coarse maximum of the partial image, far pairs covered by strictly
+    nearer returns dropped): reprojections and ND-mode labels must be those of the plain launch -- street scene, hdl-64e, 300 keyframes"""
+    import torch
+    from tools import synth
+    S = synth.make_session(1, 300, "hdl-64e", device="cuda:0", scene="street", kf_spacing=2.0)
+    torch.cuda.synchronize()
+    out = {}
+    for tag, env in (("occl", dict(LTM_OCCLUSION=1, LTM_OCCLUSION_MIN_PAIRS=0, LTM_OCCLUSION_STATS=1)), ("occl_near20", dict(LTM_OCCLUSION=1, LTM_OCCLUSION_MIN_PAIRS=0, LTM_OCCLUSION_RNEAR=20)),
+                     ("plain", dict(LTM_OCCLUSION=0))):
+        ctx = _ctx(ltm, **env)
+        scans, poses, cmap = _load(ctx, S)
+        rep = ctx.reproject(cmap, poses, 3.0)
+        lab = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda")
+        ctx.visibility_vote(cmap, rep, poses, 0, poses.n, 2.5, 0.1, 1, lab.data_ptr())      # mode 1 (ND): exact images
+        out[tag] = (rep.download(), lab.cpu().numpy())
+        ctx.close()
+    for tag in ("occl", "occl_near20"):
+        (a, ao), la = out[tag]
+        (b, bo), lb = out["plain"]
+        assert (ao == bo).all() and (a.view(np.uint32) == b.view(np.uint32)).all(), f"{tag}: reprojection differs from the plain launch"
+        assert (la == lb).all(), f"{tag}: ND labels differ"
+    assert out["plain"][0][1][-1] > 1_000_000
+

@@ -509,3 +509,47 @@ def test_tile_range_cull_on_a_long_street(gpu_ctx, orc):
     kept, flagged, got = gpu_ctx.visibility_partition(gpu_ctx.upload(cmap), gpu_ctx.upload_scans(S["scans"], S["offsets"]),
                                                       gpu_ctx.poses(S["poses"], S["inv"]), 2.5, 0.1, 0, want_labels=True)
     assert want.sum() > 0 and (got == want).all(), f"{(got != want).sum()} labels differ"
+
+
+def test_occlusion_culled_reprojection_matches_oracle(ltm, orc):
+    """the occlusion-culled launch of the exact-image kernel (forced on a small map: every pair beyond 8 m is a 'far' pair) against the
+    oracle's reprojection, bitwise -- street scene so that facades really hide what lies behind them"""
+    import os
+    from tools import synth
+    S = synth.to_numpy(synth.make_session(1, 12, "small", scene="street", kf_spacing=3.0))
+    cmap = orc.voxel_centroid(orc.merge_to_global(S["scans"], S["offsets"], S["poses"], np.eye(4)), 0.05)
+    want_pts, want_off = orc.reproject(cmap, S["inv"], np.eye(4), 50.0, 360.0, 3.0)
+    old = {k: os.environ.get(k) for k in ("LTM_OCCLUSION", "LTM_OCCLUSION_MIN_PAIRS", "LTM_OCCLUSION_RNEAR")}
+    os.environ.update(LTM_OCCLUSION="1", LTM_OCCLUSION_MIN_PAIRS="0", LTM_OCCLUSION_RNEAR="8")
+    try:
+        ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    got_pts, got_off = ctx.reproject(ctx.upload(cmap), ctx.poses(S["poses"], S["inv"]), 3.0).download()
+    assert (got_off == want_off).all()
+    assert_clouds_equal(got_pts, want_pts, "occlusion-culled reprojection")
+    want = orc.vote_labels(cmap, want_pts, want_off, S["inv"], np.eye(4), 50.0, 360.0, 2.5, 0.1, 1)
+    scans = ctx.upload_scans(want_pts, want_off)
+    labels = ctx.visibility_partition(ctx.upload(cmap), scans, ctx.poses(S["poses"], S["inv"]), 2.5, 0.1, 1, want_labels=True)[2]
+    assert (labels == want).all(), "ND-mode labels with the occlusion-culled exact images differ from the oracle"
+    ctx.close()
+
+
+def test_repeated_votes_over_shrinking_maps_match_oracle(gpu_ctx, orc, small_pair):
+    """second and third vote of the same scans at the same resolution over shrinking, re-gridded maps (the pattern of selfRemovert; the
+    scan images and bound images are served from the context's cache) against the oracle"""
+    C, _ = small_pair
+    cmap = orc.voxel_centroid(orc.merge_to_global(C["scans"], C["offsets"], C["poses"], np.eye(4)), 0.05)
+    scans = gpu_ctx.upload_scans(C["scans"], C["offsets"])
+    poses = gpu_ctx.poses(C["poses"], C["inv"])
+    cur = cmap
+    for it in range(3):
+        assert len(cur) > 4096
+        want = orc.vote_labels(cur, C["scans"], C["offsets"], C["inv"], np.eye(4), 50.0, 360.0, 2.5, 0.1, 0)
+        got = gpu_ctx.visibility_partition(gpu_ctx.upload(cur), scans, poses, 2.5, 0.1, 0, want_labels=True)[2]
+        assert (got == want).all(), f"vote {it}: {(got != want).sum()} labels differ"
+        keep = want == 0
+        keep[::97] = True          # keep a few flagged points too, drop a few unflagged ones
+        keep[5::89] = False
+        cur = orc.voxel_centroid(cur[keep], 0.05)

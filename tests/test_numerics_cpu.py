@@ -59,3 +59,48 @@ def test_outputs_are_insensitive_to_the_unpinned_last_bits(orc):
     at = out["atan2f_1ulp_every_call"]
     assert at["points_compared"] > 100_000
     assert at["fraction"] <= 2e-3, f"+-1 ulp on every atan2f moved {at['points_differing']} of {at['points_compared']} output points"
+
+
+def test_voxel_sort_key_compression_preserves_order_and_equality(ltm):
+    """the voxel grid sorts on a Morton code with the bits left out that are functions of more significant bits inside the cloud's bounding
+    box (ltm_debug_voxel_key_bits): for random boxes and random points in them the compressed code must order and group the points exactly
+    like the full code, and the lot-shaped box must save at least one 8-bit radix pass"""
+    rng = np.random.default_rng(8)
+
+    def spread3(v):
+        out = np.zeros_like(v, dtype=np.uint64)
+        for b in range(21):
+            out |= ((v >> np.uint64(b)) & np.uint64(1)) << np.uint64(3 * b)
+        return out
+
+    def pext(code, mask):
+        out = np.zeros_like(code); o = 0
+        for b in range(63):
+            if (mask >> b) & 1:
+                out |= ((code >> np.uint64(b)) & np.uint64(1)) << np.uint64(o); o += 1
+        return out
+
+    boxes = [((-60.0, -40.0, -0.3), (60.0, 40.0, 10.2), 0.05), ((0.0, 0.0, 0.0), (1.0, 1.0, 1.0), 0.4), ((-3.1, 2.0, -7.0), (-3.1, 2.0, -7.0), 0.05)]
+    for _ in range(40):
+        c = rng.uniform(-300, 300, 3); e = rng.uniform(0.01, 1.0, 3) * rng.choice([1.0, 30.0, 250.0], 3)
+        boxes.append((tuple(c - e), tuple(c + e), float(rng.choice([0.05, 0.1, 0.4, 1.0]))))
+    saved_lot = None
+    for mn, mx, leaf in boxes:
+        mn, mx = np.float32(mn), np.float32(mx)
+        nbits, mask, depth, fmin = ltm.voxel_key_bits(mn, mx, leaf)
+        assert nbits == bin(mask).count("1") or (nbits == 1 and mask == 0)
+        assert mask < (1 << (3 * depth))
+        pts = rng.uniform(mn.astype(np.float64), mx.astype(np.float64), (4000, 3)).astype(np.float32)
+        pts = np.clip(pts, mn, mx)
+        pts[:8] = [[mn[0], mn[1], mn[2]], [mx[0], mx[1], mx[2]], [mn[0], mx[1], mn[2]], [mx[0], mn[1], mx[2]], [mn[0], mn[1], mx[2]], [mx[0], mx[1], mn[2]],
+                   [mn[0], mx[1], mx[2]], [mx[0], mn[1], mn[2]]]
+        k = ((pts.astype(np.float64) - fmin) / np.float64(np.float32(leaf))).astype(np.uint64)
+        assert (k < (1 << depth)).all()
+        full = (spread3(k[:, 0]) << np.uint64(2)) | (spread3(k[:, 1]) << np.uint64(1)) | spread3(k[:, 2])
+        comp = pext(full, mask)
+        o = np.argsort(full, kind="stable")
+        assert (np.argsort(comp, kind="stable") == o).all(), f"order changed for box {mn} {mx} leaf {leaf}"
+        assert ((np.diff(full[o]) == 0) == (np.diff(comp[o]) == 0)).all(), "voxel boundaries changed"
+        if saved_lot is None:
+            saved_lot = 3 * depth - nbits
+    assert saved_lot >= 4, f"a 120 x 80 x 10.5 m map at 0.05 m: {saved_lot} of 36 bits dropped (expected the z bits tied to the top bit)"
