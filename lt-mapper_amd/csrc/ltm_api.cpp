@@ -651,7 +651,7 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
         LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream));
         return;
     }
-    const size_t rbs = ((size_t)g.rows + 7) / 8, cbs = ((size_t)g.cols + 7) / 8;
+    const size_t rbs = (size_t)g.rows, cbs = ((size_t)g.cols + 7) / 8;
     // scratch of the cull lives with the context (grown on demand): the stage runs dozens of times per step with the same sizes, and
     // taking it from the pool every time changes which blocks the stages around it find there
     const size_t tbytes = scan_temp_bytes(n_pairs);
@@ -1032,7 +1032,7 @@ struct KnnIndex {
     ltm_ctx* c;
     float4* sorted = nullptr; HashEntry* table = nullptr; uint32_t mask = 0; KnnGrid g{}; float cell2_lo = 0; size_t Mt = 0;
     void* buckets = nullptr; uint32_t n_buckets = 0;      // phase-1 table of the two-phase query (k <= 4), see ltm_kernels.hip
-    uint32_t* bitmap = nullptr;                           // occupancy bitmap of the grid (phase 2 skips empty cells), may stay null
+    void* bitmap = nullptr; uint32_t bitmap_mask = 0;     // sparse occupancy bitmap of the grid (phase 2 skips empty cells)
     explicit KnnIndex(ltm_ctx* c_) : c(c_) {}
     ~KnnIndex() { c->pool.free(sorted); c->pool.free(table); c->pool.free(buckets); c->pool.free(bitmap); }
     void build(const Cloud& target, int k, float thr)
@@ -1088,11 +1088,13 @@ struct KnnIndex {
             buckets = c->pool.alloc((size_t)n_buckets * 64);
             LTM_HIP(hipMemsetAsync(buckets, 0xff, (size_t)n_buckets * 64, c->stream));
             LTM_HIP(knn_bucket_build(sorted, keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, Mt, g, buckets, n_buckets, c->stream));
-            if (ncells <= 2147483648.0 && c->knn_two_phase != 2) {      // LTM_KNN_FAST=2: buckets only (A/B)
-                const size_t words = ((size_t)ncells + 31) / 32 + 1;
-                bitmap = reinterpret_cast<uint32_t*>(c->pool.alloc(words * 4));
-                LTM_HIP(hipMemsetAsync(bitmap, 0, words * 4, c->stream));
-                LTM_HIP(knn_bitmap_build(keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, g, bitmap, c->stream));
+            if (c->knn_two_phase != 2) {      // LTM_KNN_FAST=2: no occupancy bitmap (A/B)
+                size_t words = 1024;
+                while (words < ncell / 4 && words < ((size_t)1 << 30)) words <<= 1;      // a surface fills ~16 of a block's 64 cells: ~4 words per occupied block
+                bitmap_mask = (uint32_t)(words - 1);
+                bitmap = c->pool.alloc(words * 8);
+                LTM_HIP(hipMemsetAsync(bitmap, 0, words * 8, c->stream));
+                LTM_HIP(knn_bitmap_build(keys2.as<uint64_t>(), starts.as<uint32_t>(), ncell, g, bitmap, bitmap_mask, c->stream));
             }
         }
     }
@@ -2223,7 +2225,7 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
             {
                 ProfScope ps(c, "knn_query_p2", 0.0, 0.0);      // compaction + exact search of the undecided queries: its bytes are part of knn_query's algorithmic figure
                 LTM_HIP(knn_two_phase_exact(s.d, s.off_dev, kf_begin, kf_end, first, n, p.pose_dev, c->B2L, c->b2l_identity, index.sorted, index.Mt, index.g, index.table,
-                                            index.mask, index.bitmap, k, thr, index.cell2_lo, flag.as<uint8_t>(), pos.as<uint32_t>(), queue.as<uint32_t>(), count.as<uint32_t>(), temp.p, tb,
+                                            index.mask, index.bitmap, index.bitmap_mask, k, thr, index.cell2_lo, flag.as<uint8_t>(), pos.as<uint32_t>(), queue.as<uint32_t>(), count.as<uint32_t>(), temp.p, tb,
                                             c->stream));
             }
             if (c->knn_stats_on) {

@@ -47,7 +47,7 @@ void set_tile_cull(int v);
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                             HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
 // occlusion cull of the exact-image kernel on large maps (see ltm_kernels.hip): pair t = tile * nb + keyframe.  flags: n_tiles * nb bytes,
-// done: n_tiles * nb zeroed bytes, pos / list: n_tiles * nb uint32, count: one uint32, cmax: nb * ceil(rows/8) * ceil(cols/8) uint32, temp: scan_temp_bytes(n_tiles * nb)
+// done: n_tiles * nb zeroed bytes, pos / list: n_tiles * nb uint32, count: one uint32, cmax: nb * rows * ceil(cols/8) uint32, temp: scan_temp_bytes(n_tiles * nb)
 hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
                                  const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
                                  void* temp, size_t temp_bytes, hipStream_t s);
@@ -180,8 +180,9 @@ hipError_t knn_query_scans(const float4* scans, const uint64_t* offsets_dev, siz
 // compacted and searched exactly.  buckets: n_buckets x 64 bytes, initialised to 0xff; pos / queue: n_pts uint32 each; count: one uint32
 hipError_t knn_bucket_build(const float4* sorted_target, const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, size_t n_pts, KnnGrid g,
                             void* buckets, uint32_t n_buckets, hipStream_t s);
-// occupancy bitmap of the grid (one bit per cell, cell_id order): ceil(nx*ny*nz / 32) zeroed uint32 words; lets the exact search skip empty cells
-hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, KnnGrid g, uint32_t* bitmap, hipStream_t s);
+// sparse occupancy bitmap of the grid (4 x 4 x 4 cells per hashed 64-bit word): word_mask + 1 zeroed uint64 words (a power of two); lets the
+// exact search skip empty cells
+hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, KnnGrid g, void* occ_words, uint32_t word_mask, hipStream_t s);
 // phase 1: local_out for every query, coexist[i] = 1 (certainly coexist) / 0 (certainly diff: outside the grid) / 2 (undecided)
 hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
                               const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity, KnnGrid g, const void* buckets,
@@ -189,8 +190,8 @@ hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, 
 // phase 2: the undecided queries are compacted (scan + scatter) and searched exactly; *count = their number
 hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
                                const double* poses_dev, HostMat34 b2l, int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g,
-                               const HashEntry* table, uint32_t table_mask, const uint32_t* bitmap, int k, float thr, float cell2_lo, uint8_t* coexist, uint32_t* pos,
-                               uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s);
+                               const HashEntry* table, uint32_t table_mask, const void* bitmap, uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist,
+                               uint32_t* pos, uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g,
                            const HashEntry* table, uint32_t table_mask, int k, float thr, float cell2_lo,
                            uint8_t* near, hipStream_t s);

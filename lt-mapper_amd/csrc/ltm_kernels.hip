@@ -992,15 +992,15 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // its ~130 instructions per point for all of them (reproject_map 484 of 887 ms per step).  Now, per batch of keyframes:
 //   1. the pairs are visited in SHELLS of sensor-to-tile distance (r_near, 2 r_near, 4 r_near, ...); the first shell is projected as it
 //      is (list-driven k_map_rimg_blockmin);
-//   2. before every later shell a coarse image holds, per 8 x 8 pixel block, the LARGEST range of the image built so far (an empty
-//      pixel counts as 10000);
+//   2. before every later shell a coarse image holds, per run of 8 pixels of an image row, the LARGEST range of the image built so far
+//      (an empty pixel counts as 10000);
 //   3. a pair of that shell is dropped iff every coarse block its bounding sphere can touch is covered by returns strictly nearer
 //      than the sphere's nearest point: none of its points can then be the arg-min of any pixel (ties need an equal range, excluded
 //      by the strict comparison with margins), so the final image is bit-identical; the others are projected and become occluders of
 //      the shells behind them (a facade 80 m away hides what a single near / far split at 60 m could not).
 // The sphere's pixel rectangle is conservative: centre direction from the float transform (1e-5 rad), angular radius asin(rho / d)
 // enlarged, +-1 pixel, rows clamped like the reference clamps elevations; spheres that straddle the +-180 deg seam, reach above 80 deg
-// of elevation, are nearer than two radii or touch more than 64 blocks are simply kept.
+// of elevation, are nearer than two radii or touch more than 256 coarse entries are simply kept.
 struct SphereRect { int r0, r1, c0, c1; float d_lo; bool cullable; };
 __device__ __forceinline__ SphereRect sphere_rect(const RimgGeom& g, const float* __restrict__ ap, const float* __restrict__ tb)
 {
@@ -1058,28 +1058,29 @@ k_pair_shell_select(const float* __restrict__ approx_poses, uint32_t kb, uint32_
     if (!(d2 >= r_lo * r_lo && d2 < r_hi * r_hi)) { flags[t] = 0; return; }
     bool live = true;
     if (cmax && sr.cullable) {
-        const int rb0 = sr.r0 >> 3, rb1 = sr.r1 >> 3, cb0 = sr.c0 >> 3, cb1 = sr.c1 >> 3;
-        if ((rb1 - rb0 + 1) * (cb1 - cb0 + 1) <= 64) {
+        const int cb0 = sr.c0 >> 3, cb1 = sr.c1 >> 3;
+        if ((sr.r1 - sr.r0 + 1) * (cb1 - cb0 + 1) <= 256) {
             uint32_t m = 0;
-            for (int rb = rb0; rb <= rb1; ++rb)
-                for (int cb = cb0; cb <= cb1; ++cb) m = max(m, cmax[((size_t)kfb * rbs + rb) * cbs + cb]);
+            for (int r = sr.r0; r <= sr.r1; ++r)
+                for (int cb = cb0; cb <= cb1; ++cb) m = max(m, cmax[((size_t)kfb * rbs + r) * cbs + cb]);
             live = !(u2f(m) < sr.d_lo);
         }
     }
     done[t] = 1;
     flags[t] = live ? 1 : 0;
 }
-// cmax[kfb][rb][cb] = largest range bits of the pixels of the 8 x 8 block (positive floats order like their bits; empty = 10000)
+// cmax[kfb][row][cb] = largest range bits of the 8 pixels cb*8 .. cb*8+7 of one image row (positive floats order like their bits; empty =
+// 10000).  Row-granular on purpose: the rows just above what near facades were mapped at stay empty until far tiles fill them, and an
+// 8 x 8 block would let those rows keep every far tile near the horizon alive.
 __global__ void __launch_bounds__(kBlock)
-k_coarse_max(const uint64_t* __restrict__ img, uint32_t rows, uint32_t cols, uint32_t rbs, uint32_t cbs, uint32_t nb, uint32_t* __restrict__ cmax)
+k_coarse_max(const uint64_t* __restrict__ img, uint32_t rows, uint32_t cols, uint32_t cbs, uint32_t nb, uint32_t* __restrict__ cmax)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= nb * rbs * cbs) return;
-    const uint32_t cb = t % cbs, rb = (t / cbs) % rbs, kfb = t / (cbs * rbs);
-    const uint64_t* __restrict__ im = img + (size_t)kfb * rows * cols;
+    if (t >= nb * rows * cbs) return;
+    const uint32_t cb = t % cbs, r = (t / cbs) % rows, kfb = t / (cbs * rows);
+    const uint64_t* __restrict__ im = img + ((size_t)kfb * rows + r) * cols;
     uint32_t m = 0;
-    for (uint32_t r = rb * 8; r < min(rows, rb * 8 + 8); ++r)
-        for (uint32_t cc = cb * 8; cc < min(cols, cb * 8 + 8); ++cc) m = max(m, (uint32_t)(im[(size_t)r * cols + cc] >> 32));
+    for (uint32_t cc = cb * 8; cc < min(cols, cb * 8 + 8); ++cc) m = max(m, (uint32_t)(im[cc] >> 32));
     cmax[t] = m;
 }
 struct FlagIs { uint8_t v; __host__ __device__ uint32_t operator()(uint8_t f) const { return f == v ? 1u : 0u; } };
@@ -1099,8 +1100,8 @@ hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_
                                  void* temp, size_t temp_bytes, hipStream_t s)
 {
     const uint32_t n = (uint32_t)(n_tiles * nb);
-    const uint32_t rbs = (uint32_t)(g.rows + 7) / 8, cbs = (uint32_t)(g.cols + 7) / 8;
-    if (use_cmax) k_coarse_max<<<dim3(grid_for((size_t)nb * rbs * cbs)), dim3(kBlock), 0, s>>>(img, (uint32_t)g.rows, (uint32_t)g.cols, rbs, cbs, (uint32_t)nb, cmax);
+    const uint32_t rbs = (uint32_t)g.rows, cbs = (uint32_t)(g.cols + 7) / 8;
+    if (use_cmax) k_coarse_max<<<dim3(grid_for((size_t)nb * rbs * cbs)), dim3(kBlock), 0, s>>>(img, (uint32_t)g.rows, (uint32_t)g.cols, cbs, (uint32_t)nb, cmax);
     k_pair_shell_select<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(approx_poses_dev, (uint32_t)kb, (uint32_t)nb, tile_bounds_dev, (uint32_t)n_tiles, g, r_lo, r_hi,
                                                                 use_cmax ? cmax : nullptr, rbs, cbs, done, flags);
     auto it = rocprim::make_transform_iterator(flags, FlagIs{1});
@@ -1979,6 +1980,18 @@ hipError_t hash_build(const uint64_t* sorted_keys, const uint32_t* starts, size_
     return hipGetLastError();
 }
 
+// sparse occupancy bitmap of the kNN grid (see k_knn_bitmap_build)
+__device__ __forceinline__ uint32_t occ_word_of(uint32_t bx, uint32_t by, uint32_t bz, uint32_t mask)
+{
+    uint32_t h = bx * 0x9e3779b1u ^ (by * 0x85ebca6bu + 0x165667b1u) ^ (bz * 0xc2b2ae35u);
+    h ^= h >> 15; h *= 0x2c1b3c6du; h ^= h >> 12;
+    return h & mask;
+}
+__device__ __forceinline__ bool occ_test(const unsigned long long* __restrict__ occ, uint32_t mask, int x, int y, int z)
+{
+    const unsigned long long w = occ[occ_word_of((uint32_t)x >> 2, (uint32_t)y >> 2, (uint32_t)z >> 2, mask)];
+    return ((w >> ((((uint32_t)x & 3u) << 4) | (((uint32_t)y & 3u) << 2) | ((uint32_t)z & 3u))) & 1ull) != 0ull;
+}
 static constexpr int kMaxK = 16;
 
 // returns the coexist/near predicate of Session.cpp:590-599 for a global-frame query point.
@@ -1987,7 +2000,7 @@ static constexpr int kMaxK = 16;
 template <int KT>
 __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const float4* __restrict__ tgt, size_t Mt, const KnnGrid& g,
                                          const HashEntry* __restrict__ table, uint32_t mask, int k_param, float thr, float cell2_lo,
-                                         const uint32_t* __restrict__ bitmap = nullptr)
+                                         const unsigned long long* __restrict__ bitmap = nullptr, uint32_t bitmap_mask = 0)
 {
     if (Mt == 0) return false;                        // reference: undefined; defined here as "far"
     const int k = KT ? KT : (int)min((size_t)k_param, Mt);      // pcl::KdTreeFLANN::nearestKSearch clamps k
@@ -2061,7 +2074,7 @@ __device__ __forceinline__ bool knn_near(float qx, float qy, float qz, const flo
             key = ((uint64_t)(uint32_t)x * (uint32_t)ny + (uint32_t)y) * (uint32_t)nz + (uint32_t)z;   // == cell_id()
             const bool in = !((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz);
             if (!bitmap || !in) return in;
-            return ((bitmap[key >> 5] >> (key & 31u)) & 1u) != 0u;
+            return occ_test(bitmap, bitmap_mask, x, y, z);
         };
         {   // the centre cell alone: most queries of a static scene end here
             uint64_t key;
@@ -2224,23 +2237,25 @@ hipError_t knn_bucket_build(const float4* sorted_target, const uint64_t* sorted_
     return hipGetLastError();
 }
 
-// Occupancy bitmap of the grid, one bit per cell (cell_id order: z fastest): the exact search tests it before it probes the hash table,
-// so the empty cells among the 27 -- most of them around the sparse, far-from-the-trajectory points that make up the bulk of the
-// "diff" answers -- cost a bit test in a 5 MB array (120 x 80 x 12 m lot at the yaml cell size) instead of a 64-byte line of the table each.
-// Not built above 2^31 cells (then every cell is probed, as before).
+// Sparse occupancy bitmap of the grid: the cells are grouped in blocks of 4 x 4 x 4, a block's 64 occupancy bits live in ONE 64-bit word
+// found by hashing the block coordinates (no keys, no probing: two blocks that share a word see the OR of their bits, i.e. at worst a
+// few false "occupied" answers, never a false "empty").  The exact search tests it before it probes the hash table, so the empty
+// cells among the 27 -- most of them around the sparse, far-from-the-trajectory points that make up the bulk of the "diff" answers --
+// cost a bit test in a word that neighbouring cells and neighbouring lanes share instead of a 64-byte line of the table each.
+// Sized at two words per occupied cell / 8 (>= 4 words per occupied block on surfaces), any scene extent.
 __global__ void __launch_bounds__(kBlock)
-k_knn_bitmap_build(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ starts, size_t n_cells, uint32_t* __restrict__ bitmap)
+k_knn_bitmap_build(const uint64_t* __restrict__ sorted_keys, const uint32_t* __restrict__ starts, size_t n_cells, KnnGrid g, unsigned long long* __restrict__ occ, uint32_t mask)
 {
     const size_t u = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (u >= n_cells) return;
-    const uint64_t b = sorted_keys[starts[u]];
-    atomicOr(&bitmap[b >> 5], 1u << (b & 31u));
+    const uint64_t key = sorted_keys[starts[u]];
+    const uint32_t z = (uint32_t)(key % (uint64_t)g.nz), y = (uint32_t)((key / (uint64_t)g.nz) % (uint64_t)g.ny), x = (uint32_t)(key / ((uint64_t)g.nz * (uint64_t)g.ny));
+    atomicOr(&occ[occ_word_of(x >> 2, y >> 2, z >> 2, mask)], 1ull << (((x & 3u) << 4) | ((y & 3u) << 2) | (z & 3u)));
 }
-hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, KnnGrid g, uint32_t* bitmap, hipStream_t s)
+hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts, size_t n_cells, KnnGrid g, void* occ_words, uint32_t word_mask, hipStream_t s)
 {
-    (void)g;
     if (!n_cells) return hipSuccess;
-    k_knn_bitmap_build<<<dim3(grid_for(n_cells)), dim3(kBlock), 0, s>>>(sorted_keys, starts, n_cells, bitmap);
+    k_knn_bitmap_build<<<dim3(grid_for(n_cells)), dim3(kBlock), 0, s>>>(sorted_keys, starts, n_cells, g, reinterpret_cast<unsigned long long*>(occ_words), word_mask);
     return hipGetLastError();
 }
 
@@ -2328,7 +2343,7 @@ template <bool B2L_IDENTITY, int KT>
 __global__ void __launch_bounds__(kBlock)
 k_knn_slow(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
            const double* __restrict__ poses, HostMat34 b2l_h, const float4* __restrict__ tgt, size_t Mt, KnnGrid g,
-           const HashEntry* __restrict__ table, uint32_t mask, const uint32_t* __restrict__ bitmap, int k, float thr, float cell2_lo,
+           const HashEntry* __restrict__ table, uint32_t mask, const unsigned long long* __restrict__ bitmap, uint32_t bitmap_mask, int k, float thr, float cell2_lo,
            const uint32_t* __restrict__ queue, const uint32_t* __restrict__ count, uint8_t* __restrict__ coexist)
 {
     const uint32_t n = *count;
@@ -2340,7 +2355,7 @@ k_knn_slow(const float4* __restrict__ scans, const uint64_t* __restrict__ offset
         float3 p = make_float3(p4.x, p4.y, p4.z);
         if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
         const float3 gp = xform(load_mat(poses + 12 * kf), p);
-        coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo, bitmap) ? 1 : 0;
+        coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo, bitmap, bitmap_mask) ? 1 : 0;
     }
 }
 
@@ -2377,8 +2392,8 @@ hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, 
 
 hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
                                const double* poses_dev, HostMat34 b2l, int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g,
-                               const HashEntry* table, uint32_t table_mask, const uint32_t* bitmap, int k, float thr, float cell2_lo, uint8_t* coexist, uint32_t* pos,
-                               uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s)
+                               const HashEntry* table, uint32_t table_mask, const void* bitmap, uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist,
+                               uint32_t* pos, uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (!n_pts) return hipSuccess;
     if (k < 1 || k > 4 || Mt < (size_t)k) return hipErrorInvalidValue;
@@ -2389,7 +2404,8 @@ hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev,
     const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n_pts), 4096);
     auto slow = [&](auto b2l_tag, auto kt_tag) {
         k_knn_slow<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(blocks), dim3(kBlock), 0, s>>>(
-            scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, bitmap, k, thr, cell2_lo, queue, count, coexist);
+            scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, reinterpret_cast<const unsigned long long*>(bitmap), bitmap_mask, k, thr,
+            cell2_lo, queue, count, coexist);
     };
     auto by_kt = [&](auto b2l_tag) {
         switch (k) {
