@@ -15,7 +15,7 @@ COMMIT=$(cat "$ROOT/.commit_for_profiles" 2>/dev/null || echo unknown)
 
 # 1. kernel trace + stats of one step
 rm -rf /tmp/prof_kt
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o bench -- $BENCH --steps 1 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o bench -- $BENCH --steps 1 --warmup 0 --no-cpu-baseline --no-t-total 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_under_rocprof.json"
 f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
 python3 - "$f" "$OUT/${TAG}_rocprofv3_kernel_stats.csv" <<'PY'
 import csv, sys
@@ -29,7 +29,7 @@ PY
 # 2. HBM traffic (FETCH_SIZE, WRITE_SIZE) and VALU instruction count, each in its own pass
 for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
   rm -rf /tmp/prof_$C
-  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -o bench -- $BENCH --steps 1 --warmup 0 --no-cpu-baseline 2>/dev/null | tail -1 > /tmp/bench_$C.json
+  rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -o bench -- $BENCH --steps 1 --warmup 0 --no-cpu-baseline --no-t-total 2>/dev/null | tail -1 > /tmp/bench_$C.json
 done
 python3 - "$OUT/pmc_latest.json" "$ROOT" "$COMMIT" <<'PY'
 import csv, glob, json, sys, collections
@@ -51,7 +51,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
                 k = k.split("(")[0]
             e = agg[k][c]; e["sum"] += float(r["Counter_Value"]); e["dispatches"] += 1
 dom = next((k for k in agg if "k_vote_map_cull" in k), None)
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU, one pass each, on `python bench.py --steps 1 --warmup 0 --no-cpu-baseline`; "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU, one pass each, on `python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-t-total`; "
                "FETCH/WRITE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read stream); "
                "SQ_INSTS_VALU counts wave instructions (x64 lanes / point-projections = VALU instructions per point); sums over all dispatches of each kernel",
        "workload": bench.DEFAULT_WORKLOAD, "kernels_sha": bench.kernels_sha(), "commit": sys.argv[3], "dominant_kernel": "k_vote_map_cull"}
