@@ -117,6 +117,14 @@ def load_library(path=None):
     if _lib is not None and path is None:
         return _lib
     p = path or LIB_PATH
+    # Load order of the HIP runtime: torch ships its own libamdhip64 and this library links the system one (same soname).  Whichever is
+    # mapped first serves both; if OURS comes first and torch is imported later in the same process (build() followed by smoke()),
+    # torch initialises against a runtime it was not built with and ltm_create then finds no usable device.  Importing torch first --
+    # the order bench.py and the tests always had -- keeps one consistent runtime.  Without torch installed nothing changes.
+    try:
+        import torch  # noqa: F401
+    except Exception:
+        pass
     if not os.path.exists(p):
         raise FileNotFoundError(
             f"{p} not found: build it with `make hip` (or __graft_entry__.build()). There is no CPU fallback.")
