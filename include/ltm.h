@@ -264,6 +264,10 @@ int ltm_debug_voxel_key_bits(const float* mn3, const float* mx3, float leaf, uin
  * arithmetic: counts points (host xyz, n*3 floats; global frame if inv_pose16 is given, else local) whose exact pixel /
  * range fall outside its candidate set / bounds.  Must be 0. */
 int ltm_debug_cull_check(ltm_ctx*, const float* xyz, size_t n, const double* inv_pose16_or_null, float res_alpha, uint64_t* violations);
+/* diagnostic counters of the occlusion cull in front of the exact-image kernel on large maps (reprojection, ND votes) since the
+ * last reset: (tile, keyframe) pairs seen by culled launches, pairs of the first distance shell, pairs projected in all (the rest was
+ * proven hidden and dropped) */
+int ltm_debug_occlusion_stats(ltm_ctx*, uint64_t* pairs, uint64_t* first_shell, uint64_t* projected, int reset);
 /* diagnostic counters of the range-culled vote kernel since the last reset: points tested / points that needed the exact path */
 int ltm_debug_cull_stats(ltm_ctx*, uint64_t* survivors, uint64_t* points, int reset);
 

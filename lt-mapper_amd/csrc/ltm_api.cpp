@@ -2414,6 +2414,16 @@ int ltm_debug_voxel_key_bits(const float* mn3, const float* mx3, float leaf, uin
     return (int)kc.bits;
 }
 
+int ltm_debug_occlusion_stats(ltm_ctx* c, uint64_t* pairs, uint64_t* first_shell, uint64_t* projected, int reset)
+{
+    return guarded(c, [&] {
+        if (pairs) *pairs = c->occl_pairs;
+        if (first_shell) *first_shell = c->occl_near;
+        if (projected) *projected = c->occl_far_live;
+        if (reset) { c->occl_pairs = 0; c->occl_near = 0; c->occl_far_live = 0; }
+    });
+}
+
 int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad)
 {
     if (!c4 || !max_err_rad || !(vfov_deg > 0.0f) || !(vfov_deg < 180.0f)) return LTM_E_INVALID;

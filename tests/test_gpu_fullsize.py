@@ -189,3 +189,33 @@ def test_occlusion_culled_exact_images_equal_plain_launch_on_street_scene(ltm):
         assert (la == lb).all(), f"{tag}: ND labels differ"
     assert out["plain"][0][1][-1] > 1_000_000
 
+
+
+def test_occlusion_cull_drops_hidden_tiles_and_keeps_the_image_at_kitti_scale(ltm):
+    """configs[3] geometry at its real extent: 2000 keyframes of the hdl-64e sensor over the street grid, 45 M-point map = 11 000 tiles.  With
+    the keyframes' (tile, keyframe) pairs above the cull's threshold the DEFAULT path of ltm_reproject is the occlusion-culled one; it must
+    (a) really drop a large share of the pairs -- the parity runs against the oracle are too small for buildings to hide much -- and
+    (b) give exactly the reprojection of the plain launch, for keyframes at the start and in the middle of the trajectory."""
+    import torch
+    from tools import synth
+    S = synth.make_session(1, 2000, "hdl-64e", device="cuda:0", scene="street", kf_spacing=1.0)
+    torch.cuda.synchronize()
+    out, stats = {}, None
+    for occl in (1, 0):
+        ctx = _ctx(ltm, LTM_OCCLUSION=occl)
+        scans, poses, cmap = _load(ctx, S)
+        assert len(cmap) > 30_000_000
+        parts = []
+        for a, b in ((0, 256), (1000, 1256)):
+            parts.append(ctx.reproject(cmap, poses, 3.0, a, b).download())
+        if occl:
+            stats = ctx.occlusion_stats()
+        out[occl] = parts
+        ctx.close()
+    pairs, first, projected = stats
+    assert pairs > 4_000_000, "the culled path was not taken"
+    dropped = 1.0 - projected / pairs
+    print(f"occlusion cull at KITTI scale: {pairs} pairs, {first / pairs:.1%} in the first shell, {dropped:.1%} dropped")
+    assert dropped > 0.25, f"only {dropped:.1%} of the (tile, keyframe) pairs were proven hidden"
+    for (ap, ao), (bp, bo) in zip(out[1], out[0]):
+        assert (ao == bo).all() and (ap.view(np.uint32) == bp.view(np.uint32)).all(), "occlusion-culled reprojection differs from the plain launch"

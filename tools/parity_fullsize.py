@@ -180,7 +180,7 @@ def run_parity(config=1, kf=None, threads=None, device="cuda:0"):
             "scan_points": [int(c["offsets"][-1]) for c in cpu], "gpu_run_s": round(t_gpu, 3), "oracle_run_s": round(t_cpu, 1),
             "oracle_threads": threads, "outputs_compared": len(report), "outputs_differing": bad,
             "product_sha": provenance.product_sha(), "kernels_sha": provenance.kernels_sha(), "oracle_sha": provenance.oracle_sha(), "commit": commit,
-            "outputs": report}
+            "env": {k: v for k, v in os.environ.items() if k.startswith("LTM_")}, "outputs": report}
 
 
 def main():
