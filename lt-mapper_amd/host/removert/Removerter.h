@@ -65,18 +65,18 @@ public:
     std::pair<CloudPtr, CloudPtr> partitionCurrentMapForND(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
     std::pair<CloudPtr, CloudPtr> partitionCurrentMapForPD(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
 
-    void removeOnce(Session& _target_sess, const Session& _source_sess, float _res_alpha);
-    void revertOnce(Session& _target_sess, const Session& _source_sess, float _res_alpha);
-    void resetCurrrentMapAsDynamic(Session& _sess, bool _as_dynamic);
-    void resetCurrrentMapAsDynamic(Session& _sess);
-    void resetCurrrentMapAsStatic(Session& _sess);
-    void selfRemovert(Session& _sess, int _repeat);
+    void removeOnce(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void revertOnce(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void resetCurrrentMapAsDynamic(const Session& _sess, bool _as_dynamic);
+    void resetCurrrentMapAsDynamic(const Session& _sess);
+    void resetCurrrentMapAsStatic(const Session& _sess);
+    void selfRemovert(const Session& _sess, int _repeat);
     void removeHighDynamicPoints(void);
 
     void filterStrongND(Session& _sess_src, Session& _sess_cleaner);
-    void iremoveOnceForND(Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void iremoveOnceForND(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
     void filterStrongPD(Session& _sess_src, Session& _sess_cleaner);
-    void removeOnceForPD(Session& _target_sess, const Session& _source_sess, float _res_alpha);
+    void removeOnceForPD(const Session& _target_sess, const Session& _source_sess, float _res_alpha);
     void detectLowDynamicPoints(void);
 
     void updateCurrentMap(void);

@@ -99,10 +99,13 @@ public:
     ScansPtr keyframe_scans_updated_, keyframe_scans_updated_strong_, keyframe_scans_pd_, keyframe_scans_strong_pd_,
         keyframe_scans_strong_nd_, keyframe_scans_weak_nd_;
 
-    CloudPtr map_global_orig_, map_global_curr_, map_global_curr_static_, map_global_curr_dynamic_;
-    CloudPtr map_global_updated_, map_global_updated_strong_;
-    CloudPtr map_global_nd_, map_global_nd_strong_, map_global_nd_weak_;
-    CloudPtr map_global_pd_, map_global_pd_orig_, map_global_pd_strong_, map_global_pd_weak_;
+    // `mutable`: the reference changes these maps through `const Session&` parameters (Removerter.h:81,103-111,175,181) -- legal there because
+    // the members are boost::shared_ptr and only the pointees are written (`*a = *b`); here `*a = *b` is a re-bound device handle, so the
+    // members themselves must be writable through a const reference for the signatures to stay verbatim
+    mutable CloudPtr map_global_orig_, map_global_curr_, map_global_curr_static_, map_global_curr_dynamic_;
+    mutable CloudPtr map_global_updated_, map_global_updated_strong_;
+    mutable CloudPtr map_global_nd_, map_global_nd_strong_, map_global_nd_weak_;
+    mutable CloudPtr map_global_pd_, map_global_pd_orig_, map_global_pd_strong_, map_global_pd_weak_;
 
     void loadSessionInfo(std::string _sess_type, std::string _scan_dir, std::string _pose_path);   // Session.cpp:80-118
     void setDownsampleSize(float _voxel_size);

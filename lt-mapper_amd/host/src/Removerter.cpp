@@ -230,7 +230,7 @@ std::pair<CloudPtr, CloudPtr> Removerter::partitionCurrentMapForPD(const Session
 
 static CloudPtr append(const Session& s, const CloudPtr& a, const CloudPtr& b) { return a ? s.concat({a, b}) : s.concat({b}); }
 
-void Removerter::removeOnce(Session& t, const Session& src, float _res_alpha)      // Removerter.cpp:882-905
+void Removerter::removeOnce(const Session& t, const Session& src, float _res_alpha)      // Removerter.cpp:882-905
 {
     LTM_INFO("\nSelf-removing starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMap(t, src, _res_alpha);
@@ -242,7 +242,7 @@ void Removerter::removeOnce(Session& t, const Session& src, float _res_alpha)   
     LTM_INFO(" Current Dynamic pointcloud have: " << t.map_global_curr_dynamic_->size() << " points.");
 }
 
-void Removerter::revertOnce(Session& t, const Session& src, float _res_alpha)      // Removerter.cpp:908-931
+void Removerter::revertOnce(const Session& t, const Session& src, float _res_alpha)      // Removerter.cpp:908-931
 {
     LTM_INFO("\nSelf-reverting starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMap(t, src, _res_alpha);
@@ -254,14 +254,14 @@ void Removerter::revertOnce(Session& t, const Session& src, float _res_alpha)   
     LTM_INFO(" Current Static pointcloud have: " << t.map_global_curr_static_->size() << " points.");
 }
 
-void Removerter::resetCurrrentMapAsDynamic(Session& _sess, bool _as_dynamic)       // Removerter.cpp:714-737
+void Removerter::resetCurrrentMapAsDynamic(const Session& _sess, bool _as_dynamic)       // Removerter.cpp:714-737
 {
     _sess.map_global_curr_ = _as_dynamic ? _sess.map_global_curr_dynamic_ : _sess.map_global_curr_static_;
 }
-void Removerter::resetCurrrentMapAsDynamic(Session& _sess) { resetCurrrentMapAsDynamic(_sess, true); }
-void Removerter::resetCurrrentMapAsStatic(Session& _sess) { resetCurrrentMapAsDynamic(_sess, false); }
+void Removerter::resetCurrrentMapAsDynamic(const Session& _sess) { resetCurrrentMapAsDynamic(_sess, true); }
+void Removerter::resetCurrrentMapAsStatic(const Session& _sess) { resetCurrrentMapAsDynamic(_sess, false); }
 
-void Removerter::selfRemovert(Session& _sess, int _repeat = 1)                     // Removerter.cpp:1378-1393
+void Removerter::selfRemovert(const Session& _sess, int _repeat = 1)                     // Removerter.cpp:1378-1393
 {
     for (float _res : remove_resolution_list_) {
         for (int i = 0; i < _repeat; i++) {
@@ -302,7 +302,7 @@ void Removerter::removeHighDynamicPoints(void)                                  
     LTM_INFO(" high dynamic maps are saved. ");
 }
 
-void Removerter::iremoveOnceForND(Session& t, const Session& src, float _res_alpha)   // Removerter.cpp:831-854
+void Removerter::iremoveOnceForND(const Session& t, const Session& src, float _res_alpha)   // Removerter.cpp:831-854
 {
     LTM_INFO("\nIdentifying Strong/Weak ND points starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMapForND(t, src, _res_alpha);
@@ -311,7 +311,7 @@ void Removerter::iremoveOnceForND(Session& t, const Session& src, float _res_alp
     t.map_global_nd_ = t.map_global_nd_strong_;
     t.map_global_nd_weak_ = ds[1];
 }
-void Removerter::removeOnceForPD(Session& t, const Session& src, float _res_alpha)    // Removerter.cpp:856-880
+void Removerter::removeOnceForPD(const Session& t, const Session& src, float _res_alpha)    // Removerter.cpp:856-880
 {
     LTM_INFO("\nIdentifying Strong/Weak PD points starts ");
     auto [static_tt, dynamic_tt] = partitionCurrentMapForPD(t, src, _res_alpha);
