@@ -21,6 +21,9 @@ class OScans:
     def download(self):
         return self.pts, self.off
 
+    def info(self):
+        return len(self.off) - 1, int(self.off[-1])
+
 
 class OCloud(np.ndarray):
     def download(self):
@@ -58,6 +61,12 @@ class OracleOps:
     def voxel_scanset(self, s, leaf):
         parts = [orc.voxel_centroid(s.pts[int(s.off[k]):int(s.off[k + 1])], leaf) for k in range(len(s.off) - 1)]
         return self._pack(parts)
+
+    def voxel_grid_scanset(self, s, leaf):      # the loader's pcl::VoxelGrid per keyframe (Session.cpp:284-289)
+        return self._pack([orc.voxel_grid(s.pts[int(s.off[k]):int(s.off[k + 1])], leaf) for k in range(len(s.off) - 1)])
+
+    def preclean(self, s, radius):              # Session.cpp:506-533
+        return self._pack([orc.preclean(s.pts[int(s.off[k]):int(s.off[k + 1])], radius) for k in range(len(s.off) - 1)])
 
     @staticmethod
     def _pack(parts):

@@ -161,3 +161,105 @@ def test_bench_roofline_helpers_on_a_synthetic_profile():
     assert bench.traffic_groups({}, prof, 1) == []
     st = bench.parity_fullsize_status()
     assert set(st) >= {"record", "matches_sources"}
+
+
+def _oracle_cascade_chain(orc, S):
+    """the reference's lifelong loop on the oracle: run j+1's central session = run j's scans_updated re-loaded (VoxelGrid + pre-clean 2.5)"""
+    refs, central = [], S[0]
+    for j in range(1, len(S)):
+        ref = orc.pipeline_run(orc.make_params(), central, S[j])
+        refs.append(ref)
+        pts, off = ref.scanset("scans_updated")
+        re_pts, re_off = [], [0]
+        for k in range(len(off) - 1):
+            p = orc.preclean(orc.voxel_grid(pts[int(off[k]):int(off[k + 1])], 0.05), 2.5)
+            re_pts.append(p); re_off.append(re_off[-1] + len(p))
+        central = dict(scans=np.concatenate(re_pts), offsets=np.array(re_off, np.uint64), poses=S[0]["poses"], inv=S[0]["inv"])
+    return refs
+
+
+def _tiny_sessions(n):
+    from tools import synth
+    return [synth.to_numpy(synth.make_session(s, 4, "tiny")) for s in range(1, n + 1)]
+
+
+def _cascade_worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.cascade import run_cascade
+    from ltmapper_amd.dist import ShardedOps
+    from ltmapper_amd.removerter import Params
+    from oracle_ops import OPoses, OracleOps, OScans
+    S = _tiny_sessions(3)
+    sops = ShardedOps(OracleOps(), dist, rank, world)
+    sops.VOXEL_SHARD_MIN = 0
+    P = Params(gather_scan_outputs=True)
+    up = [(OScans(T["scans"], T["offsets"]), OPoses(T["poses"], T["inv"])) for T in S]
+    runs = run_cascade(sops, P, up[0][0], up[0][1], up[1:])
+    res = []
+    for rm in runs:
+        res.append(({k: np.asarray(v.download()) for k, v in rm.outputs.items()},
+                    {k: tuple(np.asarray(x) for x in v.download()) for k, v in rm.scan_outputs().items()}))
+    q.put((rank, res))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_cascade_over_gloo_hands_over_the_reloaded_scans(orc):
+    """configs[2] in miniature on two ranks: the keyframe-sharded cascade (rank-local scans_updated go through the loader's VoxelGrid and
+    the pre-clean on their own rank) must equal the oracle chain on every rank, both pair runs"""
+    import queue
+    import time
+    import torch.multiprocessing as mp
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_cascade_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results, deadline = [], time.time() + 300
+    while len(results) < world:
+        try:
+            results.append(q.get(timeout=2))
+        except queue.Empty:
+            if any(p.exitcode not in (None, 0) for p in procs) or time.time() > deadline:
+                for p in procs:
+                    if p.is_alive():
+                        p.terminate()
+                pytest.fail("a rank died or timed out: exit codes %s" % [p.exitcode for p in procs])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    refs = _oracle_cascade_chain(orc, _tiny_sessions(3))
+    for rank, res in results:
+        assert len(res) == 2
+        for (out, scans), ref in zip(res, refs):
+            _check_against_oracle_pipeline(out, scans, ref)
+
+
+def test_comm_meter_counts_what_the_sharded_pipeline_would_exchange(orc):
+    """dist.CommMeter on a single process: one label all-reduce of M bytes per vote pass, a scan-set all-gather in front of every merge of
+    rank-local scans, none for the replicated session scans; the results are untouched; scaling_model turns the totals into step times"""
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.dist import CommMeter, scaling_model
+    from oracle_ops import OracleOps
+    C, Q = _tiny_pair()
+    meter = CommMeter(OracleOps())
+    out, scans = _run(meter, C, Q)
+    ref = orc.pipeline_run(orc.make_params(), C, Q)
+    _check_against_oracle_pipeline(out, scans, ref)
+    ev = meter.events
+    assert ev["label_allreduce"][0] == 2 + 3 + 3, "single-res: removeOnce x 2 sessions, 3 ND and 3 PD filter passes"
+    assert ev["label_allreduce"][1] > 0
+    assert ev["scans_allgather"][0] == 2 + 2 + 4, "HD dynamic scans x 2, ND / PD diff scans, and the four merges of the debug maps"
+    assert ev["voxel_allgather"][0] == 0, "tiny maps stay replicated"
+    m = scaling_model({"vote_map_cull": 70.0, "voxel": 20.0, "knn_query": 10.0}, 110.0, {k: (v[0], v[1]) for k, v in ev.items()})
+    assert m["sharded_ms"] == 80.0 and m["replicated_ms"] == 30.0
+    assert m["ranks"]["8"]["step_ms"] < m["ranks"]["2"]["step_ms"] < 110.0
