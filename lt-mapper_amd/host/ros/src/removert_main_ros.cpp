@@ -1,13 +1,16 @@
 // removert_main_ros.cpp -- ROS1 entry point of the MI355X build: same node name, parameter namespace and launch file as
 // ltremovert/src/removert_main.cpp:3-12, so `roslaunch removert run_ltmapper.launch` keeps working.
 //
-// NOT COMPILED IN THIS REPOSITORY'S CI: the build container has no ROS.  It is deliberately thin: it copies the 26
+// Not built for real in this repository (the build container has no ROS); tests/test_host_cpp.py compiles and links it against minimal
+// stand-ins for the roscpp / image_transport / sensor_msgs declarations it uses (tests/ros_stubs).  It is deliberately thin: it copies the 26
 // `removert/` parameters from the ROS parameter server into the YAML subset the ROS-free RosParamServer mirror reads,
 // then runs the same Removerter::run() as `ltm_run`.
 #include <image_transport/image_transport.h>
 #include <ros/ros.h>
 #include <sensor_msgs/Image.h>
 #include <sensor_msgs/image_encodings.h>
+
+#include <unistd.h>
 
 #include <cstdio>
 #include <fstream>

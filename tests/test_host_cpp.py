@@ -84,3 +84,22 @@ def test_loader_voxelgrid_equals_oracle_restatement(tmp_path, orc):
             assert got.shape == want.shape, f"{name} leaf {leaf}: {got.shape[0]} vs {want.shape[0]} points"
             assert (got.view(np.uint32) == want.view(np.uint32)).all(), f"{name} leaf {leaf}: values / order differ"
             assert (len(got) == len(pts)) == (name == "wide")
+
+
+def test_ros_wrapper_compiles_and_links_against_api_stubs(tmp_path):
+    """lt-mapper_amd/host/ros/src/removert_main_ros.cpp (the catkin node `removert_removert`) cannot be built for real here -- no ROS in the
+    image -- but it must at least stay in step with the host mirror it derives from: compile it against minimal stand-ins for the roscpp /
+    image_transport / sensor_msgs declarations it uses (tests/ros_stubs) and link it with the same sources CMakeLists.txt lists"""
+    import subprocess
+    host = os.path.join(ROOT, "lt-mapper_amd", "host")
+    src = [os.path.join(host, "ros", "src", "removert_main_ros.cpp")] + [os.path.join(host, "src", f) for f in
+          ("utility.cpp", "RosParamServer.cpp", "Session.cpp", "Removerter.cpp", "Comm.cpp")]
+    cm = open(os.path.join(host, "ros", "CMakeLists.txt")).read()
+    for f in ("utility.cpp", "RosParamServer.cpp", "Session.cpp", "Removerter.cpp", "Comm.cpp", "removert_main_ros.cpp"):
+        assert f in cm, f"{f} missing from the catkin target"
+    exe = str(tmp_path / "removert_removert")
+    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "tests", "ros_stubs"), "-I", host, "-I", os.path.join(ROOT, "include"),
+           "-o", exe] + src + ["-L", os.path.join(ROOT, "lt-mapper_amd"), "-lltm_hip", "-Wl,-rpath," + os.path.join(ROOT, "lt-mapper_amd"), "-Wl,-rpath,/opt/rocm/lib"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert os.path.exists(exe)
