@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--n", type=int, default=12)
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 1, 32))
+    ap.add_argument("--sensors", default="tiny,small", help="comma-separated tools.synth sensor names to draw from")
+    ap.add_argument("--kf", type=int, nargs=2, default=[4, 8], metavar=("MIN", "MAX"), help="keyframes per session, drawn uniformly")
     args = ap.parse_args()
     import numpy as np
     import ltmapper_amd  # noqa: F401
@@ -34,6 +36,7 @@ def main():
     from test_gpu_pipeline import MAPS
     rng = np.random.default_rng(args.seed)
     cases, bad_total = [], 0
+    occl = {"pairs": 0, "near": 0, "projected": 0}
     for it in range(args.n):
         vfov = float(rng.choice([50.0, 40.0, 30.0, 60.0, 90.0]))
         hfov = float(rng.choice([360.0, 360.0, 180.0]))
@@ -43,8 +46,8 @@ def main():
         thr = float(rng.choice([0.01, 0.003, 0.04, 0.1]))
         voxel = float(rng.choice([0.05, 0.05, 0.1, 0.2]))
         scene = str(rng.choice(["lot", "street"]))
-        sensor = str(rng.choice(["tiny", "small"]))
-        n_kf = int(rng.integers(4, 9))
+        sensor = str(rng.choice(args.sensors.split(",")))
+        n_kf = int(rng.integers(args.kf[0], args.kf[1] + 1))
         l2b = None
         if rng.integers(3) == 0:
             from scipy.spatial.transform import Rotation
@@ -67,6 +70,8 @@ def main():
         report = {}
         bad = _compare_run(np, rm, ref, MAPS, report)
         sel, fast = ctx.selfcheck() if hasattr(ctx, "selfcheck") else (None, None)
+        st = ctx.occlusion_stats()       # (tile, keyframe) pairs that went through the occlusion-culled launch, and how many were projected
+        for key, v in zip(("pairs", "near", "projected"), st): occl[key] += int(v)
         ref.free(); ctx.close()
         bad_total += bad
         cases.append(dict(desc, outputs_compared=len(report), outputs_differing=bad, differing=[n for n, v in report.items() if not v["identical"]],
@@ -75,7 +80,8 @@ def main():
     from tools import provenance
     print(json.dumps({"what": "randomised end-to-end parity, GPU (C ABI) vs CPU oracle, bitwise", "seed": args.seed, "cases": len(cases),
                       "cases_with_differences": sum(1 for c in cases if c["outputs_differing"]), "product_sha": provenance.product_sha(),
-                      "oracle_sha": provenance.oracle_sha(), "detail": cases}, indent=1))
+                      "oracle_sha": provenance.oracle_sha(), "sensors": args.sensors, "keyframes": args.kf,
+                      "env": {k: v for k, v in os.environ.items() if k.startswith("LTM_")}, "occlusion": occl, "detail": cases}, indent=1))
     sys.exit(1 if bad_total else 0)
 
 
