@@ -7,6 +7,7 @@
 #include <hip/hip_runtime_api.h>
 
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -441,7 +442,22 @@ void approx_pose(const double* b2l16, const double* inv16, float* out)
         }
         gmin = std::min(gmin, diag - off);
     }
-    const double smin = gmin > 0.25 ? std::sqrt(gmin) * (1.0 - 1e-6) : 0.0;
+    double smin = gmin > 0.25 ? std::sqrt(gmin) * (1.0 - 1e-6) : 0.0;
+    // The occlusion cull of the exact-image kernel (sphere_rect) treats the pose as RIGID -- a tile's bounding sphere keeps its radius in
+    // the sensor frame -- and gates on this value being > 0.999.  A lower bound alone does not exclude a scale or shear > 1 (the reference
+    // accepts any 4x4 pose): bound the largest singular value too (Gershgorin, upper end) and, if it can exceed 1.001, report at
+    // most 0.99 -- still a valid lower bound for the tile range cull, but "not rigid" for the occlusion cull.
+    double gmax = 0.0;
+    for (int a2 = 0; a2 < 3; ++a2) {
+        double row = 0;
+        for (int b2 = 0; b2 < 3; ++b2) {
+            double g2 = 0;
+            for (int r = 0; r < 3; ++r) g2 += T[4 * r + a2] * T[4 * r + b2];
+            row += std::fabs(g2);
+        }
+        gmax = std::max(gmax, row);
+    }
+    if (!(std::sqrt(gmax) * (1.0 + 1e-6) < 1.001)) smin = std::min(smin, 0.99);
     out[15] = smin > 0.5 ? (float)std::nextafter((float)smin, 0.0f) : 1.0e-30f;   // tiny = usable transform, no tile cull
 }
 
@@ -646,7 +662,8 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
 {
     if (!map.n || !nb) return;
     const size_t n_tiles = (map.n + 4095) / 4096, n_pairs = n_tiles * nb;
-    const bool occl = c->occlusion_cull && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
+    // (the list-driven launch exists for the block-local arg-min kernel only: LTM_MAP_KERNEL=0/1, the A/B baselines, take the plain launch)
+    const bool occl = c->occlusion_cull && map_kernel_variant() == 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
     if (!occl) {
         LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream));
         return;
@@ -657,7 +674,7 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     const size_t tbytes = scan_temp_bytes(n_pairs);
     const size_t need = n_tiles * 24 + n_pairs * (1 + 1 + 4 + 4) + 64 + nb * rbs * cbs * 4 + tbytes + 8 * 256;
     if (c->occl_scratch_bytes < need) {
-        if (c->occl_scratch) { sync(c); c->pool.free(c->occl_scratch); }
+        if (c->occl_scratch) { sync(c); c->pool.free(c->occl_scratch); c->occl_scratch = nullptr; c->occl_scratch_bytes = 0; }   // (the alloc below may throw)
         c->occl_scratch = c->pool.alloc(need + need / 4);
         c->occl_scratch_bytes = need + need / 4;
     }
@@ -1254,7 +1271,10 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_VOXEL_KEYBITS")) c->voxel_key_compress = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION")) c->occlusion_cull = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION_MIN_PAIRS")) c->occlusion_min_pairs = (size_t)atoll(v);
-        if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) c->occlusion_r_near = (float)atof(v);
+        if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) {      // a non-positive first shell would select no pair in any shell; NaN / inf fall back to the default
+            const float r = (float)atof(v);
+            c->occlusion_r_near = std::isfinite(r) ? std::max(1.0f, r) : 60.0f;
+        }
         if (const char* v = getenv("LTM_KNN_STATS")) c->knn_stats_on = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
@@ -2085,8 +2105,49 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
         h2d(c, fdev.p, frames.data(), nk * sizeof(VoxelGridFrame));
         DevBuf keys(c, n * 8), keys2(c, n * 8), idx(c, n * 4), idx2(c, n * 4);
         LTM_HIP(voxelgrid_keys_seg(s.d, s.off_dev, nk, n, fdev.as<VoxelGridFrame>(), keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
-        const size_t stb = sort_temp_bytes(n);
-        {
+        // PCL groups the points of a leaf with std::sort on the LEAF INDEX ONLY (cloud_point_index_idx::operator<): the order of the float
+        // sums inside a voxel is whatever that (unstable) sort leaves, and a voxel with three or more points rounds differently in a
+        // different order.  Round 4 measured it against the reference's own sources compiled with stand-in headers (oracle/_ref): an
+        // input-order sum changes the last bit of ~0.05 % of the loaded points.  To hand over what the reference would re-load, the
+        // default makes the SAME std::sort call on the host, one keyframe per task (the permutation is a function of the key sequence
+        // alone): keys down (8 B / point), point order up (4 B / point), everything else stays on the device.  LTM_VOXELGRID_ORDER=input
+        // keeps the whole grid on the device with a stable radix sort (input order inside a voxel; faster, not bit-identical to PCL).
+        const char* order_env = std::getenv("LTM_VOXELGRID_ORDER");
+        const bool pcl_order = !(order_env && std::strcmp(order_env, "input") == 0);
+        if (pcl_order) {
+            uint64_t* hk = static_cast<uint64_t*>(pinned_alloc(c, n * 8));
+            uint32_t* hi = static_cast<uint32_t*>(pinned_alloc(c, n * 4));
+            try {
+                LTM_HIP(hipMemcpyAsync(hk, keys.p, n * 8, hipMemcpyDeviceToHost, c->stream));
+                sync(c);
+                struct Entry { uint32_t idx, cloud_point_index; };
+                std::atomic<size_t> next{0};
+                auto work = [&] {
+                    std::vector<Entry> e;
+                    for (;;) {
+                        const size_t k = next.fetch_add(1);
+                        if (k >= nk) return;
+                        const size_t a = s.off[k], b = s.off[k + 1];
+                        if (frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
+                        e.resize(b - a);
+                        for (size_t i = a; i < b; ++i) e[i - a] = Entry{(uint32_t)hk[i], (uint32_t)i};
+                        std::sort(e.begin(), e.end(), [](const Entry& x, const Entry& y) { return x.idx < y.idx; });
+                        for (size_t i = a; i < b; ++i) hi[i] = e[i - a].cloud_point_index;
+                    }
+                };
+                const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+                const size_t nt = std::min<size_t>(std::min<size_t>(hw, 64), nk);
+                std::vector<std::thread> pool;
+                for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
+                work();
+                for (std::thread& t : pool) t.join();
+                LTM_HIP(hipMemcpyAsync(idx2.p, hi, n * 4, hipMemcpyHostToDevice, c->stream));
+                LTM_HIP(gather_u64_by_u32(keys.as<uint64_t>(), idx2.as<uint32_t>(), n, keys2.as<uint64_t>(), c->stream));
+                sync(c);
+            } catch (...) { pinned_free(c, hk); pinned_free(c, hi); throw; }
+            pinned_free(c, hk); pinned_free(c, hi);
+        } else {
+            const size_t stb = sort_temp_bytes(n);
             DevBuf stemp(c, stb);
             LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, 32 + kf_bits, stemp.p, stb, c->stream));
         }
@@ -2096,7 +2157,7 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
         DevBuf temp(c, tb);
         LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
         const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
-        // the sort key leads with the keyframe id, so keyframe k still occupies sorted positions [off[k], off[k+1])
+        // the keys lead with the keyframe id (and the host order works keyframe by keyframe), so keyframe k still occupies positions [off[k], off[k+1])
         DevBuf bout(c, (nk + 1) * 4);
         LTM_HIP(gather_u32(pos.as<uint32_t>(), s.off_dev, nk + 1, n, (uint32_t)nvox, bout.as<uint32_t>(), c->stream));
         std::vector<uint32_t> b(nk + 1);

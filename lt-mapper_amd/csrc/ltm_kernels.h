@@ -71,6 +71,7 @@ void set_kf_per_block(int v);    // keyframes that share one map-tile read insid
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s);   // {survivors, points} since the last reset
 hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,
                       Geom g, unsigned long long* bad_dev, hipStream_t s);
+int map_kernel_variant();
 void set_map_kernel_variant(int v);   // 0 = per-point global atomics, 1 = LDS pre-reduction (default)
 // generic single image with up to two explicit transforms (debug / parity)
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,
@@ -103,6 +104,7 @@ hipError_t reproject_gather(const uint64_t* img, const uint32_t* pos, size_t npx
 hipError_t image_bounds(const uint32_t* pos, const uint64_t* img, size_t npx, size_t nb, uint32_t* out, hipStream_t s);
 hipError_t flag_bounds(const uint32_t* pos, const uint8_t* flag, size_t n, const uint64_t* offsets_dev, size_t kf0, uint64_t first, size_t nb,
                        uint32_t* out, hipStream_t s);
+hipError_t gather_u64_by_u32(const uint64_t* in, const uint32_t* idx_dev, size_t n, uint64_t* out, hipStream_t s);
 hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, size_t n, uint32_t tail_value_index_n,
                       uint32_t* out, hipStream_t s);
 

@@ -956,6 +956,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
 
 static int g_map_kernel_variant = 2;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction, 2: + workgroup-local arg-min pre-filter
 void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
+int map_kernel_variant() { return g_map_kernel_variant; }
 
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                             HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s)
@@ -1343,6 +1344,18 @@ __global__ void k_gather_u32(const uint32_t* in, const uint64_t* idx, size_t m, 
     if (j >= m) return;
     const uint64_t i = idx[j];
     out[j] = (i < n) ? in[i] : tail;
+}
+// out[j] = in[idx[j]] on 64-bit words (the host-ordered form of the loader's voxel grid permutes its keys with the point indices)
+__global__ void __launch_bounds__(kBlock) k_gather_u64_by_u32(const uint64_t* __restrict__ in, const uint32_t* __restrict__ idx, size_t n, uint64_t* __restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) out[i] = in[idx[i]];
+}
+hipError_t gather_u64_by_u32(const uint64_t* in, const uint32_t* idx_dev, size_t n, uint64_t* out, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_gather_u64_by_u32<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(in, idx_dev, n, out);
+    return hipGetLastError();
 }
 hipError_t gather_u32(const uint32_t* in, const uint64_t* idx_dev, size_t m, size_t n, uint32_t tail, uint32_t* out, hipStream_t s)
 {

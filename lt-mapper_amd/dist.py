@@ -201,7 +201,9 @@ class CommMeter:
     def __init__(self, ops):
         self.ops = ops
         self.events = {"label_allreduce": [0, 0], "scans_allgather": [0, 0], "voxel_allgather": [0, 0]}      # [count, payload bytes]
-        self._local = set()           # ids of scan sets that would be rank-local (LazyScans) under ShardedOps
+        # scan sets that would be rank-local (LazyScans) under ShardedOps.  The objects themselves are tagged: an id() of a collected
+        # scan set can be handed to an unrelated, replicated one by CPython, which would count collectives that never happen
+        self._tag = "_comm_meter_local_%x" % id(self)
 
     def __getattr__(self, name):
         return getattr(self.ops, name)
@@ -209,15 +211,20 @@ class CommMeter:
     def reset(self):
         for v in self.events.values():
             v[0] = v[1] = 0
-        self._local.clear()
 
     def _note(self, kind, nbytes):
         self.events[kind][0] += 1
         self.events[kind][1] += int(nbytes)
 
     def _mark(self, s):
-        self._local.add(id(s))
+        try:
+            setattr(s, self._tag, True)
+        except AttributeError:          # an object that cannot carry attributes is wrapped by the caller's ops already; count it as replicated
+            pass
         return s
+
+    def _is_local(self, s):
+        return getattr(s, self._tag, False) is True
 
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode):
         self._note("label_allreduce", self.ops.size(cmap))
@@ -231,11 +238,11 @@ class CommMeter:
 
     def zip_concat(self, a, b, c): return self._mark(self.ops.zip_concat(a, b, c))
     def voxel_scanset(self, s, leaf): return self._mark(self.ops.voxel_scanset(s, leaf))
-    def voxel_grid_scanset(self, s, leaf): return self._mark(self.ops.voxel_grid_scanset(s, leaf)) if id(s) in self._local else self.ops.voxel_grid_scanset(s, leaf)
-    def preclean(self, s, radius): return self._mark(self.ops.preclean(s, radius)) if id(s) in self._local else self.ops.preclean(s, radius)
+    def voxel_grid_scanset(self, s, leaf): return self._mark(self.ops.voxel_grid_scanset(s, leaf)) if self._is_local(s) else self.ops.voxel_grid_scanset(s, leaf)
+    def preclean(self, s, radius): return self._mark(self.ops.preclean(s, radius)) if self._is_local(s) else self.ops.preclean(s, radius)
 
     def merge_to_global(self, scans, poses):
-        if id(scans) in self._local:
+        if self._is_local(scans):
             n_kf, n_pts = scans.info()
             self._note("scans_allgather", 16 * n_pts + 8 * (n_kf + 2))
         return self.ops.merge_to_global(scans, poses)

@@ -794,9 +794,15 @@ size_t orc_preclean(const float* pts, size_t n, float radius, float* out)
  * its published behaviour -- PARITY UNPINNED): inverse leaf size in float; getMinMax3D; the "leaf size is too small" test
  * (dx*dy*dz > INT32_MAX with d = (int64)((max-min)*inv_leaf) + 1) returns the INPUT unchanged -- the common case for a raw
  * 0.05 m scan; otherwise min_b / div_b from floor(min*inv), floor(max*inv), leaf index ijk0 + ijk1*div0 + ijk2*div0*div1 with
- * ijk = (int)(floor(x*inv) - (float)min_b), points grouped by index (std::sort on the index only: the order INSIDE a voxel is
- * unspecified in the reference; input order here), float sums (CentroidPoint accumulators), divided by the count, output in
- * ascending leaf index.  min_points_per_voxel = 0, all fields downsampled.  Returns the output count (out may be NULL). */
+ * ijk = (int)(floor(x*inv) - (float)min_b), points grouped by std::sort on the LEAF INDEX ONLY (PCL's cloud_point_index_idx::operator<):
+ * the order inside a voxel is what the C++ library's std::sort leaves, and the same call is made here -- round 4: with an input-order
+ * (stable) sort the oracle differed from the reference's own sources compiled against stand-in headers (oracle/_ref) in the last bit
+ * of ~0.05 % of the loaded os1-64 points; with this call it is bit-identical.  orc_set_voxel_grid_stable(1) selects input order, which
+ * is what the device form of the cascade hand-over (ltm_voxel_grid_scanset) sums in.  Float sums (CentroidPoint accumulators),
+ * divided by the count, output in ascending leaf index.  min_points_per_voxel = 0, all fields downsampled.  Returns the output
+ * count (out may be NULL). */
+int g_voxel_grid_stable = 0;
+void orc_set_voxel_grid_stable(int stable) { g_voxel_grid_stable = stable; }
 size_t orc_voxel_grid(const float* pts, size_t n, float leaf, float* out, size_t cap)
 {
     const Pt* p = reinterpret_cast<const Pt*>(pts); Pt* o = reinterpret_cast<Pt*>(out);
@@ -825,7 +831,9 @@ size_t orc_voxel_grid(const float* pts, size_t n, float leaf, float* out, size_t
         const int i2 = (int)(std::floor(p[i].z * inv) - (float)min_b[2]);
         iv[i] = {(unsigned)(i0 + i1 * div_b[0] + i2 * div_b[0] * div_b[1]), (unsigned)i};
     }
-    std::stable_sort(iv.begin(), iv.end(), [](const std::pair<unsigned, unsigned>& a, const std::pair<unsigned, unsigned>& b) { return a.first < b.first; });
+    const auto by_leaf = [](const std::pair<unsigned, unsigned>& a, const std::pair<unsigned, unsigned>& b) { return a.first < b.first; };
+    if (g_voxel_grid_stable) std::stable_sort(iv.begin(), iv.end(), by_leaf);
+    else std::sort(iv.begin(), iv.end(), by_leaf);      /* PCL: std::sort with cloud_point_index_idx::operator< (leaf index only) */
     size_t m = 0;
     for (size_t a = 0; a < n;) {
         size_t b = a;

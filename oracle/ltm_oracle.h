@@ -89,6 +89,9 @@ size_t orc_preclean(const float* pts, size_t n, float radius, float* out);
 
 /* ---- loader-side pcl::VoxelGrid (Session.cpp:284-289) ---- returns output count; out may be NULL to count */
 size_t orc_voxel_grid(const float* pts, size_t n, float leaf, float* out, size_t cap);
+/* 0 (default): the in-voxel summation order of PCL's std::sort on the leaf index (== oracle/_ref); 1: input order (what the device
+ * form of the cascade hand-over uses; differs in the last bit where a voxel holds >= 3 points) */
+void orc_set_voxel_grid_stable(int stable);
 
 /* ---- full pipeline: Removerter::run() Steps 1-3 (Removerter.cpp:1653-1678) on in-memory sessions ---- */
 /* ---- RViz images (utility.h:114-127 convertColorMappedImg, utility.cpp:248-256 pubRangeImg, Removerter.cpp:580-585) ----

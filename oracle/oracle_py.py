@@ -203,10 +203,16 @@ def preclean(pts, radius):
     return out[:n].copy()
 
 
-def voxel_grid(pts, leaf):
-    """pcl::VoxelGrid as the session loader applies it to every scan (Session.cpp:284-289)"""
+def voxel_grid(pts, leaf, stable=False):
+    """pcl::VoxelGrid as the session loader applies it to every scan (Session.cpp:284-289).  stable=False: PCL's in-voxel order
+    (std::sort on the leaf index only; == oracle/_ref); stable=True: input order, which is what the DEVICE form of the cascade
+    hand-over (ltm_voxel_grid_scanset) sums in -- the two differ in the last bit where a voxel holds three or more points."""
     a = _pts(pts); out = np.empty_like(a)
-    n = lib().orc_voxel_grid(_p(a), _sz(a.shape[0]), _f(leaf), _p(out), _sz(out.shape[0]))
+    lib().orc_set_voxel_grid_stable(_i(1 if stable else 0))
+    try:
+        n = lib().orc_voxel_grid(_p(a), _sz(a.shape[0]), _f(leaf), _p(out), _sz(out.shape[0]))
+    finally:
+        lib().orc_set_voxel_grid_stable(_i(0))
     return out[:n].copy()
 
 

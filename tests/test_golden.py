@@ -1,5 +1,7 @@
-"""Committed golden fixtures (tests/golden/*.npz, made by tools/make_golden.py).  On CPU the oracle must still reproduce them
-(regression pin of the oracle); on the GPU the HIP path must reproduce them without the oracle in the loop."""
+"""Committed golden fixtures (tests/golden/*.npz, made by tools/make_golden.py).  Since round 4 they are outputs of REFERENCE-COMPILED
+code (oracle/_ref: the reference's unmodified sources built against stand-in ROS / Eigen / OpenCV / PCL headers; the fixture files name their
+source), generated in the build container and committed because /root/reference does not exist on the GPU box.  On CPU the oracle must
+reproduce them; on the GPU the HIP path must reproduce them with neither the oracle nor the reference in the loop."""
 import os
 
 import numpy as np
@@ -26,6 +28,8 @@ def test_oracle_reproduces_primitive_golden(orc):
     assert (rimg.view(np.uint32) == d["rimg"].view(np.uint32)).all() and (idx == d["idx"]).all()
     assert_clouds_equal(orc.voxel_centroid(d["pts"], 0.5), d["vox"], "voxel")
     assert (orc.knn_split(d["tgt"], d["pts"][:1000] * 0.1, 2, 0.05) == d["near"]).all()
+    assert (orc.knn_split(d["tgt"], (d["pts"][:1000] * 0.5).astype(np.float32), 2, 1.0) == d["near_k2_thr1"]).all()   # Session.cpp:452-484, reference-compiled
+    assert "reference-compiled" in str(d["source"])
 
 
 @pytest.mark.parametrize("case", CASES)
@@ -54,6 +58,10 @@ def test_gpu_reproduces_primitive_golden(gpu_ctx):
     q = d["pts"][:1000] * 0.1
     near, far = gpu_ctx.knn_split_cloud(gpu_ctx.upload(d["tgt"]), gpu_ctx.upload(q), 2, 0.05)
     assert_clouds_equal(near.download(), q[d["near"] == 1], "near")
+    q2 = (d["pts"][:1000] * 0.5).astype(np.float32)
+    near2, far2 = gpu_ctx.knn_split_cloud(gpu_ctx.upload(d["tgt"]), gpu_ctx.upload(q2), 2, 1.0)
+    assert_clouds_equal(near2.download(), q2[d["near_k2_thr1"] == 1], "weak -> strong ND rule (reference-compiled fixture)")
+    assert_clouds_equal(far2.download(), q2[d["near_k2_thr1"] == 0], "weak -> strong ND rule, kept weak")
 
 
 @pytest.mark.gpu

@@ -31,17 +31,30 @@ def test_voxel_grid_scanset_matches_pcl_voxelgrid_restatement(gpu_ctx, orc):
     wide[:3, :3] = [[-0.0, 1.0, 2.0], [3.0, -0.0, 1.0], [5.0, 6.0, -0.0]]                           # signed zeros must survive the pass-through
     kfs.append(wide)                                                                                # 2400 x 2400 x 200 = 1.15e9 cells: just below the limit -> gridded
     kfs.append(np.c_[rng.uniform(-1, 1, (1, 3)), [7.0]])                                            # single point
+    kfs.append(np.c_[rng.normal(0, 0.5, (40000, 3)), rng.uniform(0, 255, 40000)])                   # tens of points per leaf: the in-voxel ORDER matters
     kfs = [k.astype(np.float32) for k in kfs]
     off = np.cumsum([0] + [len(k) for k in kfs]).astype(np.uint64)
-    for leaf in (0.05, 0.4):
-        got = gpu_ctx.voxel_grid_scanset(gpu_ctx.upload_scans(np.concatenate(kfs), off), leaf)
-        g_pts, g_off = got.download()
-        passthrough = 0
-        for k, pts in enumerate(kfs):
-            want = orc.voxel_grid(pts, leaf)
-            assert_clouds_equal(g_pts[int(g_off[k]):int(g_off[k + 1])], want, f"leaf {leaf} keyframe {k}")
-            passthrough += len(want) == len(pts) and len(pts) > 1
-        assert passthrough >= (1 if leaf == 0.05 else 0)
+    order_dependent = 0
+    for order in ("pcl", "input"):
+        # default: the summation order inside a leaf is that of PCL's std::sort on the leaf index (== the reference compiled against stand-in
+        # headers, tests/test_ref_compiled.py); LTM_VOXELGRID_ORDER=input: input order on the device (oracle: stable=True)
+        os.environ["LTM_VOXELGRID_ORDER"] = order
+        try:
+            for leaf in (0.05, 0.4):
+                got = gpu_ctx.voxel_grid_scanset(gpu_ctx.upload_scans(np.concatenate(kfs), off), leaf)
+                g_pts, g_off = got.download()
+                passthrough = 0
+                for k, pts in enumerate(kfs):
+                    want = orc.voxel_grid(pts, leaf, stable=(order == "input"))
+                    assert_clouds_equal(g_pts[int(g_off[k]):int(g_off[k + 1])], want, f"order {order} leaf {leaf} keyframe {k}")
+                    passthrough += len(want) == len(pts) and len(pts) > 1
+                    if order == "pcl":
+                        other = orc.voxel_grid(pts, leaf, stable=True)
+                        order_dependent += int((other.view(np.uint32) != want.view(np.uint32)).any(axis=1).sum())
+                assert passthrough >= (1 if leaf == 0.05 else 0)
+        finally:
+            os.environ.pop("LTM_VOXELGRID_ORDER", None)
+    assert order_dependent > 0, "the data must contain leaves whose float sum depends on the order (otherwise this test cannot tell the two orders apart)"
 
 
 def _roi(central_poses, query_poses):

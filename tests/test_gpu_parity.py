@@ -536,6 +536,32 @@ def test_occlusion_culled_reprojection_matches_oracle(ltm, orc):
     ctx.close()
 
 
+def test_occlusion_cull_with_scaled_and_sheared_poses_matches_oracle(ltm, orc):
+    """the reference accepts ANY 4x4 pose (Session.cpp:102-114).  With a scale or shear above 1 a tile's bounding sphere grows in the sensor
+    frame; the occlusion cull assumes rigid poses and must switch itself off for such keyframes (only a LOWER bound of the
+    smallest singular value used to gate it).  Keyframes with scale 1.08, 0.9, a shear and rigid ones mixed, cull forced on, against the oracle."""
+    import os
+    from tools import synth
+    S = synth.to_numpy(synth.make_session(1, 12, "small", scene="street", kf_spacing=3.0))
+    cmap = orc.voxel_centroid(orc.merge_to_global(S["scans"], S["offsets"], S["poses"], np.eye(4)), 0.05)
+    inv = S["inv"].reshape(-1, 4, 4).copy()
+    for k, M in ((1, np.diag([1.08, 1.08, 1.08])), (4, np.diag([0.9, 0.9, 0.9])), (6, np.array([[1, 0.06, 0], [0, 1, 0], [0.03, 0, 1.0]])), (9, np.diag([1.0, 1.004, 1.0]))):
+        inv[k, :3, :] = M @ inv[k, :3, :]            # local = M * (rigid inverse pose) * global
+    inv = inv.reshape(-1, 16)
+    want_pts, want_off = orc.reproject(cmap, inv, np.eye(4), 50.0, 360.0, 3.0)
+    old = {k: os.environ.get(k) for k in ("LTM_OCCLUSION", "LTM_OCCLUSION_MIN_PAIRS", "LTM_OCCLUSION_RNEAR")}
+    os.environ.update(LTM_OCCLUSION="1", LTM_OCCLUSION_MIN_PAIRS="0", LTM_OCCLUSION_RNEAR="8")
+    try:
+        ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    finally:
+        for k, v in old.items():
+            os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+    got_pts, got_off = ctx.reproject(ctx.upload(cmap), ctx.poses(S["poses"], inv), 3.0).download()
+    assert (got_off == want_off).all()
+    assert_clouds_equal(got_pts, want_pts, "occlusion-culled reprojection under non-rigid poses")
+    ctx.close()
+
+
 def test_repeated_votes_over_shrinking_maps_match_oracle(gpu_ctx, orc, small_pair):
     """second and third vote of the same scans at the same resolution over shrinking, re-gridded maps (the pattern of selfRemovert; the
     scan images and bound images are served from the context's cache) against the oracle"""
