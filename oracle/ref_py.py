@@ -261,8 +261,13 @@ class Removerter:
             return np.empty((0, 4), np.float32)
         return np.ctypeslib.as_array(p, shape=(n.value, 4)).copy()
 
+    _STATE = {"central_map_static": (0, "static"), "central_map_dynamic": (0, "dynamic"), "query_map_static": (1, "static"), "query_map_dynamic": (1, "dynamic")}
+
     def cloud(self, name):
-        """same names as the oracle's PipelineResult.cloud()"""
+        """same names as the oracle's PipelineResult.cloud(): a map the reference saved, or (the four remove / revert results it only
+        saves from selfRemovert) the session member itself"""
+        if name in self._STATE:
+            return self.session_map(*self._STATE[name])
         return self.saved(name + ".pcd")
 
     def scanset(self, name):

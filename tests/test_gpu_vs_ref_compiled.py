@@ -1,0 +1,94 @@
+"""The HIP path against REFERENCE-COMPILED code directly (no oracle in between): oracle/_ref holds the reference's own, unmodified sources
+built against stand-in ROS / Eigen / OpenCV / PCL headers (oracle/refshim; built in the build container, the .so and the binary travel to the
+GPU box with the snapshot).
+
+  * Removerter::run() on in-memory sessions: every map and scan set of the C-ABI pipeline == what the reference's code produced, bitwise --
+    single-res as shipped, 3-res selfRemovert, and under full SE(3) keyframe poses (roll / pitch of a few degrees, z drift) with the
+    session tens of kilometres from the origin;
+  * the two PROCESSES on the same session directories and the same params_ltmapper.yaml: `ltm_run` (product) and `removert_removert`
+    (the reference's main() / RosParamServer / Session loader / run() / PCD writer): the output trees are byte-identical files."""
+import filecmp
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+from conftest import ROOT
+
+from oracle import ref_py
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not ref_py.available(), reason="oracle/_ref was not built (needs /root/reference in the build container)")]
+
+
+def _tilt(S, rng, origin, inverse):
+    S = dict(S)
+    out = []
+    far = np.eye(4); far[:3, 3] = origin
+    for P in S["poses"].reshape(-1, 4, 4):
+        roll, pitch = np.deg2rad(rng.normal(0, 3.0, 2))
+        cy, sy, cx, sx = np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Rt = np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]])
+        Q = P.copy()
+        Q[:3, :3] = P[:3, :3] @ Rt
+        Q[2, 3] += rng.normal(0, 0.05)
+        out.append(far @ Q)
+    S["poses"] = np.array(out).reshape(-1, 16)
+    S["inv"] = inverse(S["poses"])
+    return S
+
+
+CASES = [dict(name="small_1res", sensor="small", n_kf=6, three=False, k=2, thr=0.01),
+         dict(name="small_3res_se3_far", sensor="small", n_kf=6, three=True, k=2, thr=0.01, se3=(3.2e4, -4.4e4, 80.0)),
+         dict(name="os1-64_3res", sensor="os1-64", n_kf=5, three=True, k=2, thr=0.01),
+         dict(name="small_1res_se3_k3", sensor="small", n_kf=5, three=False, k=3, thr=0.1, se3=(-1.1e4, 2.3e4, -30.0))]
+
+
+@pytest.mark.parametrize("case", CASES, ids=[c["name"] for c in CASES])
+def test_pipeline_equals_reference_compiled(ltm, case):
+    from test_gpu_pipeline import _compare, _run_gpu
+    from tools import synth
+    rng = np.random.default_rng(5)
+    C = synth.to_numpy(synth.make_session(1, case["n_kf"], case["sensor"])); Q = synth.to_numpy(synth.make_session(2, case["n_kf"], case["sensor"]))
+    inverse = lambda poses: ref_py.inverse4x4(np.asarray(poses).reshape(-1, 16)).reshape(np.asarray(poses).shape)
+    if case.get("se3"):
+        C, Q = _tilt(C, rng, case["se3"], inverse), _tilt(Q, rng, case["se3"], inverse)
+    else:
+        C["inv"], Q["inv"] = inverse(C["poses"]), inverse(Q["poses"])
+    res = (2.5, 2.0, 1.5) if case["three"] else (2.5,)
+    R = ref_py.Removerter(ref_py.make_params(k=case["k"], knn_thr=case["thr"], use_self_removert=case["three"], res_list=res)).pipeline_run(C, Q)
+    ctx, rmv = _run_gpu(ltm, C, Q, num_nn_points_within=case["k"], dist_nn_points_within=case["thr"], gpu_use_self_removert=case["three"],
+                        remove_resolution_list=list(res))
+    _compare(rmv, R)
+    assert len(rmv.outputs["updated_map"]) > 1000
+    ctx.close(); R.close()
+
+
+@pytest.mark.parametrize("sensor,n_kf", [("tiny", 40), ("os1-64", 40)])
+def test_product_process_and_reference_process_write_identical_trees(tmp_path, sensor, n_kf):
+    import fileproto as fp
+    from tools import synth
+    exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
+    assert os.path.exists(exe) and os.path.exists(ref_py.EXE_PATH)
+    sess = [synth.to_numpy(synth.make_session(s, n_kf, sensor)) for s in (1, 2)]
+    dirs = fp.write_session_dirs(tmp_path, sess, ascii_scans=(14,))
+    outs = {}
+    for who in ("product", "reference"):
+        out = tmp_path / f"out_{who}"
+        y = tmp_path / f"{who}.yaml"
+        y.write_text(fp.yaml_text(tmp_path, dirs, out, 11, n_kf - 1))
+        r = subprocess.run([exe, str(y)], capture_output=True, text=True, timeout=900) if who == "product" else ref_py.run_process(y, timeout=1800)
+        assert r.returncode == 0, who + ": " + r.stdout[-1500:] + r.stderr[-1500:]
+        outs[who] = out
+    n_files = 0
+    for d, _, files in os.walk(outs["reference"]):
+        rel = os.path.relpath(d, outs["reference"])
+        for f in files:
+            a, b = os.path.join(outs["reference"], rel, f), os.path.join(outs["product"], rel, f)
+            assert os.path.exists(b), f"{rel}/{f}: written by the reference process only"
+            assert filecmp.cmp(a, b, shallow=False), f"{rel}/{f}: the two processes wrote different bytes"
+            n_files += 1
+    ref_names = {os.path.relpath(os.path.join(d, f), outs["reference"]) for d, _, fs in os.walk(outs["reference"]) for f in fs}
+    extra = {os.path.relpath(os.path.join(d, f), outs["product"]) for d, _, fs in os.walk(outs["product"]) for f in fs} - ref_names
+    assert not {e for e in extra if not e.startswith("viz")}, f"files only the product wrote: {sorted(extra)[:5]}"
+    assert n_files >= 14 + 5 * 20
