@@ -271,6 +271,10 @@ int ltm_debug_cull_check(ltm_ctx*, const float* xyz, size_t n, const double* inv
  * last reset: (tile, keyframe) pairs seen by culled launches, pairs of the first distance shell, pairs projected in all (the rest was
  * proven hidden and dropped) */
 int ltm_debug_occlusion_stats(ltm_ctx*, uint64_t* pairs, uint64_t* first_shell, uint64_t* projected, int reset);
+/* voxel grids of clouds since the last reset, and how many of them were recognised as the identity during their bounding-box pass (the
+ * input an order-preserving subset of an earlier grid's output, still in octree order and one point per voxel under the frame this
+ * call derives: output = copy of the input, bit for bit what the sort + centroid path gives) */
+int ltm_debug_voxel_stats(ltm_ctx*, uint64_t* grids, uint64_t* identity_hits, int reset);
 /* diagnostic counters of the range-culled vote kernel since the last reset: points tested / points that needed the exact path */
 int ltm_debug_cull_stats(ltm_ctx*, uint64_t* survivors, uint64_t* points, int reset);
 

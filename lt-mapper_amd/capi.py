@@ -104,6 +104,7 @@ SIGNATURES = {
     "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),
     "ltm_debug_cull_stats": (_i, [_vp, _pu64, _pu64, _i]),
     "ltm_debug_occlusion_stats": (_i, [_vp, _pu64, _pu64, _pu64, _i]),
+    "ltm_debug_voxel_stats": (_i, [_vp, _pu64, _pu64, _i]),
     "ltm_rimg_size": (None, [_f, _f, _f, C.POINTER(_i), C.POINTER(_i)]),
     "ltm_profile_enable": (_i, [_vp, _i]),
     "ltm_profile_reset": (_i, [_vp]),
@@ -391,6 +392,11 @@ class Context:
         a, b, d = _u64(), _u64(), _u64()
         self._ck(self.lib.ltm_debug_occlusion_stats(self.h, C.byref(a), C.byref(b), C.byref(d), 1 if reset else 0))
         return a.value, b.value, d.value
+
+    def voxel_stats(self, reset=False):
+        a, b = _u64(), _u64()
+        self._ck(self.lib.ltm_debug_voxel_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
 
     def cull_stats(self, reset=True):
         a, b = _u64(), _u64()

@@ -110,7 +110,12 @@ struct Pool {
     }
 };
 
-struct Cloud { float4* d = nullptr; size_t n = 0; };
+struct Cloud {
+    float4* d = nullptr; size_t n = 0;
+    // the octree frame (and leaf) of the voxel grid this cloud came out of, kept by order-preserving subsets of it (partition outputs, clones):
+    // lets the next grid of the cloud test "nothing to do" during its bounding-box pass (k_bbox_reduce_check)
+    bool vf_ok = false; OctreeFrame vf{}; float vleaf = 0.0f;
+};
 struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> off; uint64_t* off_dev = nullptr; size_t nkf() const { return off.size() - 1; } };
 struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; float* approx_dev = nullptr; };
 
@@ -194,6 +199,9 @@ struct ltm_ctx {
     uint64_t occl_pairs = 0, occl_near = 0, occl_far_live = 0;      // statistics (LTM_OCCLUSION_STATS): pairs seen, in the first shell, projected in all
     void* occl_scratch = nullptr; size_t occl_scratch_bytes = 0;
     int voxel_key_compress = 1;                 // LTM_VOXEL_KEYBITS=0: sort over all 3*depth Morton bits (A/B switch)
+    int voxel_fused_tail = 1;                   // LTM_VOXEL_FUSED_TAIL=0: head flags / scan / segment starts as four kernels (A/B switch)
+    int voxel_identity = 1;                     // LTM_VOXEL_IDENTITY=0: never take the "already gridded under this frame" shortcut (A/B switch)
+    uint64_t voxel_identity_hits = 0, voxel_calls = 0;
     int knn_two_phase = 1;                      // LTM_KNN_FAST=0: the one-kernel exact search for every query (A/B switch)
     int knn_stats_on = 0;                       // LTM_KNN_STATS=1: count the queries phase 1 leaves undecided (one host round trip per call)
     uint64_t knn_undecided = 0, knn_queries = 0;
@@ -326,8 +334,20 @@ Poses& get_poses(ltm_ctx* c, ltm_poses h)
 ltm_cloud new_cloud(ltm_ctx* c, float4* d, size_t n)
 {
     const uint64_t h = c->next_handle++;
-    c->clouds[h] = Cloud{d, n};
+    Cloud cl; cl.d = d; cl.n = n;
+    c->clouds[h] = cl;
     return h;
+}
+void inherit_frame(ltm_ctx* c, ltm_cloud child, const Cloud& parent)
+{
+    if (!parent.vf_ok) return;
+    Cloud& ch = c->clouds[child];
+    ch.vf_ok = true; ch.vf = parent.vf; ch.vleaf = parent.vleaf;
+}
+void set_frame(ltm_ctx* c, ltm_cloud h, const OctreeFrame& f, float leaf, bool ok)
+{
+    Cloud& cl = c->clouds[h];
+    cl.vf_ok = ok; cl.vf = f; cl.vleaf = leaf;
 }
 ltm_cloud alloc_cloud(ltm_ctx* c, size_t n, float4** d)
 {
@@ -781,8 +801,8 @@ void do_partition(ltm_ctx* c, const Cloud& map, const uint8_t* labels, ltm_cloud
     if (kept) hk = alloc_cloud(c, n - nf, &dk);
     if (flagged) hf = alloc_cloud(c, nf, &df);
     LTM_HIP(partition_scatter(map.d, labels, pos.as<uint32_t>(), n, dk, df, c->stream));
-    if (kept) *kept = hk;
-    if (flagged) *flagged = hf;
+    if (kept) { *kept = hk; inherit_frame(c, hk, map); }
+    if (flagged) { *flagged = hf; inherit_frame(c, hf, map); }
 }
 
 // --------------------------------------------------------------------------- voxel centroid
@@ -854,12 +874,34 @@ KeyCompress key_compress_for(const float mn[3], const float mx[3], const OctreeF
 
 void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3])
 {
-    DevBuf bb(c, 6 * sizeof(uint32_t));
+    DevBuf bb(c, 8 * sizeof(uint32_t));
     LTM_HIP(bbox_init(bb.as<uint32_t>(), c->stream));
     LTM_HIP(bbox_reduce(pts, n, bb.as<uint32_t>(), c->stream));
-    uint32_t enc[6];
+    uint32_t enc[8];
     d2h(c, enc, bb.p, sizeof enc);
     for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[d]); mx[d] = bbox_decode(enc[3 + d]); }
+}
+bool same_frame(const OctreeFrame& a, const OctreeFrame& b)
+{
+    return a.minx == b.minx && a.miny == b.miny && a.minz == b.minz && a.res == b.res && a.depth == b.depth;
+}
+// head flags + scan + segment starts over sorted keys: the fused single-pass kernel (default) or the four-kernel form (LTM_VOXEL_FUSED_TAIL=0);
+// `starts` gets one entry per segment (capacity n), the count goes to *count_dev
+void voxel_segments(ltm_ctx* c, const uint64_t* keys2, size_t n, unsigned kshift, uint32_t* starts, uint32_t* count_dev)
+{
+    if (c->voxel_fused_tail) {
+        const size_t tb = voxel_heads_starts_temp_bytes(n);
+        DevBuf temp(c, tb);
+        LTM_HIP(voxel_heads_starts(keys2, n, kshift, starts, temp.p, count_dev, c->stream));
+        return;
+    }
+    DevBuf heads(c, n), pos(c, n * 4);
+    LTM_HIP(head_flags(keys2, n, heads.as<uint8_t>(), c->stream, kshift));
+    const size_t tb = scan_temp_bytes(n);
+    DevBuf temp(c, tb);
+    LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+    LTM_HIP(scan_total_to(heads.as<uint8_t>(), pos.as<uint32_t>(), n, count_dev, c->stream));
+    LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts, c->stream));
 }
 
 // voxel centroids of pts[0..n) into a freshly pooled array; returns count
@@ -869,17 +911,37 @@ void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3])
 //
 // Sort layout: when Morton bits + index bits fit one 64-bit word (always, for clouds the 32-bit index allows and octrees up
 // to depth 10-13) the pair travels packed and the radix sort is keys-only over the Morton bits; otherwise key/index pairs.
-size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf, float4** out, uint32_t shard = 0, uint32_t n_shards = 1)
+size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf, float4** out, uint32_t shard = 0, uint32_t n_shards = 1,
+                          const OctreeFrame* cached = nullptr, OctreeFrame* frame_out = nullptr)
 {
     *out = nullptr;
     if (n_in == 0) return 0;
     LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
     LTM_REQUIRE(n_in < 0xffffffffull, "cloud too large for 32-bit point indices");
     ProfScope p(c, "voxel", (double)n_in, 64.0 * n_in);
+    ++c->voxel_calls;
     float mn[3], mx[3];
-    bbox_of(c, pts, n_in, mn, mx);
+    bool untouched = false;
+    if (cached && c->voxel_identity && n_shards == 1) {
+        DevBuf bb(c, 8 * sizeof(uint32_t));
+        LTM_HIP(bbox_init(bb.as<uint32_t>(), c->stream));
+        LTM_HIP(bbox_reduce_check(pts, n_in, *cached, bb.as<uint32_t>(), c->stream));
+        uint32_t enc[8];
+        d2h(c, enc, bb.p, sizeof enc);
+        for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[d]); mx[d] = bbox_decode(enc[3 + d]); }
+        untouched = enc[6] == 0;
+    } else bbox_of(c, pts, n_in, mn, mx);
     OctreeFrame f;
     if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+    if (frame_out) *frame_out = f;
+    if (untouched && same_frame(f, *cached)) {
+        // every point alone in its voxel and already in octree order under the frame this very call would use: the grid is the identity
+        float4* o = reinterpret_cast<float4*>(c->pool.alloc(n_in * sizeof(float4)));
+        d2d(c, o, pts, n_in * sizeof(float4));
+        ++c->voxel_identity_hits;
+        *out = o;
+        return n_in;
+    }
     unsigned ib = 1;
     while (ib < 32 && ((size_t)1 << ib) < n_in) ++ib;
     const bool packed = c->voxel_packed_sort && 3 * f.depth + ib <= 64;
@@ -937,14 +999,11 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
         DevBuf stemp(c, stb);
         LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, mbits, stemp.p, stb, c->stream));
     }
-    DevBuf heads(c, n), pos(c, n * 4);
-    LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream, kshift));
-    const size_t tb = scan_temp_bytes(n);
-    DevBuf temp(c, tb);
-    LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
-    const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
-    DevBuf starts(c, nvox * 4);
-    LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
+    DevBuf starts(c, n * 4), cnt(c, 4);
+    voxel_segments(c, keys2.as<uint64_t>(), n, kshift, starts.as<uint32_t>(), cnt.as<uint32_t>());
+    uint32_t nvox32 = 0;
+    d2h(c, &nvox32, cnt.p, 4);
+    const size_t nvox = nvox32;
     float4* o = reinterpret_cast<float4*>(c->pool.alloc(nvox * sizeof(float4)));
     if (packed) LTM_HIP(voxel_centroids_packed(pts, keys2.as<uint64_t>(), ((uint64_t)1 << ib) - 1, starts.as<uint32_t>(), nvox, n, o, c->stream));
     else LTM_HIP(voxel_centroids(pts, idx2.as<uint32_t>(), starts.as<uint32_t>(), nvox, n, o, c->stream));
@@ -958,8 +1017,10 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
 struct VoxelJob {
     const float4* pts; size_t n; float leaf;
     OctreeFrame f; unsigned ib = 1, kshift = 0, mbits = 0; bool packed = false;
-    std::unique_ptr<DevBuf> keys, idx, keys2, idx2, heads, pos;
+    std::unique_ptr<DevBuf> keys, idx, keys2, idx2, starts;
     float4* out = nullptr; size_t nvox = 0;
+    bool has_cached = false; OctreeFrame cached{};        // the frame the input was gridded under, if it still carries one
+    bool identity = false;                                 // decided after the bounding-box round trip: output = copy of the input
 };
 void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs);
 void voxel_centroid_batch(ltm_ctx* c, std::vector<VoxelJob>& jobs)
@@ -982,21 +1043,31 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
     }
     ProfScope p(c, "voxel", tot_pts, 64.0 * tot_pts);
     // phase A: bounding boxes, one round trip
-    DevBuf bb(c, nj * 6 * sizeof(uint32_t));
+    DevBuf bb(c, nj * 8 * sizeof(uint32_t));
     for (size_t k = 0; k < nj; ++k) {
-        LTM_HIP(bbox_init(bb.as<uint32_t>() + 6 * k, c->stream));
-        LTM_HIP(bbox_reduce(jobs[k].pts, jobs[k].n, bb.as<uint32_t>() + 6 * k, c->stream));
+        LTM_HIP(bbox_init(bb.as<uint32_t>() + 8 * k, c->stream));
+        if (jobs[k].has_cached && c->voxel_identity) LTM_HIP(bbox_reduce_check(jobs[k].pts, jobs[k].n, jobs[k].cached, bb.as<uint32_t>() + 8 * k, c->stream));
+        else LTM_HIP(bbox_reduce(jobs[k].pts, jobs[k].n, bb.as<uint32_t>() + 8 * k, c->stream));
     }
-    std::vector<uint32_t> enc(nj * 6);
+    std::vector<uint32_t> enc(nj * 8);
     d2h(c, enc.data(), bb.p, enc.size() * 4);
     // phase B: keys, sort, head flags, scan; the counts go to one small device array
     DevBuf counts(c, nj * 4);
     for (size_t k = 0; k < nj; ++k) {
         VoxelJob& j = jobs[k];
         if (j.n == 0) { LTM_HIP(hipMemsetAsync(counts.as<uint32_t>() + k, 0, 4, c->stream)); continue; }
+        ++c->voxel_calls;
         float mn[3], mx[3];
-        for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]); }
+        for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[8 * k + d]); mx[d] = bbox_decode(enc[8 * k + 3 + d]); }
         if (!octree_frame_from_bbox(mn, mx, j.leaf, &j.f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+        if (j.has_cached && c->voxel_identity && enc[8 * k + 6] == 0 && same_frame(j.f, j.cached)) {      // see voxel_centroid_raw
+            j.identity = true;
+            j.out = reinterpret_cast<float4*>(c->pool.alloc(j.n * sizeof(float4)));
+            d2d(c, j.out, j.pts, j.n * sizeof(float4));
+            LTM_HIP(fill_u32(counts.as<uint32_t>() + k, (uint32_t)j.n, 1, c->stream));
+            ++c->voxel_identity_hits;
+            continue;
+        }
         while (j.ib < 32 && ((size_t)1 << j.ib) < j.n) ++j.ib;
         j.packed = c->voxel_packed_sort && 3 * j.f.depth + j.ib <= 64;
         const KeyCompress kc = key_compress_for(mn, mx, j.f, j.packed && c->voxel_key_compress);
@@ -1017,12 +1088,8 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
             LTM_HIP(sort_pairs_u64(j.keys->as<uint64_t>(), j.keys2->as<uint64_t>(), j.idx->as<uint32_t>(), j.idx2->as<uint32_t>(), n, j.mbits, stemp.p, stb, c->stream));
         }
         j.keys.reset(); j.idx.reset();      // stream-ordered pool: reusable by the next job's buffers
-        j.heads.reset(new DevBuf(c, n)); j.pos.reset(new DevBuf(c, n * 4));
-        LTM_HIP(head_flags(j.keys2->as<uint64_t>(), n, j.heads->as<uint8_t>(), c->stream, j.kshift));
-        const size_t tb = scan_temp_bytes(n);
-        DevBuf temp(c, tb);
-        LTM_HIP(exclusive_scan_u8(j.heads->as<uint8_t>(), j.pos->as<uint32_t>(), n, temp.p, tb, c->stream));
-        LTM_HIP(scan_total_to(j.heads->as<uint8_t>(), j.pos->as<uint32_t>(), n, counts.as<uint32_t>() + k, c->stream));
+        j.starts.reset(new DevBuf(c, n * 4));
+        voxel_segments(c, j.keys2->as<uint64_t>(), n, j.kshift, j.starts->as<uint32_t>(), counts.as<uint32_t>() + k);
     }
     std::vector<uint32_t> nv(nj);
     d2h(c, nv.data(), counts.p, nj * 4);
@@ -1034,13 +1101,11 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
     for (size_t k = 0; k < nj; ++k) {
         VoxelJob& j = jobs[k];
         j.nvox = nv[k];
-        if (j.n == 0) continue;
-        DevBuf starts(c, j.nvox * 4);
-        LTM_HIP(segment_starts(j.heads->as<uint8_t>(), j.pos->as<uint32_t>(), j.n, starts.as<uint32_t>(), c->stream));
+        if (j.n == 0 || j.identity) continue;
         j.out = reinterpret_cast<float4*>(c->pool.alloc(j.nvox * sizeof(float4)));
-        if (j.packed) LTM_HIP(voxel_centroids_packed(j.pts, j.keys2->as<uint64_t>(), ((uint64_t)1 << j.ib) - 1, starts.as<uint32_t>(), j.nvox, j.n, j.out, c->stream));
-        else LTM_HIP(voxel_centroids(j.pts, j.idx2->as<uint32_t>(), starts.as<uint32_t>(), j.nvox, j.n, j.out, c->stream));
-        j.keys2.reset(); j.idx2.reset(); j.heads.reset(); j.pos.reset();
+        if (j.packed) LTM_HIP(voxel_centroids_packed(j.pts, j.keys2->as<uint64_t>(), ((uint64_t)1 << j.ib) - 1, j.starts->as<uint32_t>(), j.nvox, j.n, j.out, c->stream));
+        else LTM_HIP(voxel_centroids(j.pts, j.idx2->as<uint32_t>(), j.starts->as<uint32_t>(), j.nvox, j.n, j.out, c->stream));
+        j.keys2.reset(); j.idx2.reset(); j.starts.reset();
     }
 }
 
@@ -1272,6 +1337,8 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
         if (const char* v = getenv("LTM_KNN_FAST")) c->knn_two_phase = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_KEYBITS")) c->voxel_key_compress = atoi(v);
+        if (const char* v = getenv("LTM_VOXEL_FUSED_TAIL")) c->voxel_fused_tail = atoi(v);
+        if (const char* v = getenv("LTM_VOXEL_IDENTITY")) c->voxel_identity = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION")) c->occlusion_cull = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION_MIN_PAIRS")) c->occlusion_min_pairs = (size_t)atoll(v);
         if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) {      // a non-positive first shell would select no pair in any shell; NaN / inf fall back to the default
@@ -1382,6 +1449,7 @@ int ltm_cloud_clone(ltm_ctx* c, ltm_cloud h, ltm_cloud* out)
         float4* d;
         const ltm_cloud nh = alloc_cloud(c, src.n, &d);
         d2d(c, d, src.d, src.n * 16);
+        inherit_frame(c, nh, src);
         *out = nh;
     });
 }
@@ -1957,9 +2025,12 @@ int ltm_voxel_centroid(ltm_ctx* c, ltm_cloud hin, float leaf, ltm_cloud* out)
         LTM_REQUIRE(out, "null argument");
         const Cloud in = get_cloud(c, hin);
         float4* d = nullptr;
-        const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d);
+        OctreeFrame f{};
+        const bool have = in.vf_ok && in.vleaf == leaf;
+        const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d, 0, 1, have ? &in.vf : nullptr, &f);
         if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
         *out = new_cloud(c, d, nv);
+        if (in.n) set_frame(c, *out, f, leaf, true);
     });
 }
 
@@ -1968,7 +2039,12 @@ int ltm_voxel_centroid_batch(ltm_ctx* c, size_t n, const ltm_cloud* in, const fl
     return guarded(c, [&] {
         LTM_REQUIRE((in && leaf && out) || n == 0, "null argument");
         std::vector<VoxelJob> jobs(n);
-        for (size_t k = 0; k < n; ++k) { const Cloud cl = get_cloud(c, in[k]); jobs[k].pts = cl.d; jobs[k].n = cl.n; jobs[k].leaf = leaf[k]; }
+        for (size_t k = 0; k < n; ++k) {
+            const Cloud cl = get_cloud(c, in[k]);
+            jobs[k].pts = cl.d; jobs[k].n = cl.n; jobs[k].leaf = leaf[k];
+            jobs[k].has_cached = cl.vf_ok && cl.vleaf == leaf[k] && cl.n > 0;
+            jobs[k].cached = cl.vf;
+        }
         voxel_centroid_batch(c, jobs);
         size_t done = 0;
         try {
@@ -1976,6 +2052,7 @@ int ltm_voxel_centroid_batch(ltm_ctx* c, size_t n, const ltm_cloud* in, const fl
                 float4* d = jobs[done].out ? jobs[done].out : reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
                 jobs[done].out = nullptr;
                 out[done] = new_cloud(c, d, jobs[done].nvox);
+                if (jobs[done].n) set_frame(c, out[done], jobs[done].f, jobs[done].leaf, true);
             }
         } catch (...) {      // handles made so far stay valid for the caller to free; the rest of the outputs go back to the pool
             for (size_t k = done; k < n; ++k) if (jobs[k].out) c->pool.free(jobs[k].out);
@@ -2478,6 +2555,14 @@ int ltm_debug_voxel_key_bits(const float* mn3, const float* mx3, float leaf, uin
     return (int)kc.bits;
 }
 
+int ltm_debug_voxel_stats(ltm_ctx* c, uint64_t* grids, uint64_t* identity_hits, int reset)
+{
+    return guarded(c, [&] {
+        if (grids) *grids = c->voxel_calls;
+        if (identity_hits) *identity_hits = c->voxel_identity_hits;
+        if (reset) c->voxel_calls = c->voxel_identity_hits = 0;
+    });
+}
 int ltm_debug_occlusion_stats(ltm_ctx* c, uint64_t* pairs, uint64_t* first_shell, uint64_t* projected, int reset)
 {
     return guarded(c, [&] {

@@ -124,6 +124,9 @@ hipError_t bbox_init(uint32_t* bbox, hipStream_t s);
 hipError_t bbox_reduce(const float4* pts, size_t n, uint32_t* bbox, hipStream_t s);
 float      bbox_decode(uint32_t enc);
 struct OctreeFrame { double minx, miny, minz, res; unsigned depth; };
+hipError_t bbox_reduce_check(const float4* pts, size_t n, OctreeFrame cached_frame, uint32_t* bbox8, hipStream_t s);   // box + "strictly increasing codes under cached_frame" (bbox8[6] = 1 if not)
+size_t voxel_heads_starts_temp_bytes(size_t n);
+hipError_t voxel_heads_starts(const uint64_t* sorted_keys, size_t n, unsigned shift, uint32_t* starts, void* temp, uint32_t* total_out_dev, hipStream_t s);
 hipError_t morton_keys(const float4* pts, size_t n, OctreeFrame f, uint64_t* keys, uint32_t* idx, hipStream_t s);
 // scan-set (segmented) forms: one bbox / octree frame per keyframe, composite sort key (kf << shift) | morton
 hipError_t bbox_reduce_seg(const float4* pts, const uint64_t* offsets_dev, size_t n_kf, uint64_t n, uint32_t* bbox, hipStream_t s);

@@ -1473,10 +1473,10 @@ float bbox_decode(uint32_t e)
     float f; memcpy(&f, &u, 4);
     return f;
 }
-__global__ void k_bbox_init(uint32_t* b)
+__global__ void k_bbox_init(uint32_t* b)          // 8 words per box: min xyz, max xyz (order-preserving encoding), violation flag of the check form, pad
 {
     if (threadIdx.x < 3) b[threadIdx.x] = 0xffffffffu;
-    else if (threadIdx.x < 6) b[threadIdx.x] = 0u;
+    else if (threadIdx.x < 8) b[threadIdx.x] = 0u;
 }
 hipError_t bbox_init(uint32_t* bbox, hipStream_t s)
 {
@@ -1520,6 +1520,73 @@ hipError_t bbox_reduce(const float4* pts, size_t n, uint32_t* bbox, hipStream_t 
 {
     if (!n) return hipSuccess;
     k_bbox_reduce<<<dim3((unsigned)std::min<size_t>(grid_for(n, kBlock * 8), 1024)), dim3(kBlock), 0, s>>>(pts, n, bbox);
+    return hipGetLastError();
+}
+
+__device__ __forceinline__ uint64_t spread3(uint32_t v);
+__device__ __forceinline__ uint64_t morton_code_of(const float4 p, const OctreeFrame& f)
+{
+    const uint32_t kx = (uint32_t)(((double)p.x - f.minx) / f.res);
+    const uint32_t ky = (uint32_t)(((double)p.y - f.miny) / f.res);
+    const uint32_t kz = (uint32_t)(((double)p.z - f.minz) / f.res);
+    return (spread3(kx) << 2) | (spread3(ky) << 1) | spread3(kz);
+}
+// The bounding-box pass of a voxel grid, with a speculation riding along (round 4).  Most clouds that get re-gridded are
+// order-preserving subsets of an earlier grid's output (the kept / flagged part of a map).  If such a cloud still has the octree frame
+// it was gridded under -- `f`, carried with the cloud -- and its points' Morton codes under that frame are STRICTLY INCREASING, then the
+// sort is the identity, every voxel holds one point and the centroid (0 + x) / 1 is the point itself (unless x is -0.0: the sum turns it
+// into +0.0, so a negative zero counts as a violation).  bbox[6] is set to 1 on any violation; the host compares the frame derived from
+// the box with `f` and, if both agree, copies the cloud instead of sorting it.  Same memory pass as the plain box reduction.
+__global__ void __launch_bounds__(kBlock)
+k_bbox_reduce_check(const float4* __restrict__ pts, size_t n, OctreeFrame f, uint32_t* __restrict__ bbox)
+{
+    __shared__ uint32_t smn[3][kBlock / 64], smx[3][kBlock / 64];
+    uint32_t mn[3] = {0xffffffffu, 0xffffffffu, 0xffffffffu}, mx[3] = {0u, 0u, 0u};
+    bool bad = false;
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (size_t i0 = (size_t)blockIdx.x * blockDim.x; i0 < n; i0 += stride) {         // uniform trip count per wave: shuffles stay convergent
+        const size_t i = i0 + threadIdx.x;
+        const bool in = i < n;
+        const float4 p = in ? pts[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        const uint64_t code = in ? morton_code_of(p, f) : ~0ull;
+        uint64_t prev = __shfl_up(code, 1, 64);
+        if (lane == 0) prev = (in && i > 0) ? morton_code_of(pts[i - 1], f) : 0ull;
+        if (in) {
+            const uint32_t e[3] = {enc_f32(p.x), enc_f32(p.y), enc_f32(p.z)};
+#pragma unroll
+            for (int d = 0; d < 3; ++d) { mn[d] = min(mn[d], e[d]); mx[d] = max(mx[d], e[d]); }
+            bad |= (i > 0 && code <= prev);
+            bad |= __builtin_bit_cast(uint32_t, p.x) == 0x80000000u || __builtin_bit_cast(uint32_t, p.y) == 0x80000000u ||
+                   __builtin_bit_cast(uint32_t, p.z) == 0x80000000u || __builtin_bit_cast(uint32_t, p.w) == 0x80000000u;
+        }
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            mn[d] = min(mn[d], (uint32_t)__shfl_xor((int)mn[d], off, 64));
+            mx[d] = max(mx[d], (uint32_t)__shfl_xor((int)mx[d], off, 64));
+        }
+    }
+    const int wave = threadIdx.x >> 6;
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) { smn[d][wave] = mn[d]; smx[d][wave] = mx[d]; }
+    }
+    if (__ballot(bad) != 0ull && lane == 0) atomicOr(bbox + 6, 1u);
+    __syncthreads();
+    if (threadIdx.x < 3) {
+        const int d = threadIdx.x;
+        uint32_t a = smn[d][0], b = smx[d][0];
+        for (int w = 1; w < kBlock / 64; ++w) { a = min(a, smn[d][w]); b = max(b, smx[d][w]); }
+        atomicMin(bbox + d, a); atomicMax(bbox + 3 + d, b);
+    }
+}
+hipError_t bbox_reduce_check(const float4* pts, size_t n, OctreeFrame f, uint32_t* bbox8, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    k_bbox_reduce_check<<<dim3((unsigned)std::min<size_t>(grid_for(n, kBlock * 2), 4096)), dim3(kBlock), 0, s>>>(pts, n, f, bbox8);
     return hipGetLastError();
 }
 
@@ -1849,6 +1916,87 @@ hipError_t segment_starts(const uint8_t* heads, const uint32_t* pos, size_t n, u
 {
     if (!n) return hipSuccess;
     k_segment_starts<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(heads, pos, n, starts);
+    return hipGetLastError();
+}
+
+// Fused tail of the voxel grid (round 4): head flags + exclusive scan + segment starts in ONE pass over the sorted keys -- a single-pass
+// chained scan with decoupled look-back (Merrill & Garland).  Before: k_head_flags (8n read, n written), rocPRIM's scan (n read, 4n written),
+// k_scan_total, k_segment_starts (5n read): four launches and ~19 B per point, 62 times per step; now 8 B per point and one launch.
+// Tile = 256 threads x 8 keys, wave-striped (lane l of wave w holds keys w*512 + j*64 + l, j = 0..7: coalesced, and (j, l) order is memory
+// order, so ranks come from ballots).  Tiles take their index from a ticket, so a tile's predecessors are always running or done and the
+// look-back cannot wait for a workgroup that was never scheduled.  state[t] = flag << 32 | count: flag 1 = the tile's own count, 2 = the
+// inclusive count up to and including the tile (agent-scope atomics: the eight XCD L2s are not coherent with each other).
+static constexpr int kHsItems = 8;
+static constexpr int kHsTile = kBlock * kHsItems;
+__global__ void __launch_bounds__(kBlock)
+k_voxel_heads_starts(const uint64_t* __restrict__ keys, size_t n, unsigned shift, uint32_t* __restrict__ starts,
+                     unsigned long long* __restrict__ state, uint32_t* __restrict__ ticket, uint32_t* __restrict__ total_out)
+{
+    __shared__ uint32_t s_tile, s_wave[kBlock / 64], s_prefix;
+    if (threadIdx.x == 0) s_tile = atomicAdd(ticket, 1u);
+    __syncthreads();
+    const uint32_t tile = s_tile;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t wbase = (size_t)tile * kHsTile + (size_t)wave * (64 * kHsItems);
+    uint64_t prev_tail = 0;                               // code of the element before this wave's first one (unused if wbase == 0)
+    if (wbase > 0 && wbase < n + 1) prev_tail = keys[wbase - 1] >> shift;
+    uint32_t rank[kHsItems];
+    uint64_t heads = 0;                                   // bit j: this lane's item j is a head
+    uint32_t wave_total = 0;
+    uint64_t last = prev_tail;
+#pragma unroll
+    for (int j = 0; j < kHsItems; ++j) {
+        const size_t i = wbase + (size_t)j * 64 + lane;
+        const bool in = i < n;
+        const uint64_t code = in ? keys[i] >> shift : ~0ull;
+        uint64_t prev = __shfl_up(code, 1, 64);
+        if (lane == 0) prev = last;
+        last = __shfl(code, 63, 64);
+        const bool head = in && (i == 0 || code != prev);
+        const uint64_t m = __ballot(head);
+        rank[j] = wave_total + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+        wave_total += (uint32_t)__popcll(m);
+        if (head) heads |= 1ull << j;
+    }
+    if (lane == 0) s_wave[wave] = wave_total;
+    __syncthreads();
+    uint32_t wave_off = 0, tile_total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) wave_off += s_wave[w]; tile_total += s_wave[w]; }
+    if (threadIdx.x == 0) {
+        uint32_t excl = 0;
+        if (tile == 0) {
+            __hip_atomic_store(state, (2ull << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } else {
+            __hip_atomic_store(state + tile, (1ull << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            for (uint32_t p = tile; p-- > 0;) {
+                unsigned long long v;
+                do { v = __hip_atomic_load(state + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull);
+                excl += (uint32_t)v;
+                if ((v >> 32) == 2ull) break;
+            }
+            __hip_atomic_store(state + tile, (2ull << 32) | (unsigned long long)(excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        s_prefix = excl;
+        if ((size_t)(tile + 1) * kHsTile >= n) *total_out = excl + tile_total;        // the last tile owns the count
+    }
+    __syncthreads();
+    const uint32_t base = s_prefix + wave_off;
+#pragma unroll
+    for (int j = 0; j < kHsItems; ++j)
+        if (heads >> j & 1ull) starts[base + rank[j]] = (uint32_t)(wbase + (size_t)j * 64 + lane);
+}
+size_t voxel_heads_starts_temp_bytes(size_t n) { return ((n + kHsTile - 1) / kHsTile) * 8 + 64; }
+// starts must hold n entries at most (one per head); *total_out (device) receives the number of segments
+hipError_t voxel_heads_starts(const uint64_t* sorted_keys, size_t n, unsigned shift, uint32_t* starts, void* temp, uint32_t* total_out, hipStream_t s)
+{
+    if (!n) return hipMemsetAsync(total_out, 0, 4, s);
+    const size_t tiles = (n + kHsTile - 1) / kHsTile;
+    hipError_t e = hipMemsetAsync(temp, 0, tiles * 8 + 64, s);
+    if (e != hipSuccess) return e;
+    unsigned long long* state = static_cast<unsigned long long*>(temp);
+    uint32_t* ticket = reinterpret_cast<uint32_t*>(state + tiles);
+    k_voxel_heads_starts<<<dim3((unsigned)tiles), dim3(kBlock), 0, s>>>(sorted_keys, n, shift, starts, state, ticket, total_out);
     return hipGetLastError();
 }
 

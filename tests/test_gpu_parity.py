@@ -579,3 +579,66 @@ def test_repeated_votes_over_shrinking_maps_match_oracle(gpu_ctx, orc, small_pai
         keep[::97] = True          # keep a few flagged points too, drop a few unflagged ones
         keep[5::89] = False
         cur = orc.voxel_centroid(cur[keep], 0.05)
+
+
+def test_voxel_identity_shortcut_and_fused_tail_equal_the_plain_path(ltm, orc, small_pair):
+    """round 4: (a) the fused head-flag / scan / segment-start kernel (single pass, decoupled look-back) against the four-kernel form;
+    (b) the "already gridded under this frame" shortcut taken during the bounding-box pass: kept / flagged parts of a gridded map that keep
+    their octree frame must come back bit-identical to the sort + centroid path and to the oracle -- and parts that lose their bounding
+    box must NOT take it"""
+    import os
+
+    def ctx_with(**env):
+        old = {k: os.environ.get(k) for k in env}
+        os.environ.update({k: str(v) for k, v in env.items()})
+        try:
+            return ltm.Context(vfov=VFOV, hfov=HFOV, device=0)
+        finally:
+            for k, v in old.items():
+                os.environ.pop(k, None) if v is None else os.environ.__setitem__(k, v)
+
+    C, _ = small_pair
+    merged = orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4)
+    rng = np.random.default_rng(4)
+    big = np.concatenate([merged, merged + np.float32(0.013), merged * np.float32(1.7)])          # ~3x the points: several look-back tiles per wave of tiles
+    want_big = orc.voxel_centroid(big, 0.05)
+    outs = {}
+    for tag, env in (("default", {}), ("plain", dict(LTM_VOXEL_FUSED_TAIL=0, LTM_VOXEL_IDENTITY=0))):
+        ctx = ctx_with(**env)
+        g = ctx.voxel_centroid(ctx.upload(big), 0.05)
+        assert_clouds_equal(g.download(), want_big, f"{tag}: voxel grid of {len(big)} points")
+        labels = (rng.uniform(size=len(g)) < 0.07).astype(np.uint8)
+        pts = g.download()
+        interior = np.ones(len(pts), bool)                      # keep the extreme points so that the bounding box (hence the frame) survives
+        for d in range(3):
+            interior[[pts[:, d].argmin(), pts[:, d].argmax()]] = False
+        labels &= interior.astype(np.uint8)
+        import torch
+        lab_dev = torch.from_numpy(labels).cuda()
+        ctx.voxel_stats(reset=True)
+        kept, flagged = ctx.partition_by_labels(g, lab_dev.data_ptr())
+        k2 = ctx.voxel_centroid(kept, 0.05)                     # frame survives: the shortcut applies
+        f2 = ctx.voxel_centroid(flagged, 0.05)                  # a sparse subset: its box shrinks, the frame changes -> full path
+        k3, f3 = ctx.voxel_centroid_batch([kept, flagged], [0.05, 0.05])
+        grids, hits = ctx.voxel_stats()
+        assert_clouds_equal(k2.download(), orc.voxel_centroid(pts[labels == 0], 0.05), f"{tag}: re-grid of the kept part")
+        assert_clouds_equal(f2.download(), orc.voxel_centroid(pts[labels == 1], 0.05), f"{tag}: re-grid of the flagged part")
+        assert_clouds_equal(k3.download(), k2.download(), f"{tag}: batch form, kept")
+        assert_clouds_equal(f3.download(), f2.download(), f"{tag}: batch form, flagged")
+        assert grids == 4
+        assert hits == (2 if tag == "default" else 0), f"{tag}: {hits} identity hits"
+        # must NOT take the shortcut: another leaf size than the one the cloud was gridded with
+        ctx.voxel_stats(reset=True)
+        assert_clouds_equal(ctx.voxel_centroid(kept, 0.4).download(), orc.voxel_centroid(pts[labels == 0], 0.4), f"{tag}: other leaf")
+        assert ctx.voxel_stats()[1] == 0
+        # a second generation: the re-gridded kept part, partitioned again, still carries the frame
+        if tag == "default":
+            lab2 = torch.from_numpy((rng.uniform(size=len(k2)) < 0.5).astype(np.uint8) & interior[labels == 0].astype(np.uint8)).cuda()
+            kk, _ = ctx.partition_by_labels(k2, lab2.data_ptr())
+            ctx.voxel_stats(reset=True)
+            kk2 = ctx.voxel_centroid(kk, 0.05)
+            assert ctx.voxel_stats()[1] == 1
+            assert_clouds_equal(kk2.download(), orc.voxel_centroid(kk.download(), 0.05), "second-generation re-grid")
+        outs[tag] = (k2.download(), f2.download())
+        ctx.close()
+    assert (outs["default"][0].view(np.uint32) == outs["plain"][0].view(np.uint32)).all()
