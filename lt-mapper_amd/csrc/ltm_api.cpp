@@ -944,8 +944,10 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
     }
     unsigned ib = 1;
     while (ib < 32 && ((size_t)1 << ib) < n_in) ++ib;
-    const bool packed = c->voxel_packed_sort && 3 * f.depth + ib <= 64;
-    const KeyCompress kc = key_compress_for(mn, mx, f, packed && c->voxel_key_compress);
+    // packed (code << index bits | index in one word, keys-only sort) whenever the COMPRESSED code fits beside the index: a 45 M-point
+    // street map (depth 13, 26 index bits) misses 64 bits by one with the full code and fits easily without the undecidable bits
+    const KeyCompress kc = key_compress_for(mn, mx, f, c->voxel_packed_sort && c->voxel_key_compress);
+    const bool packed = c->voxel_packed_sort && kc.bits + ib <= 64;
     const unsigned mbits = packed ? kc.bits : 3 * f.depth;        // code bits the sort has to look at
     const unsigned kshift = packed ? ib : 0;                       // Morton code = key >> kshift
     size_t n = n_in;
@@ -1069,8 +1071,8 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
             continue;
         }
         while (j.ib < 32 && ((size_t)1 << j.ib) < j.n) ++j.ib;
-        j.packed = c->voxel_packed_sort && 3 * j.f.depth + j.ib <= 64;
-        const KeyCompress kc = key_compress_for(mn, mx, j.f, j.packed && c->voxel_key_compress);
+        const KeyCompress kc = key_compress_for(mn, mx, j.f, c->voxel_packed_sort && c->voxel_key_compress);
+        j.packed = c->voxel_packed_sort && kc.bits + j.ib <= 64;
         j.mbits = j.packed ? kc.bits : 3 * j.f.depth;
         j.kshift = j.packed ? j.ib : 0;
         const size_t n = j.n;
