@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--threads", type=int, default=min(os.cpu_count() or 1, 32))
     ap.add_argument("--sensors", default="tiny,small", help="comma-separated tools.synth sensor names to draw from")
     ap.add_argument("--kf", type=int, nargs=2, default=[4, 8], metavar=("MIN", "MAX"), help="keyframes per session, drawn uniformly")
+    ap.add_argument("--se3", action="store_true", help="full SE(3) keyframe poses: roll / pitch N(0, 1..3 deg) and z drift per keyframe (the rays are cast from "
+                                                       "that attitude), session origin 10-50 km from the coordinate origin in half of the cases")
     args = ap.parse_args()
     import numpy as np
     import ltmapper_amd  # noqa: F401
@@ -57,7 +59,15 @@ def main():
         batch = int(rng.choice([0, 0, 3]))
         desc = dict(vfov=vfov, hfov=hfov, res=res if three else None, k=k, thr=thr, voxel=voxel, scene=scene, sensor=sensor, n_kf=n_kf,
                     extrinsic=None if l2b is None else "random", max_kf_batch=batch)
-        C, Q = (synth.to_numpy(synth.make_session(s, n_kf, sensor, scene=scene, seed=synth.MASTER_SEED + it)) for s in (1, 2))
+        pose_kw = {}
+        if args.se3:
+            pose_kw = dict(tilt_deg=float(rng.choice([1.0, 3.0])), z_drift=float(rng.choice([0.05, 0.3])),
+                           origin=tuple(float(v) for v in (rng.uniform(1e4, 5e4, 3) * rng.choice([-1, 1], 3) * [1, 1, 0.005])) if rng.integers(2) else (0.0, 0.0, 0.0))
+            desc.update(pose_kw)
+        C, Q = (synth.to_numpy(synth.make_session(s, n_kf, sensor, scene=scene, seed=synth.MASTER_SEED + it, **pose_kw)) for s in (1, 2))
+        if args.se3:      # the inverse poses as the reference computes them (Session.cpp:110): the oracle's restatement of Eigen's inverse
+            for S in (C, Q):
+                S["inv"] = orc.inverse_poses(S["poses"])
         t0 = time.perf_counter()
         ref = orc.pipeline_run(orc.make_params(vfov=vfov, hfov=hfov, k=k, knn_thr=thr, voxel=voxel, lidar2base=l2b, use_self_removert=three,
                                                res_list=tuple(res), threads=args.threads), C, Q)

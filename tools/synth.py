@@ -184,9 +184,14 @@ def _cast(o, d, boxes, chunk=131072):
 
 
 def make_session(session, n_kf, sensor="os1-64", seed=MASTER_SEED, device="cpu", scene="lot", kf_spacing=1.0,
-                 max_range=120.0, noise=0.02, dropout=0.05, pose_noise=True):
+                 max_range=120.0, noise=0.02, dropout=0.05, pose_noise=True, tilt_deg=0.0, z_drift=0.0, origin=(0.0, 0.0, 0.0)):
     """returns dict(scans (P,4) f32, offsets (n_kf+1) u64, poses (n_kf,16) f64, inv (n_kf,16) f64, names)
-    with scans/offsets as torch tensors on `device` and poses as numpy."""
+    with scans/offsets as torch tensors on `device` and poses as numpy.
+
+    tilt_deg / z_drift / origin (round 4, full SE(3) poses as LT-SLAM output has them): every keyframe's sensor is rolled and pitched by
+    N(0, tilt_deg) degrees (hash-seeded) and lifted by N(0, z_drift) m -- the rays are cast from that attitude, so the scans stay consistent
+    with the scene -- and the whole session is reported `origin` metres away from where it was generated (poses only; at 40 km the 6 significant
+    digits of the pose text quantise translations to 0.1 m, exactly as the reference's writer would, ltslam/src/utility.cpp:190-200)."""
     assert scene in ("lot", "street")
     rings, n_az, el_lo, el_hi = SENSORS[sensor] if isinstance(sensor, str) else sensor
     dev = torch.device(device)
@@ -202,13 +207,28 @@ def make_session(session, n_kf, sensor="os1-64", seed=MASTER_SEED, device="cpu",
         gen.manual_seed((seed * 1000003 + session * 65537 + kf) & 0x7FFFFFFFFFFF)
         s_arc = 37.0 * session + kf_spacing * kf
         x, y, yaw = _loop_pose(s_arc) if scene == "lot" else _street_pose(s_arc)
-        o = torch.tensor([x, y, 1.9], dtype=f64, device=dev)
+        if tilt_deg or z_drift:       # Box-Muller on the hash stream: deterministic per (seed, session, keyframe)
+            def gauss(a, b):
+                u1, u2 = max(_hash01(seed, a, session, kf), 1e-12), _hash01(seed, b, session, kf)
+                return math.sqrt(-2.0 * math.log(u1)) * math.cos(2 * math.pi * u2)
+            roll, pitch = math.radians(tilt_deg) * gauss(31, 37), math.radians(tilt_deg) * gauss(41, 43)
+            dz = z_drift * gauss(47, 53)
+        else:
+            roll = pitch = dz = 0.0
+        o = torch.tensor([x, y, 1.9 + dz], dtype=f64, device=dev)
         phase = float(_hash01(seed, 17, session, kf)) * (2 * math.pi / n_az)
         az = az0 + phase
         ce, se = torch.cos(el)[:, None], torch.sin(el)[:, None]
         dl = torch.stack([(ce * torch.cos(az)[None, :]), (ce * torch.sin(az)[None, :]), se.expand(rings, n_az)], dim=2).reshape(-1, 3)
         cy, sy = math.cos(yaw), math.sin(yaw)
-        dw = torch.stack([cy * dl[:, 0] - sy * dl[:, 1], sy * dl[:, 0] + cy * dl[:, 1], dl[:, 2]], dim=1)
+        if roll or pitch:
+            cp, sp, cr, sr = math.cos(pitch), math.sin(pitch), math.cos(roll), math.sin(roll)
+            Rt = np.array([[cp, 0, sp], [0, 1, 0], [-sp, 0, cp]]) @ np.array([[1, 0, 0], [0, cr, -sr], [0, sr, cr]])      # attitude about the sensor
+            R = np.array([[cy, -sy, 0], [sy, cy, 0], [0, 0, 1]]) @ Rt
+            dw = dl @ torch.tensor(R.T, dtype=f64, device=dev)
+        else:
+            Rt = None
+            dw = torch.stack([cy * dl[:, 0] - sy * dl[:, 1], sy * dl[:, 0] + cy * dl[:, 1], dl[:, 2]], dim=1)
         if scene == "lot":
             # room: exit distance of the enclosing box; a ceiling exit is sky (no return)
             inv = 1.0 / dw
@@ -246,7 +266,10 @@ def make_session(session, n_kf, sensor="os1-64", seed=MASTER_SEED, device="cpu",
         else:
             ex = ey = eyaw = 0.0
         c2, s2 = math.cos(yaw + eyaw), math.sin(yaw + eyaw)
-        T = np.array([[c2, -s2, 0, x + ex], [s2, c2, 0, y + ey], [0, 0, 1, 1.9], [0, 0, 0, 1]], dtype=np.float64)
+        T = np.array([[c2, -s2, 0, x + ex], [s2, c2, 0, y + ey], [0, 0, 1, 1.9 + dz], [0, 0, 0, 1]], dtype=np.float64)
+        if Rt is not None:
+            T[:3, :3] = T[:3, :3] @ Rt
+        T[:3, 3] += np.asarray(origin, dtype=np.float64)
         T[:3, :] = _round_sig(T[:3, :], 6)
         poses.append(T)
     poses = np.stack(poses) if poses else np.zeros((0, 4, 4))
