@@ -9,6 +9,7 @@ session pair at the configuration's REAL sensor size -- every map and every per-
                what the reference's loader makes of run 1's scans_updated (VoxelGrid + pre-clean) -- device hand-over vs the oracle chain
   --config 3   configs[3]: street, hdl-64e (64 x 1900), 2 x 200 keyframes, single-res, whole pipeline
   --config 4   configs[4]: street, mls-128x8192 (1 M rays), 2 x 20 keyframes at 2 m, voxel 0.1, k = 2, thr 0.04
+  --config 33  configs[3], 3-res variant: street, hdl-64e, 2 x 200 keyframes, selfRemovert over [2.5, 2.0, 1.5]
 
 The oracle needs ~49 min single-threaded for configs[1], far beyond a test; with the GPU box's 256 host cores (OpenMP over
 keyframes, same serial arg-min semantics per keyframe; the label union is order-free) it takes about three minutes --
@@ -31,6 +32,7 @@ CONFIGS = {
     2: ("lot", "os1-64", 500, 1.0, True, 0.05, 2, 0.01),
     3: ("street", "hdl-64e", 200, 1.0, False, 0.05, 2, 0.01),
     4: ("street", "mls", 20, 2.0, False, 0.1, 2, 0.04),
+    33: ("street", "hdl-64e", 200, 1.0, True, 0.05, 2, 0.01),       # configs[3] is "single-res and 3-res" (SURVEY 8d row 4): the 3-res variant
 }
 
 
@@ -176,7 +178,7 @@ def run_parity(config=1, kf=None, threads=None, device="cuda:0"):
     except OSError:
         commit = None
     return {"what": "GPU (C ABI) vs CPU oracle, every output of Removerter::run() compared bitwise",
-            "config": f"BASELINE configs[{config}]", "workload": f"{scene} 2x{kf} {sensor} {'3-res' if three_res else 'single-res'} voxel {voxel} k {k} thr {thr}",
+            "config": f"BASELINE configs[{3 if config == 33 else config}]", "workload": f"{scene} 2x{kf} {sensor} {'3-res' if three_res else 'single-res'} voxel {voxel} k {k} thr {thr}",
             "scan_points": [int(c["offsets"][-1]) for c in cpu], "gpu_run_s": round(t_gpu, 3), "oracle_run_s": round(t_cpu, 1),
             "oracle_threads": threads, "outputs_compared": len(report), "outputs_differing": bad,
             "product_sha": provenance.product_sha(), "kernels_sha": provenance.kernels_sha(), "oracle_sha": provenance.oracle_sha(), "commit": commit,
