@@ -48,7 +48,7 @@ def lib():
         L.ref_rad2deg.argtypes = [_f]
         for fn in ("ref_linspace_int", "ref_splitPoseLine", "ref_parseProjectedPoints", "ref_octreeDownsampling", "ref_leaf_voxel_grid",
                    "ref_calcDescrepancy", "ref_getStaticIdxFromDynamicIdx", "ref_parsePointcloudSubsetUsingPtIdx", "ref_parseKeyframes",
-                   "ref_precleaning", "ref_saved_names"):
+                   "ref_precleaning", "ref_saved_names", "ref_vote_dynamic_idx"):
             getattr(L, fn).restype = _sz
         L.ref_rmv_create.restype = _vp
         _lib = L
@@ -229,6 +229,15 @@ class Removerter:
         a = _pts(pts); out = np.empty_like(a)
         n = lib().ref_precleaning(_vp(self.h), _p(a), _sz(a.shape[0]), _f(radius), _p(out), _sz(a.shape[0]))
         return out[:n].copy()
+
+    def vote_labels(self, cmap, scans, offsets, poses, alpha, which=0):
+        """one vote pass (Removerter.cpp:542-593 / :485-540 ND / :429-482 PD) as a label array over the map, like the oracle's vote_labels"""
+        m = _pts(cmap); sc = _pts(scans); off = np.ascontiguousarray(offsets, dtype=np.uint64)
+        out = np.empty(max(len(m), 1), np.int32)
+        n = lib().ref_vote_dynamic_idx(_vp(self.h), _i(which), _p(m), _sz(len(m)), _p(sc), _p(off), _sz(len(off) - 1), _p(_m(poses)), _f(alpha), _p(out), _sz(out.size))
+        lab = np.zeros(len(m), np.uint8)
+        lab[out[:n]] = 1
+        return lab
 
     def weak_strong_split(self, strong, weak):
         """Session::removeWeakNDMapPointsHavingStrongNDInNear (k = 2, thr = 1.0): 1 where a weak point moves to the strong map"""

@@ -357,6 +357,28 @@ int ref_pipeline_run(ref_rmv* h, const ref_params* p,
     return 0;
 }
 
+/* The vote of one pass over the given keyframes: Removerter::calcDescrepancyAndParseDynamicPointIdxForEachScan (Removerter.cpp:542-593; which = 0),
+ * ...ForND (:485-540, diff = map - scan; which = 1), ...ForPD (:429-482; which = 2).  The session's map (map_global_curr_ / _nd_ / _pd_) is `map`,
+ * the source scans are `scans` (keyframe_scans_ for which = 0, keyframe_scans_static_projected_ otherwise).  Returns the sorted unique indices. */
+size_t ref_vote_dynamic_idx(ref_rmv* h, int which, const float* map, size_t M, const float* scans, const uint64_t* off, size_t n_kf, const double* poses,
+                            float res_alpha, int32_t* out, size_t cap)
+{
+    auto* R = reinterpret_cast<ltremovert::Removerter*>(h);
+    ltremovert::Session& s = R->central_sess_;
+    fill_session(s, "Central", R->kDownsampleVoxelSize, scans, off, n_kf, poses);
+    s.keyframe_scans_static_projected_ = s.keyframe_scans_;
+    pcPtr m = to_cloud(map, M);
+    *s.map_global_curr_ = *m; *s.map_global_nd_ = *m; *s.map_global_pd_ = *m;
+    const std::pair<int, int> shape = resetRimgSize(R->kFOV, res_alpha);
+    const std::vector<int> v = which == 0 ? R->calcDescrepancyAndParseDynamicPointIdxForEachScan(s, s, shape)
+                             : which == 1 ? R->calcDescrepancyAndParseDynamicPointIdxForEachScanForND(s, s, shape)
+                                          : R->calcDescrepancyAndParseDynamicPointIdxForEachScanForPD(s, s, shape);
+    for (size_t i = 0; i < v.size() && i < cap; ++i) out[i] = v[i];
+    s.keyframe_scans_.clear(); s.keyframe_scans_static_projected_.clear();
+    s.map_global_curr_->clear(); s.map_global_nd_->clear(); s.map_global_pd_->clear();
+    return v.size();
+}
+
 /* a cloud the reference saved during the run: name relative to save_pcd_directory, e.g. "updated_map.pcd", "scans_pd/000003.pcd" */
 int ref_saved_cloud(ref_rmv* h, const char* rel, const float** pts, size_t* n, uint32_t* width, uint32_t* height)
 {

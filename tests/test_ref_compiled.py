@@ -262,6 +262,21 @@ def test_precleaning(rmv, orc):
     assert_clouds_equal(rmv.precleaning(pts, 2.5), orc.preclean(pts, 2.5), "precleaningKeyframes (Session.cpp:506-533)")
 
 
+def test_vote_passes_reference_text_all_three_forms(ref, rmv, orc):
+    """calcDescrepancyAndParseDynamicPointIdxForEachScan / ...ForND / ...ForPD (Removerter.cpp:542-593, 485-540, 429-482) over a session map:
+    scan image, map transform, map image, signed difference, threshold window, std::set union -- the reference's text against the oracle's labels"""
+    from tools import synth
+    S = synth.to_numpy(synth.make_session(1, 5, "small", tilt_deg=2.0, z_drift=0.1, origin=(2.1e4, 1.3e4, 40.0)))
+    S["inv"] = orc.inverse_poses(S["poses"])
+    cmap = orc.voxel_centroid(orc.merge_to_global(S["scans"], S["offsets"], S["poses"], np.eye(4)), 0.05)
+    for alpha in (2.5, 2.375, 1.5):
+        for which, mode in ((0, 0), (1, 1), (2, 0)):
+            got = rmv.vote_labels(cmap, S["scans"], S["offsets"], S["poses"], alpha, which)
+            want = orc.vote_labels(cmap, S["scans"], S["offsets"], S["inv"], np.eye(4), VFOV, HFOV, alpha, 0.1, mode)
+            assert (got == want).all(), f"res {alpha} form {which}: {(got != want).sum()} labels differ"
+    assert 0 < want.sum() < len(want)
+
+
 # ------------------------------------------------------------------------------------------------- the pipeline
 def _tilted(S, rng, origin):
     """the same scans under full SE(3) poses: a few degrees of roll / pitch, z drift, a far session origin"""
