@@ -196,6 +196,7 @@ struct ltm_ctx {
     int occlusion_cull = 1;                     // LTM_OCCLUSION=0: the exact-image kernel runs every (tile, keyframe) pair (A/B switch)
     size_t occlusion_min_pairs = (size_t)1 << 21;   // LTM_OCCLUSION_MIN_PAIRS: smaller launches are not worth the two extra passes (2 M pairs = 4096 tiles x 512 keyframes)
     float occlusion_r_near = 60.0f;             // LTM_OCCLUSION_RNEAR [m]: tiles nearer than this are projected first and serve as occluders
+    int occlusion_incremental = 1;              // LTM_OCCLUSION_INCREMENTAL=0: the coarse maximum is re-reduced over every image row before every shell (A/B switch)
     uint64_t occl_pairs = 0, occl_near = 0, occl_far_live = 0;      // statistics (LTM_OCCLUSION_STATS): pairs seen, in the first shell, projected in all
     void* occl_scratch = nullptr; size_t occl_scratch_bytes = 0;
     int voxel_key_compress = 1;                 // LTM_VOXEL_KEYBITS=0: sort over all 3*depth Morton bits (A/B switch)
@@ -203,6 +204,7 @@ struct ltm_ctx {
     int voxel_identity = 1;                     // LTM_VOXEL_IDENTITY=0: never take the "already gridded under this frame" shortcut (A/B switch)
     uint64_t voxel_identity_hits = 0, voxel_calls = 0;
     int knn_two_phase = 1;                      // LTM_KNN_FAST=0: the one-kernel exact search for every query (A/B switch)
+    int knn_sort_queue = 1;                     // LTM_KNN_SORT_QUEUE=0: phase 2 walks the undecided queries in scan order instead of sorted by cell (A/B switch)
     int knn_stats_on = 0;                       // LTM_KNN_STATS=1: count the queries phase 1 leaves undecided (one host round trip per call)
     uint64_t knn_undecided = 0, knn_queries = 0;
     float cull_eps_scale = 0.0f;                // LTM_CULL_EPS_SCALE: pixels of distrust per (pixel per degree); 0 = the validated default of geom_for
@@ -692,7 +694,8 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     // scratch of the cull lives with the context (grown on demand): the stage runs dozens of times per step with the same sizes, and
     // taking it from the pool every time changes which blocks the stages around it find there
     const size_t tbytes = scan_temp_bytes(n_pairs);
-    const size_t need = n_tiles * 24 + n_pairs * (1 + 1 + 4 + 4) + 64 + nb * rbs * cbs * 4 + tbytes + 8 * 256;
+    const size_t dwords = (rbs + 31) / 32;         // dirty-row bitmap of the incremental coarse maximum
+    const size_t need = n_tiles * 24 + n_pairs * (1 + 1 + 4 + 4) + 64 + nb * rbs * cbs * 4 + nb * dwords * 4 + tbytes + 9 * 256;
     if (c->occl_scratch_bytes < need) {
         if (c->occl_scratch) { sync(c); c->pool.free(c->occl_scratch); c->occl_scratch = nullptr; c->occl_scratch_bytes = 0; }   // (the alloc below may throw)
         c->occl_scratch = c->pool.alloc(need + need / 4);
@@ -707,15 +710,20 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     uint32_t* list = reinterpret_cast<uint32_t*>(carve(n_pairs * 4));
     uint32_t* count = reinterpret_cast<uint32_t*>(carve(64));
     uint32_t* cmax = reinterpret_cast<uint32_t*>(carve(nb * rbs * cbs * 4));
+    uint32_t* dirty = c->occlusion_incremental ? reinterpret_cast<uint32_t*>(carve(nb * dwords * 4)) : nullptr;
     void* temp = carve(tbytes);
     LTM_HIP(tile_bounds(map.d, map.n, tb, c->stream));
     LTM_HIP(hipMemsetAsync(done, 0, n_pairs, c->stream));
+    if (dirty) {      // rows no projection has touched yet hold empty pixels: their coarse maximum is the empty range (10000 m, utility.h:93)
+        LTM_HIP(hipMemsetAsync(dirty, 0, nb * dwords * 4, c->stream));
+        LTM_HIP(fill_u32(cmax, 0x461c4000u, nb * rbs * cbs, c->stream));
+    }
     float r_lo = 0.0f, r_hi = c->occlusion_r_near;
     size_t n_done = 0, n_proj = 0;
     for (int shell = 0; shell < 12; ++shell) {
         const bool last = shell == 11 || r_hi > 1.0e4f;
         if (last) r_hi = 3.0e38f;
-        LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream));
+        LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream, dirty));
         uint32_t n_live = 0;
         d2h(c, &n_live, count, 4);
         LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, c->stream));
@@ -1343,11 +1351,13 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_VOXEL_IDENTITY")) c->voxel_identity = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION")) c->occlusion_cull = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION_MIN_PAIRS")) c->occlusion_min_pairs = (size_t)atoll(v);
+        if (const char* v = getenv("LTM_OCCLUSION_INCREMENTAL")) c->occlusion_incremental = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) {      // a non-positive first shell would select no pair in any shell; NaN / inf fall back to the default
             const float r = (float)atof(v);
             c->occlusion_r_near = std::isfinite(r) ? std::max(1.0f, r) : 60.0f;
         }
         if (const char* v = getenv("LTM_KNN_STATS")) c->knn_stats_on = atoi(v);
+        if (const char* v = getenv("LTM_KNN_SORT_QUEUE")) c->knn_sort_queue = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
         c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
@@ -2362,6 +2372,27 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
                 LTM_HIP(knn_two_phase_fast(s.d, s.off_dev, kf_begin, kf_end, first, n, longest, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.g, index.buckets,
                                            index.n_buckets, k, thr, flag.as<uint8_t>(), local.as<float4>(), c->stream));
             }
+            unsigned ibits = 0;
+            const unsigned kbits = c->knn_sort_queue ? knn_sorted_queue_bits(index.g, n, &ibits) : 0u;
+            if (kbits) {
+                // phase 2 on a queue sorted by cell (round 4): one host round trip for the undecided count (four kNN stages per step)
+                DevBuf pos(c, n * 4), count(c, 4);
+                const size_t tb = std::max(scan_temp_bytes(n), sort_keys_temp_bytes(n));
+                DevBuf temp(c, tb);
+                ProfScope ps(c, "knn_query_p2", 0.0, 0.0);
+                DevBuf q1(c, n * 8);
+                LTM_HIP(knn_two_phase_compact_keyed(s.d, s.off_dev, kf_begin, kf_end, first, n, p.pose_dev, c->B2L, c->b2l_identity, index.g, ibits, flag.as<uint8_t>(),
+                                                    pos.as<uint32_t>(), q1.as<uint64_t>(), count.as<uint32_t>(), temp.p, tb, c->stream));
+                uint32_t und = 0;
+                d2h(c, &und, count.p, 4);
+                if (und) {
+                    DevBuf q2(c, (size_t)und * 8);
+                    LTM_HIP(knn_two_phase_exact_sorted(s.d, s.off_dev, kf_begin, kf_end, first, p.pose_dev, c->B2L, c->b2l_identity, index.sorted, index.Mt, index.g, index.table,
+                                                       index.mask, index.bitmap, index.bitmap_mask, k, thr, index.cell2_lo, flag.as<uint8_t>(), q1.as<uint64_t>(), q2.as<uint64_t>(),
+                                                       und, ibits, kbits, temp.p, tb, c->stream));
+                }
+                if (c->knn_stats_on) { c->knn_undecided += und; c->knn_queries += n; }
+            } else {
             DevBuf pos(c, n * 4), queue(c, n * 4), count(c, 4);
             const size_t tb = scan_temp_bytes(n);
             DevBuf temp(c, tb);
@@ -2375,6 +2406,7 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
                 uint32_t und = 0;
                 d2h(c, &und, count.p, 4);
                 c->knn_undecided += und; c->knn_queries += n;
+            }
             }
         } else {
             ProfScope ps(c, "knn_query", (double)n, (double)n * (16.0 + 16.0 * k + 1.0));

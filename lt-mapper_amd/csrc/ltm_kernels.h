@@ -50,7 +50,7 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // done: n_tiles * nb zeroed bytes, pos / list: n_tiles * nb uint32, count: one uint32, cmax: nb * rows * ceil(cols/8) uint32, temp: scan_temp_bytes(n_tiles * nb)
 hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
                                  const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
-                                 void* temp, size_t temp_bytes, hipStream_t s);
+                                 void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty_rows = nullptr);
 hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                   HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s);
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
@@ -197,6 +197,15 @@ hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev,
                                const double* poses_dev, HostMat34 b2l, int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g,
                                const HashEntry* table, uint32_t table_mask, const void* bitmap, uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist,
                                uint32_t* pos, uint32_t* queue, uint32_t* count, void* temp, size_t temp_bytes, hipStream_t s);
+// phase 2 over a queue sorted by cell id (queue word = cell id << ibits | query index): compaction, [host reads *count], sort + exact search
+unsigned knn_sorted_queue_bits(KnnGrid g, uint64_t n_pts, unsigned* ibits_out);
+hipError_t knn_two_phase_compact_keyed(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, const double* poses_dev,
+                                       HostMat34 b2l, int b2l_identity, KnnGrid g, unsigned ibits, const uint8_t* flags, uint32_t* pos, uint64_t* queue, uint32_t* count,
+                                       void* temp, size_t temp_bytes, hipStream_t s);
+hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, const double* poses_dev, HostMat34 b2l,
+                                      int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask, const void* bitmap,
+                                      uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist, const uint64_t* queue_in, uint64_t* queue_sorted, uint32_t n_und,
+                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s);
 hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g,
                            const HashEntry* table, uint32_t table_mask, int k, float thr, float cell2_lo,
                            uint8_t* near, hipStream_t s);

@@ -1042,7 +1042,8 @@ __device__ __forceinline__ SphereRect sphere_rect(const RimgGeom& g, const float
 // maximum of the image built so far exists -- the tile is not hidden behind it.  done[] remembers projected / dropped pairs.
 __global__ void __launch_bounds__(kBlock)
 k_pair_shell_select(const float* __restrict__ approx_poses, uint32_t kb, uint32_t nb, const float* __restrict__ tile_bounds, uint32_t n_tiles, Geom gg,
-                    float r_lo, float r_hi, const uint32_t* __restrict__ cmax, uint32_t rbs, uint32_t cbs, uint8_t* __restrict__ done, uint8_t* __restrict__ flags)
+                    float r_lo, float r_hi, const uint32_t* __restrict__ cmax, uint32_t rbs, uint32_t cbs, uint8_t* __restrict__ done, uint8_t* __restrict__ flags,
+                    uint32_t* __restrict__ dirty, uint32_t dw)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles * nb) return;
@@ -1069,16 +1070,34 @@ k_pair_shell_select(const float* __restrict__ approx_poses, uint32_t kb, uint32_
     }
     done[t] = 1;
     flags[t] = live ? 1 : 0;
+    // rows of keyframe kfb's image that the projection of this pair can lower: the rows of its pixel rectangle (the rectangle the cull itself
+    // trusts to contain every pixel the tile can touch), all rows if it has none.  The coarse maximum is recomputed for those rows only.
+    if (live && dirty) {
+        uint32_t* dk = dirty + (size_t)kfb * dw;
+        if (sr.cullable) {
+            for (int w = sr.r0 >> 5; w <= sr.r1 >> 5; ++w) {
+                const int lo = max(sr.r0, w * 32) & 31, hi = min(sr.r1, w * 32 + 31) & 31;
+                const uint32_t m = (hi == 31 ? ~0u : ((1u << (hi + 1)) - 1u)) & ~((1u << lo) - 1u);
+                if ((__hip_atomic_load(dk + w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & m) != m) atomicOr(dk + w, m);
+            }
+        } else {
+            for (uint32_t w = 0; w < dw; ++w) atomicOr(dk + w, ~0u);
+        }
+    }
 }
 // cmax[kfb][row][cb] = largest range bits of the 8 pixels cb*8 .. cb*8+7 of one image row (positive floats order like their bits; empty =
 // 10000).  Row-granular on purpose: the rows just above what near facades were mapped at stay empty until far tiles fill them, and an
 // 8 x 8 block would let those rows keep every far tile near the horizon alive.
 __global__ void __launch_bounds__(kBlock)
-k_coarse_max(const uint64_t* __restrict__ img, uint32_t rows, uint32_t cols, uint32_t cbs, uint32_t nb, uint32_t* __restrict__ cmax)
+k_coarse_max(const uint64_t* __restrict__ img, uint32_t rows, uint32_t cols, uint32_t cbs, uint32_t nb, uint32_t* __restrict__ cmax,
+             const uint32_t* __restrict__ dirty, uint32_t dw)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= nb * rows * cbs) return;
     const uint32_t cb = t % cbs, r = (t / cbs) % rows, kfb = t / (cbs * rows);
+    // round 4: only rows that the previous shell's projections could lower are re-reduced (the pass used to re-read every image of the batch
+    // before every shell: 27 ms per step on the KITTI-scale workload, a tenth of it now); an image row nothing was projected into keeps its maximum
+    if (dirty && !((dirty[(size_t)kfb * dw + (r >> 5)] >> (r & 31u)) & 1u)) return;
     const uint64_t* __restrict__ im = img + ((size_t)kfb * rows + r) * cols;
     uint32_t m = 0;
     for (uint32_t cc = cb * 8; cc < min(cols, cb * 8 + 8); ++cc) m = max(m, (uint32_t)(im[cc] >> 32));
@@ -1096,15 +1115,19 @@ k_pair_list_scatter(const uint8_t* __restrict__ flags, uint8_t v, const uint32_t
 }
 
 // one shell: [r_lo, r_hi) of sensor-to-tile distance; img = the image built so far (ignored for the first shell: use_cmax = 0)
+// dirty = nb x ((rows + 31) / 32) words (or null: every row re-reduced): in, the rows the PREVIOUS shell's projections could lower (all ones before
+// the second shell: the first one is not tracked); out, those of this shell's
 hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
                                  const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
-                                 void* temp, size_t temp_bytes, hipStream_t s)
+                                 void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty)
 {
     const uint32_t n = (uint32_t)(n_tiles * nb);
     const uint32_t rbs = (uint32_t)g.rows, cbs = (uint32_t)(g.cols + 7) / 8;
-    if (use_cmax) k_coarse_max<<<dim3(grid_for((size_t)nb * rbs * cbs)), dim3(kBlock), 0, s>>>(img, (uint32_t)g.rows, (uint32_t)g.cols, cbs, (uint32_t)nb, cmax);
+    const uint32_t dw = (rbs + 31u) / 32u;
+    if (use_cmax) k_coarse_max<<<dim3(grid_for((size_t)nb * rbs * cbs)), dim3(kBlock), 0, s>>>(img, (uint32_t)g.rows, (uint32_t)g.cols, cbs, (uint32_t)nb, cmax, dirty, dw);
+    if (dirty) { hipError_t e0 = hipMemsetAsync(dirty, 0, (size_t)nb * dw * 4, s); if (e0 != hipSuccess) return e0; }
     k_pair_shell_select<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(approx_poses_dev, (uint32_t)kb, (uint32_t)nb, tile_bounds_dev, (uint32_t)n_tiles, g, r_lo, r_hi,
-                                                                use_cmax ? cmax : nullptr, rbs, cbs, done, flags);
+                                                                use_cmax ? cmax : nullptr, rbs, cbs, done, flags, dirty, dw);
     auto it = rocprim::make_transform_iterator(flags, FlagIs{1});
     hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
     if (e != hipSuccess) return e;
@@ -2567,6 +2590,104 @@ hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev,
         k_knn_slow<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(blocks), dim3(kBlock), 0, s>>>(
             scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, reinterpret_cast<const unsigned long long*>(bitmap), bitmap_mask, k, thr,
             cell2_lo, queue, count, coexist);
+    };
+    auto by_kt = [&](auto b2l_tag) {
+        switch (k) {
+        case 1: slow(b2l_tag, std::integral_constant<int, 1>{}); break;
+        case 2: slow(b2l_tag, std::integral_constant<int, 2>{}); break;
+        case 3: slow(b2l_tag, std::integral_constant<int, 3>{}); break;
+        default: slow(b2l_tag, std::integral_constant<int, 4>{}); break;
+        }
+    };
+    if (b2l_identity) by_kt(std::true_type{}); else by_kt(std::false_type{});
+    return hipGetLastError();
+}
+
+// ---- phase 2 over a queue SORTED BY CELL (round 4).  The undecided queries of a scan arrive in ring order, i.e. scattered over the whole
+// map: every lane of a wavefront probed its own 27 cells, table entries and point runs in cache lines nobody else wanted (k_knn_slow:
+// 7 ms for a quarter of the queries on the lot, 48 ms at KITTI scale).  Here the compaction writes (cell id << index bits | query index),
+// a keys-only radix sort over the cell bits brings the queries of one cell -- and of neighbouring cells along z and y -- together, and the
+// same exact search then runs on wavefronts whose lanes share their bitmap words, table entries and target points.  Answers are written
+// back through the query index, so the order of the queue cannot change any flag.
+template <bool B2L_IDENTITY>
+__global__ void __launch_bounds__(kBlock)
+k_knn_queue_scatter_keyed(const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint64_t n, const float4* __restrict__ scans,
+                          const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt, const double* __restrict__ poses, HostMat34 b2l_h, KnnGrid g,
+                          unsigned ibits, uint64_t* __restrict__ queue, uint32_t* __restrict__ count)
+{
+    const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const bool und = flag[i] == 2;
+    if (und) {
+        const uint64_t gi = first_pt + i;
+        const size_t kf = find_kf(offsets, kb, ke, gi);
+        const float4 p4 = scans[gi];
+        float3 p = make_float3(p4.x, p4.y, p4.z);
+        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+        const float3 gp = xform(load_mat(poses + 12 * kf), p);
+        // undecided queries lie inside the grid (phase 1 answered the others): the same cell arithmetic as knn_near / knn_bucket_coexist
+        const double fx = floor(((double)gp.x - g.ox) * g.inv_cell), fy = floor(((double)gp.y - g.oy) * g.inv_cell), fz = floor(((double)gp.z - g.oz) * g.inv_cell);
+        const uint64_t cx = (uint64_t)min(max((long long)fx, 0ll), g.nx - 1), cy = (uint64_t)min(max((long long)fy, 0ll), g.ny - 1), cz = (uint64_t)min(max((long long)fz, 0ll), g.nz - 1);
+        const uint64_t key = (cx * (uint64_t)g.ny + cy) * (uint64_t)g.nz + cz;
+        queue[pos[i]] = (key << ibits) | i;
+    }
+    if (i == n - 1) *count = pos[i] + (und ? 1u : 0u);
+}
+template <bool B2L_IDENTITY, int KT>
+__global__ void __launch_bounds__(kBlock)
+k_knn_slow_sorted(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
+                  const double* __restrict__ poses, HostMat34 b2l_h, const float4* __restrict__ tgt, size_t Mt, KnnGrid g,
+                  const HashEntry* __restrict__ table, uint32_t mask, const unsigned long long* __restrict__ bitmap, uint32_t bitmap_mask, int k, float thr, float cell2_lo,
+                  const uint64_t* __restrict__ queue, uint32_t n, uint64_t imask, uint8_t* __restrict__ coexist)
+{
+    for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
+        const uint64_t i = queue[q] & imask;
+        const uint64_t gi = first_pt + i;
+        const size_t kf = find_kf(offsets, kb, ke, gi);
+        const float4 p4 = scans[gi];
+        float3 p = make_float3(p4.x, p4.y, p4.z);
+        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+        const float3 gp = xform(load_mat(poses + 12 * kf), p);
+        coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo, bitmap, bitmap_mask) ? 1 : 0;
+    }
+}
+// bits of the largest cell id + bits of the largest query index; 0 if they do not fit one word (the caller then keeps the unsorted queue)
+unsigned knn_sorted_queue_bits(KnnGrid g, uint64_t n_pts, unsigned* ibits_out)
+{
+    const unsigned __int128 cells = (unsigned __int128)(uint64_t)g.nx * (uint64_t)g.ny * (uint64_t)g.nz;
+    unsigned kbits = 1, ibits = 1;
+    while (kbits < 64 && ((unsigned __int128)1 << kbits) < cells) ++kbits;
+    while (ibits < 63 && (1ull << ibits) < n_pts) ++ibits;
+    if (ibits_out) *ibits_out = ibits;
+    return kbits + ibits <= 64 ? kbits : 0u;
+}
+hipError_t knn_two_phase_compact_keyed(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, const double* poses_dev,
+                                       HostMat34 b2l, int b2l_identity, KnnGrid g, unsigned ibits, const uint8_t* flags, uint32_t* pos, uint64_t* queue, uint32_t* count,
+                                       void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n_pts) return hipMemsetAsync(count, 0, 4, s);
+    auto it = rocprim::make_transform_iterator(flags, FlagUndecided());
+    hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, n_pts, rocprim::plus<uint32_t>(), s);
+    if (e != hipSuccess) return e;
+    if (b2l_identity) k_knn_queue_scatter_keyed<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(flags, pos, n_pts, scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, g, ibits, queue, count);
+    else k_knn_queue_scatter_keyed<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(flags, pos, n_pts, scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, g, ibits, queue, count);
+    return hipGetLastError();
+}
+hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, const double* poses_dev, HostMat34 b2l,
+                                      int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask, const void* bitmap,
+                                      uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist, const uint64_t* queue_in, uint64_t* queue_sorted, uint32_t n_und,
+                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s)
+{
+    if (!n_und) return hipSuccess;
+    if (k < 1 || k > 4 || Mt < (size_t)k) return hipErrorInvalidValue;
+    hipError_t e = rocprim::radix_sort_keys(temp, temp_bytes, queue_in, queue_sorted, (size_t)n_und, ibits, ibits + kbits, s);
+    if (e != hipSuccess) return e;
+    const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n_und), 8192);
+    const uint64_t imask = (1ull << ibits) - 1ull;
+    auto slow = [&](auto b2l_tag, auto kt_tag) {
+        k_knn_slow_sorted<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(blocks), dim3(kBlock), 0, s>>>(
+            scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, reinterpret_cast<const unsigned long long*>(bitmap), bitmap_mask, k, thr,
+            cell2_lo, queue_sorted, n_und, imask, coexist);
     };
     auto by_kt = [&](auto b2l_tag) {
         switch (k) {
