@@ -1986,22 +1986,34 @@ k_voxel_heads_starts(const uint64_t* __restrict__ keys, size_t n, unsigned shift
     uint32_t wave_off = 0, tile_total = 0;
 #pragma unroll
     for (int w = 0; w < kBlock / 64; ++w) { if (w < wave) wave_off += s_wave[w]; tile_total += s_wave[w]; }
-    if (threadIdx.x == 0) {
+    if (wave == 0) {
+        // look-back by one whole wavefront: 64 predecessors per step (a single thread walking back one uncached load at a time made the
+        // kernel latency-bound).  A predecessor that has not posted yet is waited for -- it holds an earlier ticket, so it is running.
         uint32_t excl = 0;
         if (tile == 0) {
-            __hip_atomic_store(state, (2ull << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(state, (2ull << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         } else {
-            __hip_atomic_store(state + tile, (1ull << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            for (uint32_t p = tile; p-- > 0;) {
-                unsigned long long v;
-                do { v = __hip_atomic_load(state + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull);
-                excl += (uint32_t)v;
-                if ((v >> 32) == 2ull) break;
+            if (lane == 0) __hip_atomic_store(state + tile, (1ull << 32) | tile_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            long long p0 = (long long)tile - 1;
+            for (;;) {
+                const long long p = p0 - lane;
+                unsigned long long v = 2ull << 32;                 // before tile 0: inclusive count 0
+                if (p >= 0) { do { v = __hip_atomic_load(state + p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); } while ((v >> 32) == 0ull); }
+                const uint64_t incl = __ballot((v >> 32) == 2ull);
+                const int first = incl ? __builtin_ctzll(incl) : 64;          // nearest predecessor with an inclusive count
+                uint32_t add = lane <= first ? (uint32_t)v : 0u;
+#pragma unroll
+                for (int off = 32; off > 0; off >>= 1) add += (uint32_t)__shfl_xor((int)add, off, 64);
+                excl += add;
+                if (incl) break;
+                p0 -= 64;
             }
-            __hip_atomic_store(state + tile, (2ull << 32) | (unsigned long long)(excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (lane == 0) __hip_atomic_store(state + tile, (2ull << 32) | (unsigned long long)(excl + tile_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
-        s_prefix = excl;
-        if ((size_t)(tile + 1) * kHsTile >= n) *total_out = excl + tile_total;        // the last tile owns the count
+        if (lane == 0) {
+            s_prefix = excl;
+            if ((size_t)(tile + 1) * kHsTile >= n) *total_out = excl + tile_total;        // the last tile owns the count
+        }
     }
     __syncthreads();
     const uint32_t base = s_prefix + wave_off;

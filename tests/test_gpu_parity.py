@@ -607,6 +607,7 @@ def test_voxel_identity_shortcut_and_fused_tail_equal_the_plain_path(ltm, orc, s
         ctx = ctx_with(**env)
         g = ctx.voxel_centroid(ctx.upload(big), 0.05)
         assert_clouds_equal(g.download(), want_big, f"{tag}: voxel grid of {len(big)} points")
+        rng = np.random.default_rng(41)                       # the same labels under both configurations
         labels = (rng.uniform(size=len(g)) < 0.07).astype(np.uint8)
         pts = g.download()
         interior = np.ones(len(pts), bool)                      # keep the extreme points so that the bounding box (hence the frame) survives
