@@ -6,13 +6,22 @@
  * file:line it follows.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline
  * leg may load this; the product (lt-mapper_amd/) never does.
  *
- * PARITY STATUS: the reference ships no tests, golden vectors or fixtures for this path
- *  and cannot be built here (needs ROS, PCL 1.10, OpenCV, Eigen).
- * What IS pinned: atanf/atan2f against the host glibc (pin_atan2f.c, exhaustive), and the
- * hand-derivable known-answer tests of SURVEY.md Appendix B (tests/test_oracle_kat.py).
- * The PCL/FLANN semantics (transformPointCloud<double>, OctreePointCloudVoxelCentroid,
- * KdTreeFLANN k-NN, ExtractIndices) are restated from their published behaviour and are
- * "parity unpinned" -- see DESIGN.md.
+ * PARITY STATUS (round 4): the reference ships no tests, golden vectors or fixtures for this path,
+ * and its real build needs ROS, PCL 1.10, OpenCV and Eigen, none of which exist in the image.  But everything the reference
+ * ITSELF computes is plain C++ over those libraries' containers: oracle/refshim/ compiles the reference's own, unmodified
+ * sources (/root/reference/ltremovert/src/{utility,RosParamServer,Session,Removerter,removert_main}.cpp) against stand-in
+ * headers into oracle/_ref/ (serial: no OpenMP, the reference's parallel min-update is a documented race), and this oracle
+ * is PINNED to that build: tests/test_ref_compiled.py compares them bitwise on the scalar numerics, range images, vote
+ * passes (all three forms), the std::set union / complement, the remove / revert / selfRemovert state machine, the k-NN
+ * label rule, detectLowDynamicPoints / updateCurrentMap / updateScansScanwise, parseKeyframes (quirk Q6), pre-cleaning and
+ * the whole run() -- in memory (1-res, 3-res, extrinsic, full SE(3) poses 50 km from the origin) and as a process, files
+ * to files, at configs[0]'s real size; tests/golden/*.npz are outputs of that build.
+ * STILL UNPINNED (no source in the container): the library leaves the stand-ins restate -- pcl::transformPointCloud<double>,
+ * OctreePointCloudVoxelCentroid, VoxelGrid, KdTreeFLANN / FLANN exact k-NN, ExtractIndices, the PCD reader / writer, Eigen's
+ * Matrix4d::inverse(), OpenCV's colour map.  For those the stand-ins are a SECOND, deliberately literal derivation (pointer
+ * octree, PCL's index sort, a plain kd-tree) which the oracle must match bitwise -- that is how the in-voxel summation
+ * order of pcl::VoxelGrid (std::sort on the leaf index, not input order) was found.  Also pinned: atanf/atan2f against the
+ * host glibc (pin_atan2f.c, exhaustive) and the hand-derivable known-answer tests of SURVEY.md Appendix B.
  *
  * C ABI so that tests can drive it through ctypes.  All clouds are packed XYZI float32
  * (16 B / point).  Matrices are 4x4 row-major double.
