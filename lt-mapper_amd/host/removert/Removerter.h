@@ -39,6 +39,7 @@ private:
     std::unique_ptr<AsyncWriter> writer_;
     std::vector<PendingFetch> fetches_;
     void finishOutputs();      // waits for every queued file, releases the tickets
+    bool bench_mode_ = false;  // runBench(): no output files -- saveMap / saveScans return at once
 
 public:
     Removerter();
@@ -46,6 +47,10 @@ public:
     explicit Removerter(std::shared_ptr<Device> dev);
     virtual ~Removerter();
     int rank() const { return dev_->rank(); }
+    // `ltm_run <yaml> --bench K [--warmup W]`: loads the two sessions once, then times makeGlobalMap + Steps 1-3 K times with the inputs resident
+    // on the device and no output files (the same timed region as bench.py's, driven by THIS host); prints one JSON line with the wall time
+    // per step and the per-class kernel times / launch counts of ltm_profile_read
+    int runBench(int steps, int warmup);
 
     // pubRangeImg x4 (Removerter.cpp:580-585): called for every gpu_viz_every-th source keyframe of a vote pass with the
     // BGR8 images /scan_rimg_single, /map_rimg_single, /diff_rimg_single, /map_rimg_ptidx_single.  The default writes

@@ -1,6 +1,8 @@
 // Removerter.cpp -- mirror of ltremovert/src/Removerter.cpp over the C ABI (include/ltm.h).
 #include "removert/Removerter.h"
 
+#include <sstream>
+
 #include <chrono>
 #include <cmath>
 #include <cstdio>
@@ -52,6 +54,7 @@ void Removerter::finishOutputs()
 
 void Removerter::saveMap(const std::string& file, const CloudPtr& cloud, bool octree_layout)
 {
+    if (bench_mode_) return;
     if (dev_->rank() != 0) return;      // maps are replicated on every rank: rank 0 writes them
     if (gpu_async_io_) {
         // D2H on the copy stream into pinned memory + the file write on a writer thread; the GPU goes on with the next stage
@@ -426,6 +429,7 @@ void Removerter::saveStrongNDScans(Session& _sess) { saveScans(_sess, _sess.keyf
 
 void Removerter::saveScans(Session& _sess, const ScansPtr& _scans, std::string _save_dir, bool octree_layout)   // Removerter.cpp:1637-1650
 {
+    if (bench_mode_) return;
     // one file per keyframe: in a multi-GPU run every rank writes the files of its own keyframe block (no gather needed)
     const size_t first = _scans->shard ? _scans->kb : 0;
     if (!_scans->shard && dev_->rank() != 0) return;
@@ -672,6 +676,54 @@ void Removerter::saveKeyframePoses(const Session& _sess)
     }
     if (!o) throw std::runtime_error("cannot write " + file);
     LTM_INFO(" keyframe poses of the central session saved: " << file);
+}
+
+int Removerter::runBench(int steps, int warmup)
+{
+    using clk = std::chrono::steady_clock;
+    bench_mode_ = true;
+    loadSessionInfo();
+    parseKeyframes();
+    loadKeyframes();
+    precleaningKeyframes(2.5);
+    ltm_ctx* ctx = dev_->ctx;
+    auto reset = [&](Session& s) {      // everything a run derives from the loaded scans (the reference's allocateMemory(), Session.cpp:17-78)
+        s.keyframe_scans_static_projected_.reset(); s.keyframe_scans_dynamic_.reset(); s.scans_knn_coexist_.reset(); s.scans_knn_diff_.reset();
+        s.keyframe_scans_updated_.reset(); s.keyframe_scans_updated_strong_.reset(); s.keyframe_scans_pd_.reset(); s.keyframe_scans_strong_pd_.reset();
+        s.keyframe_scans_strong_nd_.reset(); s.keyframe_scans_weak_nd_.reset(); s.knn_target_map_.reset();
+        s.map_global_orig_.reset(); s.map_global_curr_.reset(); s.map_global_curr_static_.reset(); s.map_global_curr_dynamic_.reset();
+        s.map_global_updated_.reset(); s.map_global_updated_strong_.reset(); s.map_global_nd_.reset(); s.map_global_nd_strong_.reset(); s.map_global_nd_weak_.reset();
+        s.map_global_pd_.reset(); s.map_global_pd_orig_.reset(); s.map_global_pd_strong_.reset(); s.map_global_pd_weak_.reset();
+    };
+    double total = 0.0;
+    for (int it = 0; it < warmup + steps; ++it) {
+        reset(central_sess_); reset(query_sess_); union_q_.reset(); union_c_.reset();
+        if (it == warmup) { ltmCheck(ctx, ltm_profile_enable(ctx, 1), "ltm_profile_enable"); ltmCheck(ctx, ltm_profile_reset(ctx), "ltm_profile_reset"); }
+        ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+        const auto t0 = clk::now();
+        makeGlobalMap();
+        removeHighDynamicPoints();
+        parseStaticScansViaProjection();
+        detectLowDynamicPoints();
+        updateCurrentMap();
+        parseUpdatedStaticScansViaProjection();
+        parseLDScansViaProjection();
+        updateScansScanwise();
+        ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+        if (it >= warmup) total += std::chrono::duration<double>(clk::now() - t0).count();
+    }
+    const char* names[64]; double ms[64], units[64], bytes[64]; uint64_t launches[64];
+    const int nc = ltm_profile_read(ctx, names, ms, launches, units, bytes, 64);
+    std::ostringstream js;
+    js << "{\"host\": \"lt-mapper_amd/host (C++ mirror of Removerter/Session over the C ABI)\", \"steps\": " << steps << ", \"warmup\": " << warmup
+       << ", \"ms_per_step\": " << 1e3 * total / std::max(steps, 1) << ", \"keyframes\": [" << central_sess_.keyframe_names_.size() << ", "
+       << query_sess_.keyframe_names_.size() << "], \"classes\": {";
+    for (int i = 0; i < nc && i < 64; ++i)
+        js << (i ? ", " : "") << "\"" << names[i] << "\": {\"ms_per_step\": " << ms[i] / std::max(steps, 1) << ", \"launches_per_step\": "
+           << (double)launches[i] / std::max(steps, 1) << ", \"units_per_step\": " << units[i] / std::max(steps, 1) << "}";
+    js << "}}";
+    std::cout << "[bench] " << js.str() << std::endl;
+    return 0;
 }
 
 void Removerter::run(void)                                                         // Removerter.cpp:1653-1678

@@ -1,5 +1,5 @@
 // removert_main.cpp -- ROS-free stand-in for ltremovert/src/removert_main.cpp:3-12.
-//   ltm_run <params_ltmapper.yaml> [--check-wrappers] [--gpus K | --logical-ranks K]
+//   ltm_run <params_ltmapper.yaml> [--check-wrappers] [--gpus K | --logical-ranks K] [--bench K [--warmup W]]
 // reads the `removert:` namespace of the reference's own parameter file, runs Removerter::run() and exits
 // (the reference node calls ros::spin() afterwards and never exits on its own).
 //   --gpus K           keyframes sharded over GPUs 0..K-1 of this node: one host thread + one device context per GPU, label
@@ -61,14 +61,18 @@ int main(int argc, char** argv)
         std::fflush(stdout);
         int world = 1;
         bool rccl = false, check = false;
+        int bench_steps = 0, bench_warmup = 1;
         for (int i = 2; i < argc; ++i) {
             const std::string a = argv[i];
             if (a == "--check-wrappers") check = true;
             else if ((a == "--gpus" || a == "--logical-ranks") && i + 1 < argc) { world = std::atoi(argv[++i]); rccl = a == "--gpus"; }
+            else if (a == "--bench" && i + 1 < argc) bench_steps = std::atoi(argv[++i]);
+            else if (a == "--warmup" && i + 1 < argc) bench_warmup = std::atoi(argv[++i]);
             else { std::fprintf(stderr, "ltm_run: unknown argument %s\n", a.c_str()); return 2; }
         }
         if (world < 1 || world > 64) { std::fprintf(stderr, "ltm_run: rank count out of range\n"); return 2; }
         if (check) { ltremovert::Removerter RMV; return RMV.checkFineGrainedWrappers() ? 0 : 3; }
+        if (bench_steps > 0) { ltremovert::Removerter RMV; return RMV.runBench(bench_steps, std::max(0, bench_warmup)); }
         if (world > 1 || rccl) return runSharded(world, rccl);
         ltremovert::Removerter RMV;
         RMV.run();

@@ -187,3 +187,47 @@ def test_ltm_run_file_protocol(tmp_path, orc, writer):
     w_pts, w_off = ref2.scanset("scans_updated")
     for j, k in enumerate(c_kf):
         close(read_pcd(str(out2 / "scans_updated" / sess[0]["names"][k]))[1], w_pts[int(w_off[j]):int(w_off[j + 1])], f"cascade run 2 scans_updated/{k}")
+
+
+def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
+    """VERDICT r3 item 8: `Removerter::run()` exists twice, in lt-mapper_amd/host/src/Removerter.cpp (the north-star C++ host) and in
+    lt-mapper_amd/removerter.py (tests, bench, torch.distributed sharding).  Both only sequence C-ABI calls: on the same loaded sessions they must
+    launch every kernel class the same number of times over the same number of work units.  `ltm_run --bench` reports its per-class launch counts
+    and units (ltm_profile_read); the Python host is profiled the same way on the same data."""
+    import fileproto as fp
+    from ltmapper_amd import capi
+    from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
+    from tools import synth, t_total
+    n_kf = 24
+    sess = [synth.to_numpy(synth.make_session(s, n_kf, "small")) for s in (1, 2)]
+    dirs = fp.write_session_dirs(tmp_path, sess)
+    cxx = t_total.bench_cxx_host(str(tmp_path), dirs, n_kf, three_res=True, steps=1, warmup=1)
+    # the Python host on what the C++ loader makes of those files: keyframes 0..n_kf-1 of the central session (even start: no Q6 skip), the query
+    # keyframes inside the 10 m ROI; per-scan VoxelGrid + pre-clean on the device
+    c_kf = fp.parse_keyframes(n_kf, 0, n_kf - 1)
+    q_kf = fp.query_keyframes_in_roi(sess[0], c_kf, sess[1], n_kf)
+    assert cxx["keyframes"] == [len(c_kf), len(q_kf)]
+    ctx = capi.Context(vfov=50.0, hfov=360.0, device=0)
+    loaded = []
+    for S, kfs in ((sess[0], c_kf), (sess[1], q_kf)):
+        pts = [S["scans"][int(S["offsets"][k]):int(S["offsets"][k + 1])] for k in kfs]
+        off = np.cumsum([0] + [len(p) for p in pts]).astype(np.uint64)
+        scans = ctx.preclean(ctx.voxel_grid_scanset(ctx.upload_scans(np.concatenate(pts), off), 0.05), 2.5)
+        loaded.append((scans, ctx.poses(S["poses"].reshape(-1, 16)[kfs])))
+    P = Params(gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5])
+    ctx.profile_enable(True); ctx.profile_reset()
+    rm = Removerter(HipOps(ctx), P, Session("Central", *loaded[0]), Session("Query", *loaded[1]))
+    rm.run()
+    ctx.synchronize()
+    py = ctx.profile_read()
+    ctx.close()
+    names = sorted(set(cxx["classes"]) | set(py))
+    diff = []
+    for nme in names:
+        a, b = cxx["classes"].get(nme), py.get(nme)
+        la, ua = (a["launches_per_step"], a["units_per_step"]) if a else (0, 0)
+        lb, ub = (b["launches"], b["units"]) if b else (0, 0)
+        if (la, ua) != (lb, ub):
+            diff.append((nme, (la, ua), (lb, ub)))
+    assert not diff, f"the two hosts do not issue the same work: (class, C++ host, Python host) = {diff}"
+    assert len(names) >= 12

@@ -64,6 +64,24 @@ def measure(sess, kf, three_res=False, ranks=1, runs=3, root=None, extra_yaml=""
     return res, dirs
 
 
+def bench_cxx_host(root, dirs, kf, three_res=True, steps=3, warmup=1):
+    """`ltm_run <yaml> --bench steps`: makeGlobalMap + Steps 1-3 timed by the C++ host itself, the loaded sessions resident on the device, no
+    output files -- the same timed region as bench.py's, driven by the north-star host.  Returns its JSON line as a dict."""
+    import fileproto as fp
+    exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
+    outdir = os.path.join(root, "out_bench")
+    yaml = os.path.join(root, "params_bench.yaml")
+    with open(yaml, "w") as f:
+        f.write(fp.yaml_text(root, dirs, outdir, 0, kf - 1, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,),
+                             extra="  gpu_use_self_removert: true\n" if three_res else ""))
+    p = subprocess.run([exe, yaml, "--bench", str(steps), "--warmup", str(warmup)], capture_output=True, text=True)
+    shutil.rmtree(outdir, ignore_errors=True)
+    if p.returncode != 0:
+        raise RuntimeError(p.stdout[-1500:] + p.stderr[-1500:])
+    line = [l for l in p.stdout.splitlines() if l.startswith("[bench] ")][-1]
+    return json.loads(line[len("[bench] "):])
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--kf", type=int, default=50)
