@@ -192,6 +192,21 @@ int ltm_voxel_centroid_batch(ltm_ctx*, size_t n, const ltm_cloud* in, const floa
  * octree is cut into n_shards contiguous ranges of about equal point count (a pure function of `in`), so the outputs of
  * shards 0..n_shards-1 concatenated in order ARE ltm_voxel_centroid(in); each rank sorts 1/n_shards of the points. */
 int ltm_voxel_centroid_shard(ltm_ctx*, ltm_cloud in, float leaf, uint32_t shard, uint32_t n_shards, ltm_cloud* out);
+/* Key-range exchange: the voxel grid of a cloud whose POINTS are spread over the ranks -- the merge of
+ * rank-local per-keyframe scans (utility.cpp:170-192 followed by :204-219) -- without gathering the points on every rank.  Every rank:
+ *   ltm_cloud_bbox            box of its own points            -> the ranks combine them (min / max): the box of the whole cloud
+ *   ltm_voxel_key_histogram   4096-bin histogram of its points' octree keys under the WHOLE cloud's frame (top bits of the compressed
+ *                             Morton code)                     -> summed over the ranks; cut into n contiguous bin ranges of equal weight
+ *   ltm_voxel_key_split       its points of every range, each in input order -> all-to-all: rank r receives range r from everybody, in
+ *                             rank order = keyframe order = the input order of the single-GPU merge restricted to the range
+ *   ltm_voxel_centroid_box    the voxel grid of what it received, under the whole cloud's frame (the box is given, not derived)
+ * and the outputs of ranks 0..n-1 concatenated ARE ltm_voxel_centroid of the merged cloud: a bin is a prefix of the key, so no voxel
+ * straddles a cut, and every voxel sums its points in the order the single-GPU grid does.  hist has 4096 entries; cut_bins n_parts + 1,
+ * cut_bins[0] = 0, cut_bins[n_parts] = 4096.  An empty cloud has the box (+inf, -inf) and an all-zero histogram. */
+int ltm_cloud_bbox(ltm_ctx*, ltm_cloud in, float mn[3], float mx[3]);
+int ltm_voxel_key_histogram(ltm_ctx*, ltm_cloud in, const float mn[3], const float mx[3], float leaf, uint32_t hist[4096]);
+int ltm_voxel_key_split(ltm_ctx*, ltm_cloud in, const float mn[3], const float mx[3], float leaf, uint32_t n_parts, const uint32_t* cut_bins, ltm_cloud* parts);
+int ltm_voxel_centroid_box(ltm_ctx*, ltm_cloud in, const float mn[3], const float mx[3], float leaf, ltm_cloud* out);
 /* the same applied to every keyframe of a scan set (Session.cpp:362-380 updateScansScanwise) */
 int ltm_voxel_centroid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset* out);
 

@@ -87,6 +87,10 @@ SIGNATURES = {
     "ltm_voxel_centroid": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_voxel_centroid_shard": (_i, [_vp, _u64, _f, C.c_uint32, C.c_uint32, _pu64]),
     "ltm_voxel_centroid_batch": (_i, [_vp, _sz, _pu64, C.POINTER(_f), _pu64]),
+    "ltm_cloud_bbox": (_i, [_vp, _u64, C.POINTER(_f), C.POINTER(_f)]),
+    "ltm_voxel_key_histogram": (_i, [_vp, _u64, C.POINTER(_f), C.POINTER(_f), _f, C.POINTER(C.c_uint32)]),
+    "ltm_voxel_key_split": (_i, [_vp, _u64, C.POINTER(_f), C.POINTER(_f), _f, C.c_uint32, C.POINTER(C.c_uint32), _pu64]),
+    "ltm_voxel_centroid_box": (_i, [_vp, _u64, C.POINTER(_f), C.POINTER(_f), _f, _pu64]),
     "ltm_voxel_centroid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_voxel_grid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
@@ -300,6 +304,33 @@ class Context:
         outs = (_u64 * n)()
         self._ck(self.lib.ltm_voxel_centroid_batch(self.h, n, ins, lf, outs))
         return [Cloud(self, outs[k]) for k in range(n)]
+
+    # ---- key-range exchange (include/ltm.h: ltm_cloud_bbox ... ltm_voxel_centroid_box)
+    @staticmethod
+    def _f3(v):
+        return (_f * 3)(*[float(x) for x in v])
+
+    def bbox(self, cloud):
+        mn, mx = (_f * 3)(), (_f * 3)()
+        self._ck(self.lib.ltm_cloud_bbox(self.h, cloud.h, mn, mx))
+        return np.array(mn[:], np.float32), np.array(mx[:], np.float32)
+
+    def voxel_key_histogram(self, cloud, mn, mx, leaf):
+        hist = (C.c_uint32 * 4096)()
+        self._ck(self.lib.ltm_voxel_key_histogram(self.h, cloud.h, self._f3(mn), self._f3(mx), leaf, hist))
+        return np.frombuffer(hist, dtype=np.uint32).copy()
+
+    def voxel_key_split(self, cloud, mn, mx, leaf, cuts):
+        n = len(cuts) - 1
+        cb = (C.c_uint32 * (n + 1))(*[int(x) for x in cuts])
+        outs = (_u64 * n)()
+        self._ck(self.lib.ltm_voxel_key_split(self.h, cloud.h, self._f3(mn), self._f3(mx), leaf, n, cb, outs))
+        return [Cloud(self, outs[k]) for k in range(n)]
+
+    def voxel_centroid_box(self, cloud, mn, mx, leaf):
+        out = _u64()
+        self._ck(self.lib.ltm_voxel_centroid_box(self.h, cloud.h, self._f3(mn), self._f3(mx), leaf, C.byref(out)))
+        return Cloud(self, out.value)
 
     def voxel_centroid_shard(self, cloud, leaf, shard, n_shards):
         out = _u64()

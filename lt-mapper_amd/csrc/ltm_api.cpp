@@ -920,7 +920,7 @@ void voxel_segments(ltm_ctx* c, const uint64_t* keys2, size_t n, unsigned kshift
 // Sort layout: when Morton bits + index bits fit one 64-bit word (always, for clouds the 32-bit index allows and octrees up
 // to depth 10-13) the pair travels packed and the radix sort is keys-only over the Morton bits; otherwise key/index pairs.
 size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf, float4** out, uint32_t shard = 0, uint32_t n_shards = 1,
-                          const OctreeFrame* cached = nullptr, OctreeFrame* frame_out = nullptr)
+                          const OctreeFrame* cached = nullptr, OctreeFrame* frame_out = nullptr, const float* box_mn = nullptr, const float* box_mx = nullptr)
 {
     *out = nullptr;
     if (n_in == 0) return 0;
@@ -938,6 +938,8 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
         d2h(c, enc, bb.p, sizeof enc);
         for (int d = 0; d < 3; ++d) { mn[d] = bbox_decode(enc[d]); mx[d] = bbox_decode(enc[3 + d]); }
         untouched = enc[6] == 0;
+    } else if (box_mn && box_mx) {      // the bounding box of a LARGER cloud this one is a part of (key-range exchange, ltm_voxel_centroid_box)
+        for (int d = 0; d < 3; ++d) { mn[d] = box_mn[d]; mx[d] = box_mx[d]; }
     } else bbox_of(c, pts, n_in, mn, mx);
     OctreeFrame f;
     if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
@@ -2081,6 +2083,101 @@ int ltm_voxel_centroid_shard(ltm_ctx* c, ltm_cloud hin, float leaf, uint32_t sha
         const Cloud in = get_cloud(c, hin);
         float4* d = nullptr;
         const size_t nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d, shard, n_shards);
+        if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
+        *out = new_cloud(c, d, nv);
+    });
+}
+
+// ---- key-range exchange (multi-GPU voxel grid of a cloud whose POINTS are spread over the ranks)
+static void box_check(const float* mn, const float* mx)
+{
+    LTM_REQUIRE(mn && mx, "null bounding box");
+    for (int d = 0; d < 3; ++d) LTM_REQUIRE(std::isfinite(mn[d]) && std::isfinite(mx[d]) && mn[d] <= mx[d], "bounding box must be finite and ordered");
+}
+// packed keys of `in` under the frame of the box (mn, mx): the compressed Morton code starts at bit `ib` of every key, `shift` brings its top
+// <= 12 bits down to the histogram bin
+static void box_keys(ltm_ctx* c, const Cloud& in, const float* mn, const float* mx, float leaf, DevBuf& keys, unsigned* ib_out, unsigned* shift_out)
+{
+    OctreeFrame f;
+    if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
+    unsigned ib = 1;
+    while (ib < 32 && ((size_t)1 << ib) < in.n) ++ib;
+    const KeyCompress kc = key_compress_for(mn, mx, f, true);
+    if (kc.bits + ib > 64) throw Err{LTM_E_UNSUPPORTED, "voxel key + index bits exceed 64"};
+    LTM_HIP(morton_keys_packed(in.d, in.n, f, kc, ib, keys.as<uint64_t>(), c->stream));
+    *ib_out = ib;
+    *shift_out = ib + (kc.bits > 12 ? kc.bits - 12 : 0);
+}
+
+int ltm_cloud_bbox(ltm_ctx* c, ltm_cloud hin, float* mn, float* mx)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(mn && mx, "null argument");
+        const Cloud in = get_cloud(c, hin);
+        if (in.n == 0) { for (int d = 0; d < 3; ++d) { mn[d] = INFINITY; mx[d] = -INFINITY; } return; }
+        bbox_of(c, in.d, in.n, mn, mx);
+    });
+}
+
+int ltm_voxel_key_histogram(ltm_ctx* c, ltm_cloud hin, const float* mn, const float* mx, float leaf, uint32_t* hist)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(hist, "null argument");
+        LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
+        const Cloud in = get_cloud(c, hin);
+        std::memset(hist, 0, kVoxelKeyBins * sizeof(uint32_t));
+        if (in.n == 0) return;
+        box_check(mn, mx);
+        LTM_REQUIRE(in.n < 0xffffffffull, "cloud too large for 32-bit point indices");
+        DevBuf keys(c, in.n * 8), hd(c, kVoxelKeyBins * sizeof(uint32_t));
+        unsigned ib, shift;
+        box_keys(c, in, mn, mx, leaf, keys, &ib, &shift);
+        LTM_HIP(key_histogram(keys.as<uint64_t>(), in.n, shift, hd.as<uint32_t>(), c->stream));
+        d2h(c, hist, hd.p, kVoxelKeyBins * sizeof(uint32_t));
+    });
+}
+
+int ltm_voxel_key_split(ltm_ctx* c, ltm_cloud hin, const float* mn, const float* mx, float leaf, uint32_t n_parts, const uint32_t* cut_bins, ltm_cloud* parts)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(parts && cut_bins, "null argument");
+        LTM_REQUIRE(n_parts >= 1 && n_parts <= 4096, "part count out of range");
+        LTM_REQUIRE(cut_bins[0] == 0 && cut_bins[n_parts] == (uint32_t)kVoxelKeyBins, "cuts must run from bin 0 to the number of bins");
+        for (uint32_t r = 0; r < n_parts; ++r) LTM_REQUIRE(cut_bins[r] <= cut_bins[r + 1], "cuts must not decrease");
+        const Cloud in = get_cloud(c, hin);
+        for (uint32_t r = 0; r < n_parts; ++r) parts[r] = 0;
+        if (in.n == 0) { float4* d; for (uint32_t r = 0; r < n_parts; ++r) parts[r] = alloc_cloud(c, 0, &d); return; }
+        box_check(mn, mx);
+        LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
+        LTM_REQUIRE(in.n < 0xffffffffull, "cloud too large for 32-bit point indices");
+        DevBuf keys(c, in.n * 8), flags(c, in.n);
+        unsigned ib, shift;
+        box_keys(c, in, mn, mx, leaf, keys, &ib, &shift);
+        for (uint32_t r = 0; r < n_parts; ++r) {
+            // part r = the points whose histogram bin lies in [cut[r], cut[r+1]), in input order (bins are prefixes of the code: no voxel straddles a cut)
+            const uint64_t lo = (uint64_t)cut_bins[r] << shift;
+            const uint64_t hi = cut_bins[r + 1] >= (uint32_t)kVoxelKeyBins ? ~0ull : (uint64_t)cut_bins[r + 1] << shift;
+            if (cut_bins[r] == cut_bins[r + 1]) { float4* d; parts[r] = alloc_cloud(c, 0, &d); continue; }
+            LTM_HIP(key_range_flags(keys.as<uint64_t>(), in.n, lo, hi, flags.as<uint8_t>(), c->stream));
+            ltm_cloud rest_unused = 0;
+            (void)rest_unused;
+            do_partition(c, in, flags.as<uint8_t>(), nullptr, &parts[r]);
+            c->clouds[parts[r]].vf_ok = false;         // a part of a merged cloud was never gridded
+        }
+    });
+}
+
+int ltm_voxel_centroid_box(ltm_ctx* c, ltm_cloud hin, const float* mn, const float* mx, float leaf, ltm_cloud* out)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(out, "null argument");
+        const Cloud in = get_cloud(c, hin);
+        float4* d = nullptr;
+        size_t nv = 0;
+        if (in.n) {
+            box_check(mn, mx);
+            nv = voxel_centroid_raw(c, in.d, in.n, leaf, &d, 0, 1, nullptr, nullptr, mn, mx);
+        }
         if (!d) d = reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4)));
         *out = new_cloud(c, d, nv);
     });

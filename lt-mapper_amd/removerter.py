@@ -48,6 +48,15 @@ class HipOps:
     def voxel(self, c, leaf): return self.ctx.voxel_centroid(c, leaf)
     def voxel_batch(self, clouds, leaf): return self.ctx.voxel_centroid_batch(clouds, [leaf] * len(clouds))   # independent grids, two host round trips in all
     def voxel_shard(self, c, leaf, shard, n_shards): return self.ctx.voxel_centroid_shard(c, leaf, shard, n_shards)
+    # key-range exchange pieces (dist.ShardedOps.merge_voxel)
+    def bbox(self, c): return self.ctx.bbox(c)
+    def voxel_key_histogram(self, c, mn, mx, leaf): return self.ctx.voxel_key_histogram(c, mn, mx, leaf)
+    def voxel_key_split(self, c, mn, mx, leaf, cuts): return self.ctx.voxel_key_split(c, mn, mx, leaf, cuts)
+    def voxel_box(self, c, mn, mx, leaf): return self.ctx.voxel_centroid_box(c, mn, mx, leaf)
+
+    def merge_voxel_batch(self, merges, clouds, leaf):
+        """voxel grids of [merge_to_global(scans, poses) for (scans, poses) in merges] + clouds, as ONE batch (single GPU: nothing to exchange)"""
+        return self.voxel_batch([self.merge_to_global(s, p) for s, p in merges] + list(clouds), leaf)
     def voxel_scanset(self, s, leaf): return self.ctx.voxel_centroid_scanset(s, leaf)
     def voxel_grid_scanset(self, s, leaf): return self.ctx.voxel_grid_scanset(s, leaf)      # the loader's pcl::VoxelGrid, Session.cpp:284-289
     def preclean(self, s, radius): return self.ctx.preclean(s, radius)                      # Session.cpp:506-533

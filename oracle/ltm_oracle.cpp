@@ -173,6 +173,7 @@ void vote_one_kf(const Pt* map, size_t M, const Pt* scan, size_t S, const double
  * ------------------------------------------------------------------------------------- */
 struct OctreeFrame { double minx, miny, minz; double res; unsigned depth; bool ok; };
 
+OctreeFrame octree_frame_of_box(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float leaf);
 OctreeFrame octree_frame(const Pt* pts, size_t n, float leaf)
 {
     OctreeFrame f; f.ok = false; f.res = (double)leaf; f.depth = 0; f.minx = f.miny = f.minz = 0;
@@ -182,6 +183,13 @@ OctreeFrame octree_frame(const Pt* pts, size_t n, float leaf)
         mnx = std::min(mnx, pts[i].x); mny = std::min(mny, pts[i].y); mnz = std::min(mnz, pts[i].z);
         mxx = std::max(mxx, pts[i].x); mxy = std::max(mxy, pts[i].y); mxz = std::max(mxz, pts[i].z);
     }
+    return octree_frame_of_box(mnx, mny, mnz, mxx, mxy, mxz, leaf);
+}
+/* the frame PCL derives from a bounding box (getMinMax3D result): used directly by the multi-rank tests, where the box is that of a larger
+ * cloud the points are a part of (key-range exchange) */
+OctreeFrame octree_frame_of_box(float mnx, float mny, float mnz, float mxx, float mxy, float mxz, float leaf)
+{
+    OctreeFrame f; f.ok = false; f.res = (double)leaf; f.depth = 0; f.minx = f.miny = f.minz = 0;
     const float eps512 = FLT_EPSILON * 512.0f;
     double min_x = mnx, min_y = mny, min_z = mnz;
     double max_x = (float)(mxx + eps512), max_y = (float)(mxy + eps512), max_z = (float)(mxz + eps512);
@@ -210,12 +218,12 @@ inline uint64_t morton_xyz(unsigned kx, unsigned ky, unsigned kz, unsigned depth
     return m;
 }
 
-void voxel_centroid(const Cloud& in, float leaf, Cloud& out)
+void voxel_centroid(const Cloud& in, float leaf, Cloud& out, const float* box = nullptr)
 {
     const size_t n = in.size();
     Cloud res;
     if (n == 0) { out.swap(res); return; }
-    OctreeFrame f = octree_frame(in.data(), n, leaf);
+    OctreeFrame f = box ? octree_frame_of_box(box[0], box[1], box[2], box[3], box[4], box[5], leaf) : octree_frame(in.data(), n, leaf);
     if (!f.ok) { fprintf(stderr, "[oracle] voxel_centroid: octree depth > 21 unsupported\n"); out.swap(res); return; }
     std::vector<std::pair<uint64_t, uint32_t>> keyed(n);
     for (size_t i = 0; i < n; ++i) {
@@ -711,6 +719,25 @@ void orc_vote_labels(const float* map, size_t M, const float* scans, const uint6
 #pragma omp critical
         for (size_t i = 0; i < M; ++i) labels[i] |= local[i];
     }
+}
+
+/* multi-rank tests only: the voxel grid of `pts` under the octree frame of the box mn_mx[6] (of a larger cloud the points are part of), and the
+ * points' Morton keys under that frame */
+size_t orc_voxel_centroid_box(const float* pts, size_t n, const float* mn_mx, float leaf, float* out, size_t cap)
+{
+    Cloud in(reinterpret_cast<const Pt*>(pts), reinterpret_cast<const Pt*>(pts) + n), o;
+    voxel_centroid(in, leaf, o, mn_mx);
+    for (size_t i = 0; i < o.size() && i < cap && out; ++i) reinterpret_cast<Pt*>(out)[i] = o[i];
+    return o.size();
+}
+int orc_voxel_keys_box(const float* pts, size_t n, const float* mn_mx, float leaf, uint64_t* keys)
+{
+    const OctreeFrame f = octree_frame_of_box(mn_mx[0], mn_mx[1], mn_mx[2], mn_mx[3], mn_mx[4], mn_mx[5], leaf);
+    if (!f.ok) return -1;
+    const Pt* p = reinterpret_cast<const Pt*>(pts);
+    for (size_t i = 0; i < n; ++i)
+        keys[i] = morton_xyz((unsigned)(((double)p[i].x - f.minx) / f.res), (unsigned)(((double)p[i].y - f.miny) / f.res), (unsigned)(((double)p[i].z - f.minz) / f.res), f.depth);
+    return (int)f.depth;
 }
 
 size_t orc_voxel_centroid(const float* pts, size_t n, float leaf, float* out, size_t cap)

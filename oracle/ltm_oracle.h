@@ -71,6 +71,9 @@ void orc_vote_labels(const float* map, size_t M, const float* scans, const uint6
 /* ---- voxel centroid (utility.cpp:204-219; PCL OctreePointCloudVoxelCentroid) ----
  * returns number of voxels; writes at most cap points to out (may be NULL to count). */
 size_t orc_voxel_centroid(const float* pts, size_t n, float leaf, float* out, size_t cap);
+/* multi-rank tests: grid / Morton keys under the octree frame of a GIVEN box mn_mx = {min x y z, max x y z}; keys returns the depth (< 0: too deep) */
+size_t orc_voxel_centroid_box(const float* pts, size_t n, const float* mn_mx, float leaf, float* out, size_t cap);
+int orc_voxel_keys_box(const float* pts, size_t n, const float* mn_mx, float leaf, uint64_t* keys);
 
 /* ---- reprojection (utility.cpp:74-89, Session.cpp:348-360) ----
  * out gets at most cap points; out_offsets has (kf_end-kf_begin)+1 entries. returns total points. */

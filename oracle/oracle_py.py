@@ -37,6 +37,8 @@ def lib():
         L.orc_rad2deg.restype = _f
         L.orc_rad2deg.argtypes = [_f]
         L.orc_voxel_centroid.restype = _sz
+        L.orc_voxel_centroid_box.restype = _sz
+        L.orc_voxel_keys_box.restype = _i
         L.orc_reproject.restype = _sz
         L.orc_preclean.restype = _sz
         L.orc_voxel_grid.restype = _sz
@@ -159,6 +161,21 @@ def voxel_centroid(pts, leaf):
     out = np.empty((max(a.shape[0], 1), 4), dtype=np.float32)
     n = lib().orc_voxel_centroid(_p(a), _sz(a.shape[0]), _f(leaf), _p(out), _sz(out.shape[0]))
     return out[:n].copy()
+
+
+def voxel_centroid_box(pts, mn, mx, leaf):
+    a = _pts(pts); out = np.empty_like(a)
+    box = np.ascontiguousarray(np.concatenate([mn, mx]), dtype=np.float32)
+    n = lib().orc_voxel_centroid_box(_p(a), _sz(a.shape[0]), _p(box), _f(leaf), _p(out), _sz(out.shape[0]))
+    return out[:n].copy()
+
+
+def voxel_keys_box(pts, mn, mx, leaf):
+    a = _pts(pts); keys = np.empty(a.shape[0], np.uint64)
+    box = np.ascontiguousarray(np.concatenate([mn, mx]), dtype=np.float32)
+    depth = lib().orc_voxel_keys_box(_p(a), _sz(a.shape[0]), _p(box), _f(leaf), _p(keys))
+    assert depth >= 0
+    return keys, depth
 
 
 def reproject(cmap, inv_poses, b2l, vfov, hfov, alpha=3.0, kf_begin=0, kf_end=None, threads=1):

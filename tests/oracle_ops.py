@@ -55,6 +55,31 @@ class OracleOps:
         full = orc.voxel_centroid(c, leaf)
         return _c(full[(len(full) * shard) // n_shards:(len(full) * (shard + 1)) // n_shards])
 
+    # ---- key-range exchange (dist.ShardedOps.merge_voxel): box, 4096-bin key histogram, order-preserving split, grid under a given box
+    def bbox(self, c):
+        a = np.asarray(c).reshape(-1, 4)
+        if len(a) == 0:
+            return np.full(3, np.inf, np.float32), np.full(3, -np.inf, np.float32)
+        return a[:, :3].min(0), a[:, :3].max(0)
+
+    def _bins(self, c, mn, mx, leaf):
+        keys, depth = orc.voxel_keys_box(np.asarray(c).reshape(-1, 4), mn, mx, leaf)
+        return (keys >> np.uint64(max(3 * depth - 12, 0))).astype(np.int64)        # top 12 bits of the Morton code: a prefix, so no voxel straddles a bin
+
+    def voxel_key_histogram(self, c, mn, mx, leaf):
+        if len(c) == 0:
+            return np.zeros(4096, np.uint32)
+        return np.bincount(self._bins(c, mn, mx, leaf), minlength=4096).astype(np.uint32)
+
+    def voxel_key_split(self, c, mn, mx, leaf, cuts):
+        a = np.asarray(c).reshape(-1, 4)
+        if len(a) == 0:
+            return [self.empty_cloud() for _ in range(len(cuts) - 1)]
+        b = self._bins(c, mn, mx, leaf)
+        return [_c(a[(b >= cuts[r]) & (b < cuts[r + 1])]) for r in range(len(cuts) - 1)]
+
+    def voxel_box(self, c, mn, mx, leaf): return _c(orc.voxel_centroid_box(c, mn, mx, leaf)) if len(c) else self.empty_cloud()
+
     def cloud_to_tensor(self, c): return torch.from_numpy(np.ascontiguousarray(np.asarray(c), dtype=np.float32).reshape(-1, 4))
     def cloud_from_tensor(self, t): return _c(t.numpy())
 
