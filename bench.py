@@ -303,7 +303,8 @@ def main():
             "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
             "t_total": t_total, "parity_fullsize": parity_fullsize_status(),
             "scaling_model": scaling_model({k: v["ms"] / args.steps for k, v in prof.items()}, ms_per_step,
-                                           {k: (v[0] / args.steps, v[1] / args.steps) for k, v in meter.events.items()}) if meter else None,
+                                           {k: (v[0] / args.steps, v[1] / args.steps) for k, v in meter.events.items()},
+                                           sharded_voxel_fraction=(meter.sharded_voxel_points / max(prof.get("voxel", {}).get("units", 0.0), 1.0))) if meter else None,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},

@@ -20,6 +20,7 @@ Everything else (merge, the tiny weak->strong ND split) is replicated.  The coll
 torch.distributed calls (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests), so the same code is exercised
 on CPU with world_size 2.  `ops` is any object with the stage interface of removerter.HipOps.
 """
+import numpy as np
 import torch
 
 
@@ -189,6 +190,59 @@ class ShardedOps:
     def merge_to_global(self, scans, poses):
         return self.ops.merge_to_global(self.materialize(scans), poses)
 
+    # ---- merge + voxel grid of a RANK-LOCAL scan set: key-range exchange instead of "all-gather the scans, grid 45 M points on every rank"
+    @staticmethod
+    def balanced_cuts(hist, parts):
+        """bin cuts [0, ..., 4096] so that every part gets about the same number of points; identical on every rank (same histogram)"""
+        total = int(hist.sum())
+        cum = np.concatenate([[0], np.cumsum(hist.astype(np.int64))])
+        cuts = [0]
+        for r in range(1, parts):
+            want = (total * r) // parts
+            cuts.append(max(int(np.searchsorted(cum, want, side="left")), cuts[-1]))
+        cuts.append(len(hist))
+        return [min(c, len(hist)) for c in cuts]
+
+    def _alltoall_clouds(self, parts):
+        """parts[r] goes to rank r; returns what this rank received, concatenated in SOURCE-rank order (= keyframe order)"""
+        ts = [self.ops.cloud_to_tensor(p) for p in parts]
+        dev = ts[0].device
+        send_n = torch.tensor([t.shape[0] for t in ts], dtype=torch.int64, device=dev)
+        recv_n = torch.empty_like(send_n)
+        self.dist.all_to_all_single(recv_n, send_n, group=self.group)
+        send_rows, recv_rows = [int(x) for x in send_n.cpu().tolist()], [int(x) for x in recv_n.cpu().tolist()]
+        send = torch.cat(ts).contiguous() if sum(send_rows) else torch.zeros((0, 4), dtype=torch.float32, device=dev)
+        recv = torch.empty((sum(recv_rows), 4), dtype=torch.float32, device=dev)
+        self.dist.all_to_all_single(recv, send, output_split_sizes=recv_rows, input_split_sizes=send_rows, group=self.group)
+        return self.ops.cloud_from_tensor(recv)
+
+    def merge_voxel(self, scans, poses, leaf):
+        """voxel(merge_to_global(scans, poses), leaf) -- bit for bit -- for a scan set whose keyframes live on their ranks: every rank merges its
+        own keyframes, the ranks agree on the bounding box (min / max all-reduce) and on cuts of the octree key space (summed 4096-bin histogram),
+        every point moves ONCE to the rank that owns its key range (all-to-all; arrival order = rank order = keyframe order = the input order of the
+        single-GPU merge), each rank grids its range under the common frame, and the centroid lists are all-gathered in rank order."""
+        if self.world == 1 or not isinstance(scans, LazyScans):
+            return self.voxel(self.ops.merge_to_global(self.materialize(scans), poses), leaf)
+        kb, ke = self._check(scans, poses)
+        loc = self.ops.merge_to_global(scans.local, self._local_poses(poses))
+        mn, mx = self.ops.bbox(loc)
+        dev = self.ops.cloud_to_tensor(loc).device
+        box = torch.tensor([float(v) for v in mn] + [-float(v) for v in mx], dtype=torch.float32, device=dev)     # float32 min / max are exact
+        self.dist.all_reduce(box, op=self.dist.ReduceOp.MIN, group=self.group)
+        box = box.cpu().numpy()
+        gmn, gmx = box[:3].astype(np.float32), (-box[3:]).astype(np.float32)
+        if not np.isfinite(gmn).all():                   # no rank has a point
+            return self.ops.empty_cloud()
+        hist = torch.as_tensor(self.ops.voxel_key_histogram(loc, gmn, gmx, leaf).astype(np.int64), device=dev)
+        self.dist.all_reduce(hist, op=self.dist.ReduceOp.SUM, group=self.group)
+        cuts = self.balanced_cuts(hist.cpu().numpy(), self.world)
+        mine = self._alltoall_clouds(self.ops.voxel_key_split(loc, gmn, gmx, leaf, cuts))
+        return self._allgather_cloud(self.ops.voxel_box(mine, gmn, gmx, leaf))
+
+    def merge_voxel_batch(self, merges, clouds, leaf):
+        outs = [self.merge_voxel(s, p, leaf) for s, p in merges]
+        return outs + (self.voxel_batch(list(clouds), leaf) if clouds else [])
+
 
 class CommMeter:
     """What the keyframe-sharded pipeline WOULD exchange, recorded on a single-GPU run: wraps the plain stage operations and notes, for every
@@ -200,7 +254,8 @@ class CommMeter:
 
     def __init__(self, ops):
         self.ops = ops
-        self.events = {"label_allreduce": [0, 0], "scans_allgather": [0, 0], "voxel_allgather": [0, 0]}      # [count, payload bytes]
+        self.events = {"label_allreduce": [0, 0], "scans_allgather": [0, 0], "voxel_allgather": [0, 0], "points_alltoall": [0, 0]}      # [count, payload bytes]
+        self.sharded_voxel_points = 0         # input points of the voxel grids whose sort divides by the number of ranks
         # scan sets that would be rank-local (LazyScans) under ShardedOps.  The objects themselves are tagged: an id() of a collected
         # scan set can be handed to an unrelated, replicated one by CPython, which would count collectives that never happen
         self._tag = "_comm_meter_local_%x" % id(self)
@@ -211,6 +266,7 @@ class CommMeter:
     def reset(self):
         for v in self.events.values():
             v[0] = v[1] = 0
+        self.sharded_voxel_points = 0
 
     def _note(self, kind, nbytes):
         self.events[kind][0] += 1
@@ -247,10 +303,33 @@ class CommMeter:
             self._note("scans_allgather", 16 * n_pts + 8 * (n_kf + 2))
         return self.ops.merge_to_global(scans, poses)
 
+    def merge_voxel_batch(self, merges, clouds, leaf):
+        """what ShardedOps.merge_voxel exchanges for a rank-local scan set: two tiny all-reduces (box, histogram), ONE all-to-all of the points
+        (every point crosses the fabric once: a rank receives 1/N of them) and the all-gather of the centroid list"""
+        if hasattr(self.ops, "merge_voxel_batch"):
+            outs = self.ops.merge_voxel_batch(merges, clouds, leaf)
+        else:
+            outs = self.ops.voxel_batch([self.ops.merge_to_global(s, p) for s, p in merges] + list(clouds), leaf)
+        for (scans, _), o in zip(merges, outs):
+            if self._is_local(scans):
+                _, n_pts = scans.info()
+                self._note("points_alltoall", 16 * n_pts)
+                self._note("voxel_allgather", 16 * self.ops.size(o))
+                self.sharded_voxel_points += n_pts
+            elif self.ops.size(o) and scans.info()[1] >= ShardedOps.VOXEL_SHARD_MIN:
+                self._note("voxel_allgather", 16 * self.ops.size(o))
+                self.sharded_voxel_points += scans.info()[1]
+        for c, o in zip(clouds, outs[len(merges):]):
+            if self.ops.size(c) >= ShardedOps.VOXEL_SHARD_MIN:
+                self._note("voxel_allgather", 16 * self.ops.size(o))
+                self.sharded_voxel_points += self.ops.size(c)
+        return outs
+
     def voxel(self, c, leaf):
         out = self.ops.voxel(c, leaf)
         if self.ops.size(c) >= ShardedOps.VOXEL_SHARD_MIN:
             self._note("voxel_allgather", 16 * self.ops.size(out))
+            self.sharded_voxel_points += self.ops.size(c)
         return out
 
     def voxel_batch(self, clouds, leaf):
@@ -258,6 +337,7 @@ class CommMeter:
         for c, o in zip(clouds, outs):
             if self.ops.size(c) >= ShardedOps.VOXEL_SHARD_MIN:
                 self._note("voxel_allgather", 16 * self.ops.size(o))
+                self.sharded_voxel_points += self.ops.size(c)
         return outs
 
 
@@ -266,23 +346,32 @@ SHARDED_CLASSES = ("vote_map_cull", "vote_map_exact", "vote_scan", "vote_compare
                    "knn_query_p2", "voxel_scanset", "voxel_grid_scanset")
 
 
-def scaling_model(class_ms_per_step, step_ms, events_per_step, ranks=(2, 4, 8), link_gbs=150.0, latency_us=25.0):
+def scaling_model(class_ms_per_step, step_ms, events_per_step, ranks=(2, 4, 8), link_gbs=150.0, latency_us=25.0, sharded_voxel_fraction=0.0):
     """strong-scaling estimate of ONE pair run from single-GPU measurements: T(N) = replicated + sharded / N + collectives(N), with the kernel
     time of the sharded classes measured with HIP events, replicated = the rest of the step (replicated kernels + host gaps), and ring
     collectives at `link_gbs` per direction and `latency_us` each (assumptions, stated in the output: no multi-GPU node was reachable)"""
     sharded = sum(v for k, v in class_ms_per_step.items() if k in SHARDED_CLASSES)
-    # voxel grids large enough to be sharded (>= VOXEL_SHARD_MIN points): their sort divides too; approximated by the payload they return
+    # the voxel grids whose input is split over the ranks (key-range exchange of rank-local scans, voxel_centroid_shard of large replicated
+    # clouds): their share of the `voxel` class is taken as their share of its input POINTS (sort and tail are linear in them), and the merges
+    # in front of them (`merge` class) run on rank-local keyframes
+    sharded += sharded_voxel_fraction * class_ms_per_step.get("voxel", 0.0) + (class_ms_per_step.get("merge", 0.0) if sharded_voxel_fraction > 0 else 0.0)
     replicated = max(step_ms - sharded, 0.0)
     out = {"replicated_ms": round(replicated, 3), "sharded_ms": round(sharded, 3), "comm_events_per_step": {k: {"count": v[0], "payload_bytes": v[1]} for k, v in events_per_step.items()},
            "comm_bytes_per_step": int(sum(v[1] for v in events_per_step.values())),
            "assumptions": {"ring_bandwidth_GB_s_per_direction": link_gbs, "latency_us_per_collective": latency_us,
-                           "all_reduce_bytes_on_the_wire_per_rank": "2 (N-1)/N x payload", "all_gather": "(N-1)/N x payload"},
+                           "all_reduce_bytes_on_the_wire_per_rank": "2 (N-1)/N x payload", "all_gather": "(N-1)/N x payload",
+                           "all_to_all": "a rank sends and receives (N-1)/N^2 x payload, spread over min(N-1, 7) point-to-point xGMI links",
+                           "sharded_voxel_fraction_of_the_voxel_class": round(sharded_voxel_fraction, 4)},
            "status": "MODEL from single-GPU measurements -- unmeasured on multi-GPU hardware", "ranks": {}}
     for n in ranks:
         comm_ms = 0.0
         for kind, (cnt, nbytes) in events_per_step.items():
-            factor = 2.0 * (n - 1) / n if kind == "label_allreduce" else (n - 1) / n
-            comm_ms += 1e3 * factor * nbytes / (link_gbs * 1e9) + cnt * latency_us * 1e-3 * (2 if kind == "scans_allgather" else 1)
+            if kind == "points_alltoall":
+                factor = (n - 1) / float(n * n) / min(n - 1, 7)
+            else:
+                factor = 2.0 * (n - 1) / n if kind == "label_allreduce" else (n - 1) / n
+            comm_ms += 1e3 * factor * nbytes / (link_gbs * 1e9) + cnt * latency_us * 1e-3 * (2 if kind in ("scans_allgather", "points_alltoall") else 1)
+        received = sum((nbytes / n if kind == "points_alltoall" else nbytes) for kind, (cnt, nbytes) in events_per_step.items())
         t = replicated + sharded / n + comm_ms
-        out["ranks"][str(n)] = {"comm_ms": round(comm_ms, 3), "step_ms": round(t, 3), "speedup": round(step_ms / t, 3)}
+        out["ranks"][str(n)] = {"comm_ms": round(comm_ms, 3), "step_ms": round(t, 3), "speedup": round(step_ms / t, 3), "bytes_received_per_rank_per_step": int(received)}
     return out

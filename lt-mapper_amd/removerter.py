@@ -174,6 +174,14 @@ class Removerter:
     def octreeDownsamplingBatch(self, clouds, leaf):    # the same for several independent clouds (consecutive calls in the reference)
         return self.ops.voxel_batch(list(clouds), leaf)
 
+    def mergeVoxelBatch(self, merges, clouds, leaf):
+        """octreeDownsampling(mergeScansWithinGlobalCoordUtil(scans, poses)) for every (scans, poses) of `merges` (utility.cpp:170-192 + :204-219) and
+        octreeDownsampling of every cloud of `clouds`, as one batch.  One GPU: merges, then all grids together.  Keyframe-sharded: the merges of
+        rank-local scan sets become key-range exchanges (dist.ShardedOps.merge_voxel) instead of all-gathers of the scans."""
+        if hasattr(self.ops, "merge_voxel_batch"):
+            return self.ops.merge_voxel_batch(list(merges), list(clouds), leaf)
+        return self.ops.voxel_batch([self.ops.merge_to_global(s, p) for s, p in merges] + list(clouds), leaf)
+
     def _append(self, a, b):                            # `*a += *b`
         if a is None:
             return self.ops.clone(b)
@@ -225,11 +233,10 @@ class Removerter:
         if not self.P.gpu_skip_hd_knn:
             t0 = time.perf_counter()
             k, thr = self.P.num_nn_points_within, self.P.dist_nn_points_within
-            merged = []
             for s in (C, Q):
                 _, s.keyframe_scans_dynamic_ = self.ops.knn_partition(s.map_global_curr_static_, s.keyframe_scans_, s.keyframe_poses, k, thr)  # Session.cpp:487-504
-                merged.append(self.ops.merge_to_global(s.keyframe_scans_dynamic_, s.keyframe_poses))
-            self.outputs["central_sess_high_dyn"], self.outputs["query_sess_high_dyn"] = self.octreeDownsamplingBatch(merged, 0.05)
+            self.outputs["central_sess_high_dyn"], self.outputs["query_sess_high_dyn"] = self.mergeVoxelBatch(
+                [(s.keyframe_scans_dynamic_, s.keyframe_poses) for s in (C, Q)], [], 0.05)
             self._tick("hd_knn", t0)
 
     def parseStaticScansViaProjection(self):            # Removerter.cpp:1527-1538, Session.cpp:305-309
@@ -256,7 +263,7 @@ class Removerter:
         self._tick("ld_knn", t0)
         t0 = time.perf_counter()
         # strong ND: constructGlobalNDMap (Session.cpp:430-435), filterStrongND (:1403-1411), weak->strong propagation (Session.cpp:452-484)
-        C.map_global_nd_ = self.octreeDownsampling(self.ops.merge_to_global(C.scans_knn_diff_, C.keyframe_poses), 0.05)
+        C.map_global_nd_ = self.mergeVoxelBatch([(C.scans_knn_diff_, C.keyframe_poses)], [], 0.05)[0]
         maps = (C.map_global_nd_, None, None)
         for _ in range(3):
             maps = self._removeOnceLD(maps, Q, 2.5, 1)
@@ -266,7 +273,7 @@ class Removerter:
             C.map_global_nd_strong_ = self.ops.concat([C.map_global_nd_strong_, add])
             C.map_global_nd_weak_ = new_weak
         # strong PD: constructGlobalPDMap (Session.cpp:437-445), filterStrongPD (:1395-1401)
-        Q.map_global_pd_ = self.octreeDownsampling(self.ops.merge_to_global(Q.scans_knn_diff_, Q.keyframe_poses), 0.05)
+        Q.map_global_pd_ = self.mergeVoxelBatch([(Q.scans_knn_diff_, Q.keyframe_poses)], [], 0.05)[0]
         Q.map_global_pd_orig_ = Q.map_global_pd_
         maps = (Q.map_global_pd_, None, None)
         for _ in range(3):
@@ -277,13 +284,13 @@ class Removerter:
         t0 = time.perf_counter()
         # :1443-1480 merged maps "for visual debug" -- several of these re-voxelise state that Step 3 reads
         o = self.outputs
-        ins = [self.ops.merge_to_global(Q.scans_knn_coexist_, Q.keyframe_poses), self.ops.merge_to_global(C.scans_knn_coexist_, C.keyframe_poses),
-               self.ops.merge_to_global(Q.scans_knn_diff_, Q.keyframe_poses), self.ops.merge_to_global(C.scans_knn_diff_, C.keyframe_poses),
-               C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_]
+        merges = [(Q.scans_knn_coexist_, Q.keyframe_poses), (C.scans_knn_coexist_, C.keyframe_poses),
+                  (Q.scans_knn_diff_, Q.keyframe_poses), (C.scans_knn_diff_, C.keyframe_poses)]
+        ins = [C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_]
         has_strong_nd = self.ops.size(C.map_global_nd_strong_) != 0
         if has_strong_nd:
             ins.append(C.map_global_nd_strong_)
-        res = self.octreeDownsamplingBatch(ins, 0.05)      # eight independent grids (:1445-1476), one batch
+        res = self.mergeVoxelBatch(merges, ins, 0.05)      # eight independent grids (:1445-1476), one batch
         self._union_q = o["union_map_queryside"] = res[0]
         self._union_c = o["union_map_centralside"] = res[1]
         o["pd_map"], o["nd_map"] = res[2], res[3]

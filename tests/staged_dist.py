@@ -23,6 +23,13 @@ class StagedDist:
             o.copy_(x)
 
     @staticmethod
+    def all_to_all_single(out, inp, output_split_sizes=None, input_split_sizes=None, group=None):
+        ci = inp.cpu().contiguous()
+        co = torch.empty(out.shape, dtype=out.dtype)
+        dist.all_to_all_single(co, ci, output_split_sizes, input_split_sizes, group=group)
+        out.copy_(co)
+
+    @staticmethod
     def all_gather_object(objs, obj, group=None):
         dist.all_gather_object(objs, obj, group=group)
 

@@ -643,3 +643,31 @@ def test_voxel_identity_shortcut_and_fused_tail_equal_the_plain_path(ltm, orc, s
         outs[tag] = (k2.download(), f2.download())
         ctx.close()
     assert (outs["default"][0].view(np.uint32) == outs["plain"][0].view(np.uint32)).all()
+
+
+def test_key_range_exchange_pieces_reassemble_the_single_gpu_grid(gpu_ctx, orc, small_pair):
+    """multi-GPU building blocks (include/ltm.h: ltm_cloud_bbox, ltm_voxel_key_histogram, ltm_voxel_key_split, ltm_voxel_centroid_box): a merged cloud
+    cut into "rank-local" slices, every slice split by key range under the WHOLE cloud's box, the ranges reassembled in slice order and gridded under
+    that box -- concatenated they must be the grid of the whole cloud, for balanced cuts of 2, 3 and 8 ranks and for degenerate cuts"""
+    from ltmapper_amd.dist import ShardedOps
+    C, _ = small_pair
+    merged = orc.merge_to_global(C["scans"], C["offsets"], C["poses"], I4)
+    want = orc.voxel_centroid(merged, 0.05)
+    n = len(merged)
+    for world in (2, 3, 8):
+        bounds = [(n * r) // world for r in range(world + 1)]
+        bounds[1] = bounds[0]                                   # one rank without points
+        slices = [gpu_ctx.upload(merged[bounds[r]:bounds[r + 1]]) for r in range(world)]
+        boxes = [gpu_ctx.bbox(s) for s in slices]
+        assert not np.isfinite(boxes[0][0]).any(), "an empty cloud reports the box (+inf, -inf)"
+        mn = np.min([b[0] for b in boxes], axis=0); mx = np.max([b[1] for b in boxes], axis=0)
+        assert (mn == merged[:, :3].min(0)).all() and (mx == merged[:, :3].max(0)).all()
+        hist = sum(gpu_ctx.voxel_key_histogram(s, mn, mx, 0.05).astype(np.int64) for s in slices)
+        assert hist.sum() == n
+        for cuts in (ShardedOps.balanced_cuts(hist, world), [0] * world + [4096], [0] + [4096] * world):
+            parts = [gpu_ctx.voxel_key_split(s, mn, mx, 0.05, cuts) for s in slices]            # parts[source][destination]
+            outs = []
+            for dst in range(world):
+                got = np.concatenate([parts[src][dst].download() for src in range(world)])      # arrival order = source order = input order
+                outs.append(gpu_ctx.voxel_centroid_box(gpu_ctx.upload(got), mn, mx, 0.05).download())
+            assert_clouds_equal(np.concatenate(outs), want, f"world {world} cuts {cuts[:4]}...")

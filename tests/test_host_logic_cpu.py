@@ -245,8 +245,9 @@ def test_cascade_over_gloo_hands_over_the_reloaded_scans(orc):
 
 
 def test_comm_meter_counts_what_the_sharded_pipeline_would_exchange(orc):
-    """dist.CommMeter on a single process: one label all-reduce of M bytes per vote pass, a scan-set all-gather in front of every merge of
-    rank-local scans, none for the replicated session scans; the results are untouched; scaling_model turns the totals into step times"""
+    """dist.CommMeter on a single process: one label all-reduce of M bytes per vote pass, a key-range exchange (one all-to-all of the points + the
+    all-gather of the centroid list) for every merge + grid of rank-local scans (round 4: no scan-set all-gather any more), none for the replicated
+    session scans; the results are untouched; scaling_model turns the totals into step times"""
     import ltmapper_amd  # noqa: F401
     from ltmapper_amd.dist import CommMeter, scaling_model
     from oracle_ops import OracleOps
@@ -258,8 +259,11 @@ def test_comm_meter_counts_what_the_sharded_pipeline_would_exchange(orc):
     ev = meter.events
     assert ev["label_allreduce"][0] == 2 + 3 + 3, "single-res: removeOnce x 2 sessions, 3 ND and 3 PD filter passes"
     assert ev["label_allreduce"][1] > 0
-    assert ev["scans_allgather"][0] == 2 + 2 + 4, "HD dynamic scans x 2, ND / PD diff scans, and the four merges of the debug maps"
-    assert ev["voxel_allgather"][0] == 0, "tiny maps stay replicated"
-    m = scaling_model({"vote_map_cull": 70.0, "voxel": 20.0, "knn_query": 10.0}, 110.0, {k: (v[0], v[1]) for k, v in ev.items()})
-    assert m["sharded_ms"] == 80.0 and m["replicated_ms"] == 30.0
+    assert ev["scans_allgather"][0] == 0, "merges of rank-local scans go through the key-range exchange"
+    assert ev["points_alltoall"][0] == 2 + 2 + 4, "HD dynamic scans x 2, ND / PD diff scans, and the four merges of the debug maps"
+    assert ev["voxel_allgather"][0] == ev["points_alltoall"][0], "one centroid all-gather per exchange (tiny replicated maps stay replicated)"
+    assert ev["points_alltoall"][1] > 0 and meter.sharded_voxel_points * 16 == ev["points_alltoall"][1]
+    m = scaling_model({"vote_map_cull": 70.0, "voxel": 20.0, "knn_query": 10.0, "merge": 4.0}, 110.0, {k: (v[0], v[1]) for k, v in ev.items()}, sharded_voxel_fraction=0.5)
+    assert m["sharded_ms"] == 80.0 + 10.0 + 4.0 and m["replicated_ms"] == 16.0
     assert m["ranks"]["8"]["step_ms"] < m["ranks"]["2"]["step_ms"] < 110.0
+    assert m["ranks"]["8"]["bytes_received_per_rank_per_step"] < m["ranks"]["2"]["bytes_received_per_rank_per_step"]
