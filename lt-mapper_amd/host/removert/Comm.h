@@ -35,6 +35,9 @@ public:
     virtual void allGatherU64(ltm_ctx* ctx, uint64_t mine, std::vector<uint64_t>& all) = 0;
     // concatenation in rank order of every rank's device array: recv_dev must hold sum(bytes[r]); bytes[rank()] == send_bytes
     virtual void allGatherV(ltm_ctx* ctx, const void* send_dev, size_t send_bytes, void* recv_dev, const std::vector<uint64_t>& bytes) = 0;
+    // all-to-all-v of device buffers: send_bytes[r] consecutive bytes of send_dev (in rank order) go to rank r; what arrives from rank r lands
+    // at recv_dev after the pieces of ranks 0..r-1 -- recv_bytes[r] bytes each (the caller has exchanged the sizes, e.g. with allGatherV)
+    virtual void allToAllV(ltm_ctx* ctx, const void* send_dev, const std::vector<uint64_t>& send_bytes, void* recv_dev, const std::vector<uint64_t>& recv_bytes) = 0;
     virtual void barrier() = 0;
     // a rank died: release the others instead of letting them wait for an exchange that will never complete
     virtual void abort() {}

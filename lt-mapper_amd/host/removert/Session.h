@@ -148,6 +148,10 @@ public:
     // the scans / poses / keyframe range to hand to a per-keyframe C-ABI stage for `scans` (whole or shard)
     void stageArgs(const ScansPtr& scans, ltm_poses* poses, size_t* kb, size_t* ke) const;
     CloudPtr mergeScansToGlobal(const ScansPtr& scans) const;        // utility.cpp:170-192
+    // octreeDownsampling(mergeScansToGlobal(scans), leaf), bit for bit.  Keyframe-sharded run with a rank-local `scans`: the key-range exchange of
+    // include/ltm.h (box and histogram combined over the ranks, one all-to-all of the points, all-gather of the centroid lists) instead of
+    // gathering the scans and gridding the whole merge on every rank
+    CloudPtr mergeVoxel(const ScansPtr& scans, float leaf) const;
     CloudPtr octreeDownsampling(const CloudPtr& src, float leaf) const;   // utility.cpp:204-219
     // the same for several independent clouds (consecutive octreeDownsampling calls of the reference): one ltm_voxel_centroid_batch,
     // i.e. two host round trips for all of them

@@ -25,7 +25,8 @@ struct LocalGroup
     bool failed = false;
     std::vector<std::vector<uint8_t>> stage;      // one staging buffer per rank
     std::vector<uint64_t> scalars;
-    explicit LocalGroup(int w) : world(w), stage((size_t)w), scalars((size_t)w, 0) {}
+    std::vector<std::vector<uint64_t>> a2a_sizes;  // allToAllV: every rank's send table
+    explicit LocalGroup(int w) : world(w), stage((size_t)w), scalars((size_t)w, 0), a2a_sizes((size_t)w) {}
 
     void barrier()
     {
@@ -106,6 +107,30 @@ public:
             for (int r = 0; r < g_->world; ++r) {
                 if (bytes[(size_t)r]) check(ctx, ltm_buffer_copy(ctx, static_cast<uint8_t*>(recv_dev) + at, g_->stage[(size_t)r].data(), bytes[(size_t)r], 0), "ltm_buffer_copy h2d");
                 at += bytes[(size_t)r];
+            }
+            g_->barrier();
+        } catch (...) { g_->fail(); throw; }
+    }
+
+    void allToAllV(ltm_ctx* ctx, const void* send_dev, const std::vector<uint64_t>& send_bytes, void* recv_dev, const std::vector<uint64_t>& recv_bytes) override
+    {
+        try {
+            if ((int)send_bytes.size() != g_->world || (int)recv_bytes.size() != g_->world) throw std::runtime_error("LocalComm::allToAllV: size tables do not match the world");
+            size_t total = 0;
+            for (uint64_t b : send_bytes) total += b;
+            std::vector<uint8_t>& mine = g_->stage[(size_t)rank_];
+            mine.resize(total);
+            if (total) check(ctx, ltm_buffer_copy(ctx, mine.data(), send_dev, total, 1), "ltm_buffer_copy d2h");
+            g_->a2a_sizes[(size_t)rank_] = send_bytes;
+            g_->barrier();
+            size_t at = 0;
+            for (int r = 0; r < g_->world; ++r) {
+                const std::vector<uint64_t>& theirs = g_->a2a_sizes[(size_t)r];
+                if (theirs[(size_t)rank_] != recv_bytes[(size_t)r]) throw std::runtime_error("LocalComm::allToAllV: a sender and its receiver disagree on a piece size");
+                size_t off = 0;
+                for (int q = 0; q < rank_; ++q) off += theirs[(size_t)q];
+                if (recv_bytes[(size_t)r]) check(ctx, ltm_buffer_copy(ctx, static_cast<uint8_t*>(recv_dev) + at, g_->stage[(size_t)r].data() + off, recv_bytes[(size_t)r], 0), "ltm_buffer_copy h2d");
+                at += recv_bytes[(size_t)r];
             }
             g_->barrier();
         } catch (...) { g_->fail(); throw; }

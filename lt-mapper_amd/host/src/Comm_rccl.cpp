@@ -94,6 +94,31 @@ public:
         LTM_NCCL(ncclGroupEnd());
     }
 
+    // every point of a merge moves once, to the rank that owns its key range: grouped point-to-point sends and receives -- on xGMI's full mesh all
+    // seven links of a GPU carry a piece at the same time, unlike the ring of an all-gather
+    void allToAllV(ltm_ctx* ctx, const void* send_dev, const std::vector<uint64_t>& send_bytes, void* recv_dev, const std::vector<uint64_t>& recv_bytes) override
+    {
+        const int w = world();
+        if ((int)send_bytes.size() != w || (int)recv_bytes.size() != w) throw std::runtime_error("RcclComm::allToAllV: size tables do not match the world");
+        LTM_HIPRT(hipSetDevice(g_->devs[(size_t)rank_]));
+        size_t so = 0, ro = 0, self_so = 0, self_ro = 0;
+        LTM_NCCL(ncclGroupStart());
+        for (int r = 0; r < w; ++r) {
+            const char* src = static_cast<const char*>(send_dev) + so;
+            char* dst = static_cast<char*>(recv_dev) + ro;
+            if (r == rank_) { self_so = so; self_ro = ro; }
+            else {
+                if (send_bytes[(size_t)r]) LTM_NCCL(ncclSend(src, send_bytes[(size_t)r], ncclChar, r, comm(), stream(ctx)));
+                if (recv_bytes[(size_t)r]) LTM_NCCL(ncclRecv(dst, recv_bytes[(size_t)r], ncclChar, r, comm(), stream(ctx)));
+            }
+            so += send_bytes[(size_t)r]; ro += recv_bytes[(size_t)r];
+        }
+        LTM_NCCL(ncclGroupEnd());
+        if (send_bytes[(size_t)rank_] != recv_bytes[(size_t)rank_]) throw std::runtime_error("RcclComm::allToAllV: own piece sizes disagree");
+        if (send_bytes[(size_t)rank_])
+            LTM_HIPRT(hipMemcpyAsync(static_cast<char*>(recv_dev) + self_ro, static_cast<const char*>(send_dev) + self_so, send_bytes[(size_t)rank_], hipMemcpyDeviceToDevice, stream(ctx)));
+    }
+
     void barrier() override {}      // every exchange is stream-ordered; the host threads never need to meet
     void abort() override { g_->abortAll(); }
 };

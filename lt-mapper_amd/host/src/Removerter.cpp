@@ -298,10 +298,14 @@ void Removerter::removeHighDynamicPoints(void)                                  
     if (gpu_skip_hd_knn_) return;
     central_sess_.extractHighDynPointsViaKnnDiff(central_sess_.map_global_curr_static_);
     query_sess_.extractHighDynPointsViaKnnDiff(query_sess_.map_global_curr_static_);
-    auto c = central_sess_.octreeDownsampling(central_sess_.mergeScansToGlobal(central_sess_.keyframe_scans_dynamic_), 0.05f);
-    auto q = query_sess_.octreeDownsampling(query_sess_.mergeScansToGlobal(query_sess_.keyframe_scans_dynamic_), 0.05f);
-    saveMap(save_pcd_directory_ + "central_sess_high_dyn.pcd", c);
-    saveMap(save_pcd_directory_ + "query_sess_high_dyn.pcd", q);
+    // merge + grid of the two sessions' dynamic scans: one batch on a single GPU; keyframe-sharded, the scans are rank-local and each merge is a
+    // key-range exchange (Session::mergeVoxel) -- the same split as lt-mapper_amd/removerter.py's mergeVoxelBatch
+    std::vector<CloudPtr> hd;
+    if (dev_->world() > 1) hd = {central_sess_.mergeVoxel(central_sess_.keyframe_scans_dynamic_, 0.05f), query_sess_.mergeVoxel(query_sess_.keyframe_scans_dynamic_, 0.05f)};
+    else hd = central_sess_.octreeDownsamplingBatch({central_sess_.mergeScansToGlobal(central_sess_.keyframe_scans_dynamic_),
+                                                    query_sess_.mergeScansToGlobal(query_sess_.keyframe_scans_dynamic_)}, 0.05f);
+    saveMap(save_pcd_directory_ + "central_sess_high_dyn.pcd", hd[0]);
+    saveMap(save_pcd_directory_ + "query_sess_high_dyn.pcd", hd[1]);
     LTM_INFO(" high dynamic maps are saved. ");
 }
 
@@ -348,11 +352,20 @@ void Removerter::detectLowDynamicPoints(void)                                   
     // :1443-1480 merged maps "for visual debug" (they also re-voxelise state that Step 3 reads)
     Session& C = central_sess_; Session& Q = query_sess_;
     const bool has_strong_nd = C.map_global_nd_strong_->size() != 0;
-    std::vector<CloudPtr> ins = {Q.mergeScansToGlobal(Q.scans_knn_coexist_), C.mergeScansToGlobal(C.scans_knn_coexist_),
-                                 Q.mergeScansToGlobal(Q.scans_knn_diff_), C.mergeScansToGlobal(C.scans_knn_diff_),
-                                 C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_};
-    if (has_strong_nd) ins.push_back(C.map_global_nd_strong_);
-    auto ds = C.octreeDownsamplingBatch(ins, 0.05f);        // the eight independent voxel grids of :1445-1476 as one batch
+    std::vector<CloudPtr> ds;
+    if (dev_->world() > 1) {
+        // keyframe-sharded: the four merges of rank-local scans are key-range exchanges, the replicated maps one batch
+        ds = {Q.mergeVoxel(Q.scans_knn_coexist_, 0.05f), C.mergeVoxel(C.scans_knn_coexist_, 0.05f), Q.mergeVoxel(Q.scans_knn_diff_, 0.05f), C.mergeVoxel(C.scans_knn_diff_, 0.05f)};
+        std::vector<CloudPtr> rest = {C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_};
+        if (has_strong_nd) rest.push_back(C.map_global_nd_strong_);
+        for (const CloudPtr& c : C.octreeDownsamplingBatch(rest, 0.05f)) ds.push_back(c);
+    } else {
+        std::vector<CloudPtr> ins = {Q.mergeScansToGlobal(Q.scans_knn_coexist_), C.mergeScansToGlobal(C.scans_knn_coexist_),
+                                     Q.mergeScansToGlobal(Q.scans_knn_diff_), C.mergeScansToGlobal(C.scans_knn_diff_),
+                                     C.map_global_nd_weak_, Q.map_global_pd_strong_, Q.map_global_pd_weak_};
+        if (has_strong_nd) ins.push_back(C.map_global_nd_strong_);
+        ds = C.octreeDownsamplingBatch(ins, 0.05f);        // the eight independent voxel grids of :1445-1476 as one batch
+    }
     union_q_ = ds[0];
     saveMap(save_pcd_directory_ + "union_map_queryside.pcd", union_q_);
     union_c_ = ds[1];

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -369,6 +370,92 @@ CloudPtr Session::mergeScansToGlobal(const ScansPtr& scans) const
     ltmCheck(dev_->ctx, ltm_merge_to_global(dev_->ctx, whole->h, poses_h_, &h), "ltm_merge_to_global");
     return wrap(h);
 }
+CloudPtr Session::mergeVoxel(const ScansPtr& scans, float leaf) const
+{
+    if (dev_->world() == 1 || !scans->shard) return octreeDownsampling(mergeScansToGlobal(scans), leaf);
+    Comm& comm = *dev_->comm;
+    ltm_ctx* ctx = dev_->ctx;
+    const int w = dev_->world(), me = dev_->rank();
+    // this rank's keyframes in the global frame
+    ltm_cloud hl = 0;
+    ltmCheck(ctx, ltm_merge_to_global(ctx, scans->h, poses_local_h_, &hl), "ltm_merge_to_global");
+    CloudPtr loc = wrap(hl);
+    // the box of the whole merge: six floats per rank through the byte all-gather, min / max on the host (exact in float)
+    float box[6];
+    ltmCheck(ctx, ltm_cloud_bbox(ctx, loc->h, box, box + 3), "ltm_cloud_bbox");
+    auto gather_host = [&](const void* mine, size_t bytes, std::vector<uint8_t>& all) {
+        void *d_my = nullptr, *d_all = nullptr;
+        ltmCheck(ctx, ltm_buffer_alloc(ctx, bytes, &d_my), "ltm_buffer_alloc");
+        ltmCheck(ctx, ltm_buffer_alloc(ctx, bytes * (size_t)w, &d_all), "ltm_buffer_alloc");
+        ltmCheck(ctx, ltm_buffer_copy(ctx, d_my, mine, bytes, 0), "ltm_buffer_copy");
+        comm.allGatherV(ctx, d_my, bytes, d_all, std::vector<uint64_t>((size_t)w, bytes));
+        all.resize(bytes * (size_t)w);
+        ltmCheck(ctx, ltm_buffer_copy(ctx, all.data(), d_all, all.size(), 1), "ltm_buffer_copy");
+        ltmCheck(ctx, ltm_buffer_free(ctx, d_my), "ltm_buffer_free");
+        ltmCheck(ctx, ltm_buffer_free(ctx, d_all), "ltm_buffer_free");
+    };
+    std::vector<uint8_t> raw;
+    gather_host(box, sizeof box, raw);
+    float mn[3] = {INFINITY, INFINITY, INFINITY}, mx[3] = {-INFINITY, -INFINITY, -INFINITY};
+    for (int r = 0; r < w; ++r) {
+        float b[6];
+        std::memcpy(b, raw.data() + (size_t)r * sizeof b, sizeof b);
+        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], b[d]); mx[d] = std::max(mx[d], b[3 + d]); }
+    }
+    if (!std::isfinite(mn[0])) { ltm_cloud he = 0; ltmCheck(ctx, ltm_cloud_alloc(ctx, 0, &he), "ltm_cloud_alloc"); return wrap(he); }
+    // cuts of the key space: summed 4096-bin histogram, equal weight per rank (the arithmetic of dist.ShardedOps.balanced_cuts)
+    std::vector<uint32_t> hist(4096);
+    ltmCheck(ctx, ltm_voxel_key_histogram(ctx, loc->h, mn, mx, leaf, hist.data()), "ltm_voxel_key_histogram");
+    gather_host(hist.data(), hist.size() * sizeof(uint32_t), raw);
+    std::vector<uint64_t> cum(4097, 0);
+    for (size_t b = 0; b < 4096; ++b) {
+        uint64_t v = 0;
+        for (int r = 0; r < w; ++r) { uint32_t x; std::memcpy(&x, raw.data() + ((size_t)r * 4096 + b) * 4, 4); v += x; }
+        cum[b + 1] = cum[b] + v;
+    }
+    std::vector<uint32_t> cuts((size_t)w + 1, 0);
+    for (int r = 1; r < w; ++r) {
+        const uint64_t want = cum[4096] * (uint64_t)r / (uint64_t)w;
+        const uint32_t at = (uint32_t)(std::lower_bound(cum.begin(), cum.end(), want) - cum.begin());
+        cuts[(size_t)r] = std::min<uint32_t>(std::max(at, cuts[(size_t)r - 1]), 4096u);
+    }
+    cuts[(size_t)w] = 4096;
+    // every point moves once, to the owner of its key range; arrival order = rank order = keyframe order
+    std::vector<ltm_cloud> parts((size_t)w, 0);
+    ltmCheck(ctx, ltm_voxel_key_split(ctx, loc->h, mn, mx, leaf, (uint32_t)w, cuts.data(), parts.data()), "ltm_voxel_key_split");
+    std::vector<CloudPtr> keep;
+    std::vector<uint64_t> send_n((size_t)w), send_bytes((size_t)w), recv_bytes((size_t)w);
+    for (int r = 0; r < w; ++r) { keep.push_back(wrap(parts[(size_t)r])); send_n[(size_t)r] = keep.back()->size(); send_bytes[(size_t)r] = send_n[(size_t)r] * sizeof(PointType); }
+    gather_host(send_n.data(), send_n.size() * 8, raw);                       // everybody's send table: row r, column me = what rank r sends here
+    size_t n_recv = 0;
+    for (int r = 0; r < w; ++r) { uint64_t v; std::memcpy(&v, raw.data() + ((size_t)r * (size_t)w + (size_t)me) * 8, 8); recv_bytes[(size_t)r] = v * sizeof(PointType); n_recv += v; }
+    CloudPtr send = concat(keep);                                             // the parts back to back, in destination order
+    ltm_cloud hr = 0;
+    ltmCheck(ctx, ltm_cloud_alloc(ctx, n_recv, &hr), "ltm_cloud_alloc");
+    CloudPtr recv = wrap(hr);
+    const void *sp = nullptr, *rp = nullptr;
+    ltmCheck(ctx, ltm_cloud_device_ptr(ctx, send->h, &sp), "ltm_cloud_device_ptr");
+    ltmCheck(ctx, ltm_cloud_device_ptr(ctx, recv->h, &rp), "ltm_cloud_device_ptr");
+    comm.allToAllV(ctx, sp, send_bytes, const_cast<void*>(rp), recv_bytes);
+    ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+    // this rank's key range under the common frame, then the centroid lists of all ranks in rank order
+    ltm_cloud hv = 0;
+    ltmCheck(ctx, ltm_voxel_centroid_box(ctx, recv->h, mn, mx, leaf, &hv), "ltm_voxel_centroid_box");
+    CloudPtr mine = wrap(hv);
+    std::vector<uint64_t> sizes;
+    comm.allGatherU64(ctx, mine->size(), sizes);
+    size_t total = 0;
+    for (uint64_t& v : sizes) { total += v; v *= sizeof(PointType); }
+    ltm_cloud ho = 0;
+    ltmCheck(ctx, ltm_cloud_alloc(ctx, total, &ho), "ltm_cloud_alloc");
+    CloudPtr out = wrap(ho);
+    const void *ms = nullptr, *od = nullptr;
+    ltmCheck(ctx, ltm_cloud_device_ptr(ctx, mine->h, &ms), "ltm_cloud_device_ptr");
+    ltmCheck(ctx, ltm_cloud_device_ptr(ctx, out->h, &od), "ltm_cloud_device_ptr");
+    comm.allGatherV(ctx, ms, mine->size() * sizeof(PointType), const_cast<void*>(od), sizes);
+    ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+    return out;
+}
 CloudPtr Session::octreeDownsampling(const CloudPtr& src, float leaf) const
 {
     ltm_ctx* ctx = dev_->ctx;
@@ -489,10 +576,10 @@ void Session::extractHighDynPointsViaKnnDiff(const CloudPtr& _target_map)
     keyframe_scans_dynamic_ = wrap_shard(di);
 }
 
-void Session::constructGlobalNDMap() { map_global_nd_ = octreeDownsampling(mergeScansToGlobal(scans_knn_diff_), 0.05f); }
+void Session::constructGlobalNDMap() { map_global_nd_ = mergeVoxel(scans_knn_diff_, 0.05f); }
 void Session::constructGlobalPDMap()
 {
-    map_global_pd_ = octreeDownsampling(mergeScansToGlobal(scans_knn_diff_), 0.05f);
+    map_global_pd_ = mergeVoxel(scans_knn_diff_, 0.05f);
     map_global_pd_orig_ = map_global_pd_;
 }
 void Session::revertStrongPDMapPointsHavingWeakPDInNear() {}
