@@ -23,11 +23,13 @@ oracle:
 host:
 	@if [ -f $(PKG)/host/Makefile ]; then $(MAKE) -C $(PKG)/host; fi
 
-ubench: tools/ubench/valu_rate
+ubench: tools/ubench/valu_rate tools/ubench/mfma_overlap
 tools/ubench/valu_rate: tools/ubench/valu_rate.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -w $< -o $@
+tools/ubench/mfma_overlap: tools/ubench/mfma_overlap.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -w $< -o $@
 
 clean:
-	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so tools/ubench/valu_rate
+	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so tools/ubench/valu_rate tools/ubench/mfma_overlap
 	$(MAKE) -C oracle clean
 .PHONY: all hip oracle host ubench clean
