@@ -181,6 +181,7 @@ def main():
     barrier()
     ctx.profile_reset()
     ctx.profile_enable(True)
+    ctx.voxel_stats(reset=True)
     if meter:
         meter.reset()
     t0 = time.perf_counter()
@@ -192,6 +193,7 @@ def main():
     ctx.profile_enable(False)
     prof = ctx.profile_read()
     cull_surv, cull_pts = ctx.cull_stats()
+    vox_grids, vox_identity = ctx.voxel_stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -307,6 +309,8 @@ def main():
                                            sharded_voxel_fraction=(meter.sharded_voxel_points / max(prof.get("voxel", {}).get("units", 0.0), 1.0))) if meter else None,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
+            "voxel_grids": {"per_step": round(vox_grids / max(args.steps, 1), 2), "recognised_as_identity_per_step": round(vox_identity / max(args.steps, 1), 2),
+                            "what": "voxel grids of clouds per step and how many of them the bounding-box pass recognised as the identity (DESIGN.md 4.2)"},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
             "synth_generation_s": round(t_gen, 2),
         }
