@@ -198,7 +198,7 @@ def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
     from ltmapper_amd import capi
     from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
     from tools import synth, t_total
-    n_kf = 24
+    n_kf = 44      # the two sessions start 37 m apart on the same loop: the query's first keyframes fall into the central ROI from ~40 central keyframes on
     sess = [synth.to_numpy(synth.make_session(s, n_kf, "small")) for s in (1, 2)]
     dirs = fp.write_session_dirs(tmp_path, sess)
     cxx = t_total.bench_cxx_host(str(tmp_path), dirs, n_kf, three_res=True, steps=1, warmup=1)
@@ -206,6 +206,7 @@ def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
     # keyframes inside the 10 m ROI; per-scan VoxelGrid + pre-clean on the device
     c_kf = fp.parse_keyframes(n_kf, 0, n_kf - 1)
     q_kf = fp.query_keyframes_in_roi(sess[0], c_kf, sess[1], n_kf)
+    assert len(q_kf) >= 3, "the test needs an overlapping query session"
     assert cxx["keyframes"] == [len(c_kf), len(q_kf)]
     ctx = capi.Context(vfov=50.0, hfov=360.0, device=0)
     loaded = []
