@@ -139,7 +139,28 @@ void Removerter::makeGlobalMap(Session& _sess)
         LTM_INFO(" The original pointcloud is saved (global coord): " << name);
     }
 }
-void Removerter::makeGlobalMap(void) { makeGlobalMap(central_sess_); makeGlobalMap(query_sess_); }
+// both sessions' merges first, then their two grids as ONE batch (two host round trips instead of four) -- the same sequence of C-ABI calls as
+// lt-mapper_amd/removerter.py's makeGlobalMap (tests/test_gpu_cli.py compares the two hosts' kernel-class launch counts)
+void Removerter::makeGlobalMap(void)
+{
+    Session* ss[2] = {&central_sess_, &query_sess_};
+    for (Session* s : ss) {
+        s->mergeScansWithinGlobalCoord();
+        LTM_INFO(" Map pointcloud (having redundant points) have: " << s->map_global_orig_->size() << " points.");
+        LTM_INFO(" Downsampling leaf size is " << kDownsampleVoxelSize << " m.");
+    }
+    auto ds = central_sess_.octreeDownsamplingBatch({central_sess_.map_global_orig_, query_sess_.map_global_orig_}, kDownsampleVoxelSize);
+    for (int i = 0; i < 2; ++i) {
+        Session& s = *ss[i];
+        s.map_global_curr_ = ds[(size_t)i];
+        s.map_global_orig_.reset();
+        if (kFlagSaveMapPointcloud) {
+            const std::string name = save_pcd_directory_ + "OriginalNoisy" + s.sess_type_ + "MapGlobal.pcd";
+            saveMap(name, s.map_global_curr_);
+            LTM_INFO(" The original pointcloud is saved (global coord): " << name);
+        }
+    }
+}
 
 // Removerter.cpp:801-828 / :771-799 / :740-768 : one visibility vote + index-ascending split
 std::pair<CloudPtr, CloudPtr> Removerter::votePartition(const Session& tgt, const CloudPtr& map, const ScansPtr& scans, const Session& src, float res, int mode)
@@ -711,6 +732,7 @@ int Removerter::runBench(int steps, int warmup)
     double total = 0.0;
     for (int it = 0; it < warmup + steps; ++it) {
         reset(central_sess_); reset(query_sess_); union_q_.reset(); union_c_.reset();
+        ltmCheck(ctx, ltm_clear_caches(ctx), "ltm_clear_caches");      // a step is a whole pass: no scan image survives from the previous one (as in bench.py)
         if (it == warmup) { ltmCheck(ctx, ltm_profile_enable(ctx, 1), "ltm_profile_enable"); ltmCheck(ctx, ltm_profile_reset(ctx), "ltm_profile_reset"); }
         ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
         const auto t0 = clk::now();
@@ -728,6 +750,7 @@ int Removerter::runBench(int steps, int warmup)
     const char* names[64]; double ms[64], units[64], bytes[64]; uint64_t launches[64];
     const int nc = ltm_profile_read(ctx, names, ms, launches, units, bytes, 64);
     std::ostringstream js;
+    js.precision(17);
     js << "{\"host\": \"lt-mapper_amd/host (C++ mirror of Removerter/Session over the C ABI)\", \"steps\": " << steps << ", \"warmup\": " << warmup
        << ", \"ms_per_step\": " << 1e3 * total / std::max(steps, 1) << ", \"keyframes\": [" << central_sess_.keyframe_names_.size() << ", "
        << query_sess_.keyframe_names_.size() << "], \"classes\": {";

@@ -89,6 +89,7 @@ PY
 # 5. the other configurations (one run each)
 if [ -z "$QUICK" ]; then
   $BENCH --workload street-2x2000-hdl64e-1res --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_street_2x2000_hdl64e.json"
+  $BENCH --workload street-2x2000-hdl64e-3res --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_street_2x2000_hdl64e_3res.json"
   $BENCH --workload street-2x200-mls-knn --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_street_2x200_mls.json"
   $BENCH --workload lot-cascade-6x500 --steps 2 --warmup 1 --no-cpu-baseline 2>/dev/null | tail -1 > "$OUT/${TAG}_bench_lot_cascade_6x500.json"
 fi
