@@ -116,10 +116,10 @@ def run_cascade_parity(kf=None, threads=None, device="cuda:0", n_sessions=3):
             "oracle_sha": provenance.oracle_sha(), "commit": commit, "outputs": report}
 
 
-def run_parity(config=1, kf=None, threads=None, device="cuda:0"):
+def run_parity(config=1, kf=None, threads=None, device="cuda:0", sessions=3):
     """returns the report dict; report["outputs_differing"] == 0 means bitwise parity of all outputs"""
     if config == 2:
-        return run_cascade_parity(kf, threads, device)
+        return run_cascade_parity(kf, threads, device, n_sessions=sessions)
     import numpy as np
     import torch
     import ltmapper_amd  # noqa: F401
@@ -190,8 +190,9 @@ def main():
     ap.add_argument("--config", type=int, default=1, choices=sorted(CONFIGS))
     ap.add_argument("--kf", type=int, default=None)
     ap.add_argument("--threads", type=int, default=None)
+    ap.add_argument("--sessions", type=int, default=3, help="--config 2: length of the cascade 01 -> 02 -> ... (BASELINE: 6)")
     args = ap.parse_args()
-    rep = run_parity(args.config, args.kf, args.threads)
+    rep = run_parity(args.config, args.kf, args.threads, sessions=args.sessions)
     print(json.dumps(rep, indent=1))
     sys.exit(1 if rep["outputs_differing"] else 0)
 
