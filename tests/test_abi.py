@@ -44,6 +44,18 @@ def test_product_never_references_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".h", ".hpp", "Makefile")):
                 text = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle_py" not in text and "ltm_oracle" not in text and "libltm_oracle" not in text, f"{f} references the oracle"
+                # ... nor the reference-compiled build (oracle/_ref, oracle/refshim): test infrastructure as well
+                assert "ref_py" not in text and "libltm_ref" not in text and "refshim" not in text and "removert_removert" not in text.replace("removert_removert node", ""), \
+                    f"{f} references the reference-compiled build"
+
+
+def test_product_binaries_link_neither_the_oracle_nor_the_reference_build():
+    import subprocess
+    for so in (os.path.join(ROOT, "lt-mapper_amd", "libltm_hip.so"), os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")):
+        if not os.path.exists(so):
+            continue
+        deps = subprocess.run(["ldd", so], capture_output=True, text=True).stdout
+        assert "ltm_oracle" not in deps and "ltm_ref" not in deps, deps
 
 
 def test_elevation_polynomial_fit_of_the_bounded_error_projection(ltm):
