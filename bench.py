@@ -343,7 +343,6 @@ CLASS_OWN_KERNELS = {
     "vote_map_cull": ["k_vote_map_cull"],
     "vote_scan": ["k_scan_rimg", "k_image_max", "k_scan_qbound", "k_image_bounds"],
     "vote_compare": ["k_compare_flag"],
-    "vote_fill": ["k_fill_u64", "k_fill_u32"],
     "partition": ["k_partition_scatter"],
     "reproject_gather": ["k_reproject_gather"],
     "merge": ["k_transform_scans", "k_zip_concat"],
@@ -354,6 +353,7 @@ CLASS_OWN_KERNELS = {
     "knn_query": ["k_knn_fast", "k_knn_query_cloud", "k_knn_query_scans"],
     "knn_query_p2": ["k_knn_slow", "k_knn_queue_scatter"],
 }
+# (vote_fill is not listed: k_fill_u64 / k_fill_u32 also initialise images, tables and flags of other stages, so their counters are not the class's own)
 CLASSES_WITH_LIBRARY_KERNELS = {"partition": "rocprim scan", "reproject_gather": "rocprim scan", "voxel": "rocprim radix sort", "voxel_scanset": "rocprim radix sort + scan",
                                 "voxel_grid_scanset": "rocprim radix sort + scan", "knn_build": "rocprim radix sort", "knn_query_p2": "rocprim scan"}
 
