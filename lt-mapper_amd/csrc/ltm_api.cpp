@@ -2304,11 +2304,18 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
         const char* order_env = std::getenv("LTM_VOXELGRID_ORDER");
         const bool pcl_order = !(order_env && std::strcmp(order_env, "input") == 0);
         if (pcl_order) {
+            const bool timing = getenv("LTM_VOXELGRID_TIMING") != nullptr;
+            auto now = [] { return std::chrono::steady_clock::now(); };
+            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            const auto t0 = now();
             uint64_t* hk = static_cast<uint64_t*>(pinned_alloc(c, n * 8));
             uint32_t* hi = static_cast<uint32_t*>(pinned_alloc(c, n * 4));
+            const auto t1 = now();
+            auto t2 = t1, t3 = t1;
             try {
                 LTM_HIP(hipMemcpyAsync(hk, keys.p, n * 8, hipMemcpyDeviceToHost, c->stream));
                 sync(c);
+                t2 = now();
                 struct Entry { uint32_t idx, cloud_point_index; };
                 std::atomic<size_t> next{0};
                 auto work = [&] {
@@ -2330,11 +2337,15 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                 for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
                 work();
                 for (std::thread& t : pool) t.join();
+                t3 = now();
                 LTM_HIP(hipMemcpyAsync(idx2.p, hi, n * 4, hipMemcpyHostToDevice, c->stream));
                 LTM_HIP(gather_u64_by_u32(keys.as<uint64_t>(), idx2.as<uint32_t>(), n, keys2.as<uint64_t>(), c->stream));
                 sync(c);
             } catch (...) { pinned_free(c, hk); pinned_free(c, hi); throw; }
             pinned_free(c, hk); pinned_free(c, hi);
+            if (timing)
+                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down %.1f ms, std::sort on host threads %.1f ms, order up + gather %.1f ms\n",
+                        n, nk, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
         } else {
             const size_t stb = sort_temp_bytes(n);
             DevBuf stemp(c, stb);
