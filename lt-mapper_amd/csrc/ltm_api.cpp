@@ -2331,8 +2331,12 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                         for (size_t i = a; i < b; ++i) hi[i] = e[i - a].cloud_point_index;
                     }
                 };
+                // one keyframe per task; a scans_updated set of 500 keyframes x 130 k points is ~5 s of single-thread std::sort, so the host's core
+                // count decides what the exact order costs (LTM_VOXELGRID_THREADS overrides; default: every hardware thread up to 256)
                 const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-                const size_t nt = std::min<size_t>(std::min<size_t>(hw, 64), nk);
+                const char* tenv = getenv("LTM_VOXELGRID_THREADS");
+                const size_t cap = tenv && atoi(tenv) > 0 ? (size_t)atoi(tenv) : 256;
+                const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw, cap), nk));
                 std::vector<std::thread> pool;
                 for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
                 work();
