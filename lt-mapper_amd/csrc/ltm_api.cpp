@@ -2331,11 +2331,13 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                         for (size_t i = a; i < b; ++i) hi[i] = e[i - a].cloud_point_index;
                     }
                 };
-                // one keyframe per task; a scans_updated set of 500 keyframes x 130 k points is ~5 s of single-thread std::sort, so the host's core
-                // count decides what the exact order costs (LTM_VOXELGRID_THREADS overrides; default: every hardware thread up to 256)
+                // one keyframe per task; a scans_updated set of 500 keyframes x 107 k points is ~2.5 s of single-thread std::sort, so the host decides what
+                // the exact order costs: ~100 ms on the 256-thread GPU box, where 64, 128, 192 and 256 threads measured the same (87-105 ms, more
+                // threads only noisier: profiles/r4_voxel_grid_scanset_pcl_order_threads.txt) against 5 ms for the all-device input order
+                // (LTM_VOXELGRID_THREADS overrides the cap of 64)
                 const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
                 const char* tenv = getenv("LTM_VOXELGRID_THREADS");
-                const size_t cap = tenv && atoi(tenv) > 0 ? (size_t)atoi(tenv) : 256;
+                const size_t cap = tenv && atoi(tenv) > 0 ? (size_t)atoi(tenv) : 64;
                 const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw, cap), nk));
                 std::vector<std::thread> pool;
                 for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
