@@ -503,6 +503,22 @@ def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel
                 "keyframes_visited_per_session": visited, "measured_s": round(wall, 2), "extrapolated_step_s": round(est, 1)}
 
     ncores = os.cpu_count() or 1
+
+    def cpu_quota():
+        """CPUs' worth of time the container may use (cgroup cpu.max / cfs quota), None if unlimited or unreadable.  The gpurun boxes
+        show 256 hardware threads and an affinity mask of 256 but `cpu.max = 1600000 100000`: 16 CPUs (profiles/r4_host_cpu_quota.txt),
+        so a figure "on all 256 cores" there is a figure on 16 CPUs' worth of time spread over 256 threads."""
+        try:
+            q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+            return None if q == "max" else round(int(q) / int(per), 2)
+        except Exception:
+            pass
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); per = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            return None if q <= 0 else round(q / per, 2)
+        except Exception:
+            return None
+    quota = cpu_quota()
     one = leg(1, args.cpu_stride)
     # the oracle parallelises over keyframes: the visited keyframes must outnumber the threads several times or the scaled stage
     # times overestimate (50 keyframes on 256 threads take one round, 500 take two, not ten) -- with many cores run every keyframe
@@ -518,7 +534,7 @@ def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel
             return None
     if ncores > 1 and args.cpu_allcore:
         allc = leg(ncores, max(1, min(args.cpu_stride_allcore, n_kf // (4 * ncores))))
-        allc.update(oracle_sha=provenance.oracle_sha(), host_cores=ncores, cpu_model=cpu_model(), workload=getattr(args, "workload", None))
+        allc.update(oracle_sha=provenance.oracle_sha(), host_cores=ncores, cgroup_cpu_quota_cpus=quota, cpu_model=cpu_model(), workload=getattr(args, "workload", None))
     elif ncores > 1:
         # quoted, not measured now -- and only if it was measured with THIS oracle on a host of the same shape: a ratio of
         # a fresh GPU time and a CPU time from another host or another oracle build would mean nothing
@@ -570,7 +586,7 @@ def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel
                      f"{one['keyframe_stride']}th keyframe ({one['keyframes_visited_per_session']} of {n_kf} per session) in the per-keyframe loops (votes, "
                      f"reprojections, kNN queries) scaled x{n_kf / one['keyframes_visited_per_session']:.1f}; voxel grids and kd-tree builds timed in full; "
                      f"{one['measured_s']:.1f} s measured, {one['extrapolated_step_s']:.0f} s extrapolated per step",
-           "measured_s": one["measured_s"], "extrapolated_step_s": one["extrapolated_step_s"], "host_cores": ncores,
+           "measured_s": one["measured_s"], "extrapolated_step_s": one["extrapolated_step_s"], "host_cores": ncores, "cgroup_cpu_quota_cpus": quota,
            "all_cores": allc,
            "full_unsampled_runs_committed": full or None}
     return out
