@@ -88,6 +88,9 @@ def parse_args():
     ap.add_argument("--cpu-allcore", action="store_true", help="cpu_baseline: also time the oracle on all host cores now (every keyframe when the box has "
                                                                "many cores: ~3 min on 256); without it the committed measurement is quoted")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--overlap-sessions", action="store_true", help="EXPERIMENT (one GPU, pair workloads): merge + grid and Step 1 of the query session on a second "
+                    "context / stream / host thread beside the central session's (removerter.Removerter query_side).  Kernel times of overlapping launches "
+                    "are inflated by each other, so the roofline figures of such a line describe the overlap, not the kernels")
     return ap.parse_args()
 
 
@@ -155,6 +158,12 @@ def main():
         ops = meter = CommMeter(HipOps(ctx))      # single GPU: note what the sharded pipeline would exchange (a few dictionary updates per stage)
 
     loaded = [load(S) for S in sess_t]   # loading + pre-clean are Step 0 plumbing, outside the timed region
+    ctx2 = q2 = None
+    if args.overlap_sessions:
+        assert world == 1 and n_sessions == 2, "--overlap-sessions: one GPU, one session pair"
+        ctx2 = capi.Context(vfov=50.0, hfov=360.0, device=local_rank)
+        S = sess_t[1]
+        q2 = (ctx2.preclean(ctx2.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64)), 2.5), ctx2.poses(S["poses"], S["inv"]))
 
     def one_step():
         ctx.clear_caches()   # no derived data (scan range images) survives from a previous step: every step is a fresh run
@@ -162,7 +171,11 @@ def main():
             runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:])
             return runs[-1]
         (cs, cp), (qs, qp) = loaded
-        rm = Removerter(ops, P, Session("Central", cs, cp), Session("Query", qs, qp))
+        side = None
+        if ctx2 is not None:
+            ctx2.clear_caches()
+            side = (HipOps(ctx2), Session("Query", q2[0], q2[1]))
+        rm = Removerter(ops, P, Session("Central", cs, cp), Session("Query", qs, qp), query_side=side)
         rm.run()
         return rm
 
@@ -181,6 +194,10 @@ def main():
     barrier()
     ctx.profile_reset()
     ctx.profile_enable(True)
+    if ctx2 is not None:
+        ctx2.synchronize()
+        ctx2.profile_reset()
+        ctx2.profile_enable(True)
     ctx.voxel_stats(reset=True)
     if meter:
         meter.reset()
@@ -192,6 +209,14 @@ def main():
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
     prof = ctx.profile_read()
+    if ctx2 is not None:       # the second context's launches belong to the same step
+        ctx2.profile_enable(False)
+        for k, v in ctx2.profile_read().items():
+            if k in prof:
+                for f in ("ms", "launches", "units", "bytes"):
+                    prof[k][f] += v[f]
+            else:
+                prof[k] = dict(v)
     cull_surv, cull_pts = ctx.cull_stats()
     vox_grids, vox_identity = ctx.voxel_stats()
     if dist is not None:
@@ -300,7 +325,8 @@ def main():
                        "remove_resolution_list": P.remove_resolution_list if three_res else [2.5], "self_removert": three_res,
                        "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points_last_pair": [M_c, M_q],
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
-                       "parallelism": f"keyframe-sharded x{world} (label all-reduce + scan all-gather)" if world > 1 else "single GPU",
+                       "parallelism": f"keyframe-sharded x{world} (label all-reduce + scan all-gather)" if world > 1 else
+                                      ("single GPU, the two sessions' merge + Step-1 chains side by side on two contexts (--overlap-sessions experiment)" if args.overlap_sessions else "single GPU"),
                        "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
             "t_total": t_total, "parity_fullsize": parity_fullsize_status(),

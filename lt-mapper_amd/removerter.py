@@ -157,9 +157,13 @@ class Session:
 class Removerter:
     kReprojectionAlpha = 3.0     # Session.h:13
 
-    def __init__(self, ops, params: Params, central: Session, query: Session):
+    def __init__(self, ops, params: Params, central: Session, query: Session, query_side=None):
+        """`query_side` = (ops2, query session as ops2 sees it): an experiment, off by default -- the merge + grid and the Step-1 chain of the
+        query session run on a second device context (own stream, own pool) from a second host thread while this one does the central
+        session's; the two chains share nothing (Removerter.cpp:1584-1591 runs them one after the other), their results are the same clouds."""
         self.ops, self.P = ops, params
         self.central_sess_, self.query_sess_ = central, query
+        self.query_side = query_side
         self.outputs = {}        # name -> cloud handle, the *.pcd maps of the output protocol (SURVEY.md 8b)
         self.timings = {}
 
@@ -182,10 +186,11 @@ class Removerter:
             return self.ops.merge_voxel_batch(list(merges), list(clouds), leaf)
         return self.ops.voxel_batch([self.ops.merge_to_global(s, p) for s, p in merges] + list(clouds), leaf)
 
-    def _append(self, a, b):                            # `*a += *b`
+    def _append(self, a, b, ops=None):                  # `*a += *b`
+        ops = ops or self.ops
         if a is None:
-            return self.ops.clone(b)
-        return self.ops.concat([a, b])
+            return ops.clone(b)
+        return ops.concat([a, b])
 
     # ------------------------------------------------------------------ Step 0
     def makeGlobalMap(self):                            # Removerter.cpp:213-252 (+ Session.cpp:186-202)
@@ -198,37 +203,74 @@ class Removerter:
             s.map_global_orig_ = None   # only ever read by makeGlobalMap
 
     # ------------------------------------------------------------------ Step 1
-    def removeOnce(self, target, source, res_alpha):    # Removerter.cpp:882-905
-        static_tt, dynamic_tt = self.ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
-        target.map_global_curr_static_, target.map_global_curr_dynamic_ = self.octreeDownsamplingBatch(
-            [static_tt, self._append(target.map_global_curr_dynamic_, dynamic_tt)], 0.05)      # :896, :903 -- independent of each other
+    def removeOnce(self, target, source, res_alpha, ops=None):    # Removerter.cpp:882-905
+        ops = ops or self.ops
+        static_tt, dynamic_tt = ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
+        target.map_global_curr_static_, target.map_global_curr_dynamic_ = ops.voxel_batch(
+            [static_tt, self._append(target.map_global_curr_dynamic_, dynamic_tt, ops)], 0.05)      # :896, :903 -- independent of each other
         target.map_global_curr_ = target.map_global_curr_static_
 
-    def revertOnce(self, target, source, res_alpha):    # Removerter.cpp:908-931
-        static_tt, dynamic_tt = self.ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
-        target.map_global_curr_dynamic_, target.map_global_curr_static_ = self.octreeDownsamplingBatch(
-            [dynamic_tt, self._append(target.map_global_curr_static_, static_tt)], 0.05)       # :921, :928
+    def revertOnce(self, target, source, res_alpha, ops=None):    # Removerter.cpp:908-931
+        ops = ops or self.ops
+        static_tt, dynamic_tt = ops.vote_partition(target.map_global_curr_, source.keyframe_scans_, source.keyframe_poses, res_alpha, 0.1, 0)
+        target.map_global_curr_dynamic_, target.map_global_curr_static_ = ops.voxel_batch(
+            [dynamic_tt, self._append(target.map_global_curr_static_, static_tt, ops)], 0.05)       # :921, :928
         target.map_global_curr_ = target.map_global_curr_dynamic_
 
-    def selfRemovert(self, sess, repeat=1):             # Removerter.cpp:1378-1393
+    def selfRemovert(self, sess, repeat=1, ops=None):   # Removerter.cpp:1378-1393
         for res in self.P.remove_resolution_list:
             res = float(np.float32(res))
             for _ in range(repeat):                                            # `i < _repeat`, Removerter.cpp:1381: repeat 0 runs nothing
-                self.removeOnce(sess, sess, res)
+                self.removeOnce(sess, sess, res, ops)
                 sess.map_global_curr_ = sess.map_global_curr_dynamic_          # resetCurrrentMapAsDynamic :714-737
-                self.revertOnce(sess, sess, float(np.float32(0.95 * res)))     # :1385 double product narrowed to float
+                self.revertOnce(sess, sess, float(np.float32(0.95 * res)), ops)   # :1385 double product narrowed to float
                 sess.map_global_curr_ = sess.map_global_curr_static_           # resetCurrrentMapAsStatic
-                self.removeOnce(sess, sess, res)
+                self.removeOnce(sess, sess, res, ops)
+
+    def _removeHighDynamicOf(self, sess, ops=None):     # one session's share of Removerter.cpp:1584-1591
+        if self.P.gpu_use_self_removert and len(self.P.remove_resolution_list) > 0:
+            self.selfRemovert(sess, self.P.repeat_removert_iter, ops)
+        else:
+            self.removeOnce(sess, sess, 2.5, ops)
+
+    def _sessionsSideBySide(self):
+        """makeGlobalMap + the Step-1 chain of both sessions, the query session's on `query_side`'s context from a second thread (see __init__).
+        Afterwards the query session's three maps are copied into the main context (a device copy of ~0.3 GB) where everything else runs."""
+        import threading
+        ops2, Q2 = self.query_side
+        C, Q = self.central_sess_, self.query_sess_
+        err = []
+
+        def chain(s, ops):
+            try:
+                s.map_global_curr_ = ops.voxel(ops.merge_to_global(s.keyframe_scans_, s.keyframe_poses), self.P.downsample_voxel_size)
+                s.map_global_orig_noisy_ = s.map_global_curr_
+                self._removeHighDynamicOf(s, ops)
+                ops.sync()
+            except BaseException as e:      # noqa: BLE001 -- re-raised on the calling thread
+                err.append(e)
+        self.ops.sync()                      # nothing of the previous step is in flight when the second stream starts to reuse its blocks
+        th = threading.Thread(target=chain, args=(Q2, ops2))
+        th.start()
+        chain(C, self.ops)
+        th.join()
+        if err:
+            raise err[0]
+        for name in ("map_global_orig_noisy_", "map_global_curr_static_", "map_global_curr_dynamic_"):
+            src = getattr(Q2, name)
+            setattr(Q, name, self.ops.cloud_from_tensor(ops2.cloud_to_tensor(src)) if src is not None else None)
+        Q.map_global_curr_ = Q.map_global_curr_static_
+        for s in (C, Q):
+            self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_orig_noisy_
 
     def removeHighDynamicPoints(self):                  # Removerter.cpp:1580-1604
         t0 = time.perf_counter()
         C, Q = self.central_sess_, self.query_sess_
-        if self.P.gpu_use_self_removert and len(self.P.remove_resolution_list) > 0:
-            self.selfRemovert(C, self.P.repeat_removert_iter)
-            self.selfRemovert(Q, self.P.repeat_removert_iter)
+        if self.query_side is not None:
+            self._sessionsSideBySide()
         else:
-            self.removeOnce(C, C, 2.5)
-            self.removeOnce(Q, Q, 2.5)
+            self._removeHighDynamicOf(C)
+            self._removeHighDynamicOf(Q)
         self._tick("remove_high_dynamic", t0)
         if not self.P.gpu_skip_hd_knn:
             t0 = time.perf_counter()
@@ -366,5 +408,6 @@ class Removerter:
                             query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
 
     def run(self):
-        self.makeGlobalMap()
+        if self.query_side is None:
+            self.makeGlobalMap()         # with `query_side` it is part of the two side-by-side chains (removeHighDynamicPoints)
         self.run_steps_1_to_3()

@@ -61,6 +61,29 @@ def test_pipeline_three_res_self_removert(ltm, orc, small_pair):
     ctx.close()
 
 
+def test_pipeline_sessions_side_by_side_on_two_contexts(ltm, orc, small_pair):
+    """Removerter(query_side=...): merge + grid and the Step-1 chain of the query session on a second context (own stream, own pool) from a
+    second host thread beside the central session's; three times in a row on the same contexts so that recycled pool blocks are exercised."""
+    from ltmapper_amd.removerter import HipOps, Params, Removerter, Session
+    C, Q = small_pair
+    res = (2.5, 2.0, 1.5)
+    ref = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01, use_self_removert=True, res_list=res), C, Q)
+    ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    ctx2 = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    P = Params(gpu_use_self_removert=True, remove_resolution_list=list(res))
+    up = lambda c, S: (c.upload_scans(S["scans"], S["offsets"]), c.poses(S["poses"], S["inv"]))    # noqa: E731
+    cs, qs, qs2 = up(ctx, C), up(ctx, Q), up(ctx2, Q)
+    for _ in range(3):
+        ctx.clear_caches(); ctx2.clear_caches()
+        rmv = Removerter(HipOps(ctx), P, Session("Central", *cs), Session("Query", *qs), query_side=(HipOps(ctx2), Session("Query", *qs2)))
+        rmv.run()
+        _compare(rmv, ref)
+        del rmv
+    del cs, qs, qs2
+    ctx2.close()
+    ctx.close()
+
+
 def test_pipeline_other_knn_params_and_extrinsic(ltm, orc, small_pair):
     """code-default kNN parameters (k=3, thr=0.1) and a non-identity LiDAR->base extrinsic"""
     C, Q = small_pair

@@ -55,6 +55,29 @@ def test_python_orchestration_matches_cpp_oracle_pipeline(orc, three_res):
     _check_against_oracle_pipeline(out, scans, ref)
 
 
+@pytest.mark.parametrize("three_res", [False, True])
+def test_sessions_side_by_side_on_two_op_sets_equal_the_plain_run(orc, three_res):
+    """Removerter(query_side=...): the merge + grid and the Step-1 chain of the query session run from a second thread on a second set of
+    stage ops (a second device context on the GPU); every output must be what the one-after-the-other run produces."""
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.removerter import Params, Removerter, Session
+    from oracle_ops import OPoses, OracleOps, OScans
+    C, Q = _tiny_pair()
+    kw = dict(gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5]) if three_res else {}
+    want_out, want_scans = _run(OracleOps(), C, Q, **kw)
+    mk = lambda n, S: Session(n, OScans(S["scans"], S["offsets"]), OPoses(S["poses"], S["inv"]))   # noqa: E731
+    rm = Removerter(OracleOps(), Params(**kw), mk("Central", C), mk("Query", Q), query_side=(OracleOps(), mk("Query", Q)))
+    rm.run()
+    out = {k: np.asarray(v.download()) for k, v in rm.outputs.items()}
+    assert sorted(out) == sorted(want_out)
+    for k in want_out:
+        assert_clouds_equal(out[k], want_out[k], k)
+    for k, v in rm.scan_outputs().items():
+        pts, off = v.download()
+        assert (np.asarray(off) == want_scans[k][1]).all(), k
+        assert_clouds_equal(pts, want_scans[k][0], k)
+
+
 def _worker(rank, world, port, q):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
