@@ -158,6 +158,7 @@ def main():
         ops = meter = CommMeter(HipOps(ctx))      # single GPU: note what the sharded pipeline would exchange (a few dictionary updates per stage)
 
     loaded = [load(S) for S in sess_t]   # loading + pre-clean are Step 0 plumbing, outside the timed region
+    snap = {"on": False, "prof": {}, "events": {}, "svp": 0, "step1_wall": 0.0, "step1_ms": {}, "step1_voxel_units": 0.0, "step1_events": {}, "step1_svp": 0, "swap_bytes": 0.0}
     ctx2 = q2 = None
     if args.overlap_sessions:
         assert world == 1 and n_sessions == 2, "--overlap-sessions: one GPU, one session pair"
@@ -176,7 +177,31 @@ def main():
             ctx2.clear_caches()
             side = (HipOps(ctx2), Session("Query", q2[0], q2[1]))
         rm = Removerter(ops, P, Session("Central", cs, cp), Session("Query", qs, qp), query_side=side)
+        if snap["on"]:
+            # makeGlobalMap + Step 1 is the part of the step that an even number of ranks runs on two rank groups (ShardedOps.session_groups): its
+            # kernel classes, wall time and would-be collectives are snapshot at its end so that the scaling model can price that split
+            t_start, base_prof, base_ev, base_svp = time.perf_counter(), snap["prof"], snap["events"], snap["svp"]
+
+            def on_stage(name):
+                if name != ("remove_high_dynamic" if P.gpu_skip_hd_knn else "hd_knn"):
+                    return
+                snap["step1_wall"] += time.perf_counter() - t_start
+                now = ctx.profile_read()
+                for k, v in now.items():
+                    snap["step1_ms"][k] = snap["step1_ms"].get(k, 0.0) + v["ms"] - base_prof.get(k, {}).get("ms", 0.0)
+                snap["step1_voxel_units"] += now.get("voxel", {}).get("units", 0.0) - base_prof.get("voxel", {}).get("units", 0.0)
+                for k, v in meter.events.items():
+                    e = snap["step1_events"].setdefault(k, [0, 0])
+                    e[0] += v[0] - base_ev.get(k, (0, 0))[0]
+                    e[1] += v[1] - base_ev.get(k, (0, 0))[1]
+                snap["step1_svp"] += meter.sharded_voxel_points - base_svp
+            rm.on_stage = on_stage
         rm.run()
+        if snap["on"]:
+            snap["prof"], snap["events"], snap["svp"] = ctx.profile_read(), {k: tuple(v) for k, v in meter.events.items()}, meter.sharded_voxel_points
+            names = ("OriginalNoisy%sMapGlobal", "%s_map_static", "%s_map_dynamic", "%s_sess_high_dyn")
+            snap["swap_bytes"] += 16 * sum(len(rm.outputs[n % (sname if "Noisy" in n else sname.lower())]) for sname in ("Central", "Query") for n in names
+                                           if rm.outputs.get(n % (sname if "Noisy" in n else sname.lower())) is not None) / 2.0
         return rm
 
     def barrier():
@@ -201,6 +226,7 @@ def main():
     ctx.voxel_stats(reset=True)
     if meter:
         meter.reset()
+    snap["on"] = bool(meter) and n_sessions == 2 and not args.overlap_sessions
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = None
@@ -332,7 +358,11 @@ def main():
             "t_total": t_total, "parity_fullsize": parity_fullsize_status(),
             "scaling_model": scaling_model({k: v["ms"] / args.steps for k, v in prof.items()}, ms_per_step,
                                            {k: (v[0] / args.steps, v[1] / args.steps) for k, v in meter.events.items()},
-                                           sharded_voxel_fraction=(meter.sharded_voxel_points / max(prof.get("voxel", {}).get("units", 0.0), 1.0))) if meter else None,
+                                           sharded_voxel_fraction=(meter.sharded_voxel_points / max(prof.get("voxel", {}).get("units", 0.0), 1.0)),
+                                           step1=({"class_ms": {k: v / args.steps for k, v in snap["step1_ms"].items()}, "wall_ms": 1e3 * snap["step1_wall"] / args.steps,
+                                                   "events": {k: (v[0] / args.steps, v[1] / args.steps) for k, v in snap["step1_events"].items()},
+                                                   "sharded_voxel_fraction": snap["step1_svp"] / max(snap["step1_voxel_units"], 1.0),
+                                                   "swap_bytes": snap["swap_bytes"] / args.steps} if snap["on"] and snap["step1_wall"] > 0 else None)) if meter else None,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
             "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
             "voxel_grids": {"per_step": round(vox_grids / max(args.steps, 1), 2), "recognised_as_identity_per_step": round(vox_identity / max(args.steps, 1), 2),

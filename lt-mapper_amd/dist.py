@@ -55,9 +55,56 @@ class ShardedOps:
     # (~0.35 ms for 6.8 M points on one MI355X), so it pays only for the big merges of makeGlobalMap (23 M points in, 6.8 M out).
     VOXEL_SHARD_MIN = 1 << 24
 
-    def __init__(self, ops, dist, rank, world, group=None):
+    # Step 1 (merge + grid, remove / revert passes, HD kNN) of the two sessions is independent work on different data (Removerter.cpp:1584-1591
+    # runs one after the other): with an even world the even ranks take the central session and the odd ranks the query session, each group
+    # sharding ITS session's keyframes world/2 ways.  A rank then does the replicated part (partitions, re-grids, host round trips) of one
+    # session instead of two and its label all-reduces span half the ranks; the price is one swap of the finished maps between rank pairs.
+    SESSION_GROUPS = True
+
+    def __init__(self, ops, dist, rank, world, group=None, peer=None):
         self.ops, self.dist, self.rank, self.world, self.group = ops, dist, rank, world, group
+        self.peer = peer                   # global rank of this rank's partner in the other session group (set on group ops only)
         self._pose_slices = {}
+        self._session_groups = None
+
+    def session_groups(self):
+        """(ops bound to this rank's session group, 0 = central / 1 = query) or None when the world does not split"""
+        if not self.SESSION_GROUPS or self.group is not None or self.world < 2 or self.world % 2:
+            return None
+        if self._session_groups is None:     # every rank creates both groups, in the same order (torch.distributed.new_group is collective)
+            pgs = [self.dist.new_group(ranks=list(range(g, self.world, 2))) for g in (0, 1)]
+            g = self.rank % 2
+            gops = ShardedOps(self.ops, self.dist, self.rank // 2, self.world // 2, group=pgs[g], peer=self.rank ^ 1)
+            gops.VOXEL_SHARD_MIN = self.VOXEL_SHARD_MIN
+            self._session_groups = (gops, g)
+        return self._session_groups
+
+    def swap_clouds_with_peer(self, clouds):
+        """this rank's clouds go to its partner rank of the other session group and the partner's come back, in list order: one message of sizes
+        and one of points each way (rank pairs 2i <-> 2i+1 sit on different xGMI links, all pairs swap at the same time)"""
+        assert self.peer is not None, "swap_clouds_with_peer is an operation of session-group ops"
+        ts = [self.ops.cloud_to_tensor(c) for c in clouds]
+        dev = ts[0].device
+        mine_n = torch.tensor([t.shape[0] for t in ts], dtype=torch.int64, device=dev)
+        their_n = torch.empty_like(mine_n)
+        send = torch.cat(ts).contiguous() if int(mine_n.sum()) else torch.zeros((0, 4), dtype=torch.float32, device=dev)
+
+        def swap(out, inp):
+            if self.dist.get_rank() < self.peer:
+                self.dist.send(inp, self.peer); self.dist.recv(out, self.peer)
+            else:
+                self.dist.recv(out, self.peer); self.dist.send(inp, self.peer)
+        swap(their_n, mine_n)
+        rows = [int(x) for x in their_n.cpu().tolist()]
+        recv = torch.empty((sum(rows), 4), dtype=torch.float32, device=dev)
+        if sum(rows) or send.shape[0]:
+            # both sides take part as soon as either has a point (a zero-row message is still a message)
+            swap(recv, send)
+        out, at = [], 0
+        for n in rows:
+            out.append(self.ops.cloud_from_tensor(recv[at:at + n].contiguous()) if n else self.ops.empty_cloud())
+            at += n
+        return out
 
     def __getattr__(self, name):           # replicated stages are forwarded untouched
         return getattr(self.ops, name)
@@ -346,15 +393,39 @@ SHARDED_CLASSES = ("vote_map_cull", "vote_map_exact", "vote_scan", "vote_compare
                    "knn_query_p2", "voxel_scanset", "voxel_grid_scanset")
 
 
-def scaling_model(class_ms_per_step, step_ms, events_per_step, ranks=(2, 4, 8), link_gbs=150.0, latency_us=25.0, sharded_voxel_fraction=0.0):
-    """strong-scaling estimate of ONE pair run from single-GPU measurements: T(N) = replicated + sharded / N + collectives(N), with the kernel
-    time of the sharded classes measured with HIP events, replicated = the rest of the step (replicated kernels + host gaps), and ring
-    collectives at `link_gbs` per direction and `latency_us` each (assumptions, stated in the output: no multi-GPU node was reachable)"""
-    sharded = sum(v for k, v in class_ms_per_step.items() if k in SHARDED_CLASSES)
+def _sharded_ms(class_ms, sharded_voxel_fraction):
+    """kernel time of a set of classes that divides by the number of ranks"""
+    sharded = sum(v for k, v in class_ms.items() if k in SHARDED_CLASSES)
     # the voxel grids whose input is split over the ranks (key-range exchange of rank-local scans, voxel_centroid_shard of large replicated
     # clouds): their share of the `voxel` class is taken as their share of its input POINTS (sort and tail are linear in them), and the merges
     # in front of them (`merge` class) run on rank-local keyframes
-    sharded += sharded_voxel_fraction * class_ms_per_step.get("voxel", 0.0) + (class_ms_per_step.get("merge", 0.0) if sharded_voxel_fraction > 0 else 0.0)
+    return sharded + sharded_voxel_fraction * class_ms.get("voxel", 0.0) + (class_ms.get("merge", 0.0) if sharded_voxel_fraction > 0 else 0.0)
+
+
+def _comm_ms(events, n, link_gbs, latency_us):
+    """ring collectives among n ranks at `link_gbs` per direction; the all-to-all spreads over the point-to-point links"""
+    if n < 2:
+        return 0.0
+    ms = 0.0
+    for kind, (cnt, nbytes) in events.items():
+        if kind == "points_alltoall":
+            factor = (n - 1) / float(n * n) / min(n - 1, 7)
+        else:
+            factor = 2.0 * (n - 1) / n if kind == "label_allreduce" else (n - 1) / n
+        ms += 1e3 * factor * nbytes / (link_gbs * 1e9) + cnt * latency_us * 1e-3 * (2 if kind in ("scans_allgather", "points_alltoall") else 1)
+    return ms
+
+
+def scaling_model(class_ms_per_step, step_ms, events_per_step, ranks=(2, 4, 8), link_gbs=150.0, latency_us=25.0, sharded_voxel_fraction=0.0, step1=None):
+    """strong-scaling estimate of ONE pair run from single-GPU measurements: T(N) = replicated + sharded / N + collectives(N), with the kernel
+    time of the sharded classes measured with HIP events, replicated = the rest of the step (replicated kernels + host gaps), and ring
+    collectives at `link_gbs` per direction and `latency_us` each (assumptions, stated in the output: no multi-GPU node was reachable).
+
+    `step1` = {"class_ms": ..., "wall_ms": ..., "events": ..., "sharded_voxel_fraction": ..., "swap_bytes": ...}: the same quantities for the part
+    of the step that ShardedOps.session_groups() runs on two rank groups (makeGlobalMap + Step 1: one session per group).  For an even N a rank
+    then does the replicated Step-1 work of ONE session (half), shards its session N/2 ways (the same sharded time per rank), exchanges only
+    its session's collectives among N/2 ranks and swaps the finished maps with its partner rank."""
+    sharded = _sharded_ms(class_ms_per_step, sharded_voxel_fraction)
     replicated = max(step_ms - sharded, 0.0)
     out = {"replicated_ms": round(replicated, 3), "sharded_ms": round(sharded, 3), "comm_events_per_step": {k: {"count": v[0], "payload_bytes": v[1]} for k, v in events_per_step.items()},
            "comm_bytes_per_step": int(sum(v[1] for v in events_per_step.values())),
@@ -363,15 +434,30 @@ def scaling_model(class_ms_per_step, step_ms, events_per_step, ranks=(2, 4, 8), 
                            "all_to_all": "a rank sends and receives (N-1)/N^2 x payload, spread over min(N-1, 7) point-to-point xGMI links",
                            "sharded_voxel_fraction_of_the_voxel_class": round(sharded_voxel_fraction, 4)},
            "status": "MODEL from single-GPU measurements -- unmeasured on multi-GPU hardware", "ranks": {}}
+    g = None
+    if step1:
+        s1 = _sharded_ms(step1["class_ms"], step1.get("sharded_voxel_fraction", 0.0))
+        r1 = max(step1["wall_ms"] - s1, 0.0)
+        ev2 = {k: (v[0] - step1["events"].get(k, (0, 0))[0], v[1] - step1["events"].get(k, (0, 0))[1]) for k, v in events_per_step.items()}
+        ev1_one_session = {k: (v[0] / 2.0, v[1] / 2.0) for k, v in step1["events"].items()}
+        g = {"replicated_ms": r1, "sharded_ms": s1, "rest_replicated_ms": max(replicated - r1, 0.0), "rest_sharded_ms": max(sharded - s1, 0.0)}
+        out["session_groups"] = {"what": "makeGlobalMap + Step 1 on two rank groups, one session each (ShardedOps.session_groups; even N)",
+                                 "step1_wall_ms": round(step1["wall_ms"], 3), "step1_replicated_ms": round(r1, 3), "step1_sharded_ms": round(s1, 3),
+                                 "swap_bytes_each_way": int(step1.get("swap_bytes", 0)),
+                                 "step1_comm_events_per_step": {k: {"count": v[0], "payload_bytes": v[1]} for k, v in step1["events"].items()}}
     for n in ranks:
-        comm_ms = 0.0
-        for kind, (cnt, nbytes) in events_per_step.items():
-            if kind == "points_alltoall":
-                factor = (n - 1) / float(n * n) / min(n - 1, 7)
-            else:
-                factor = 2.0 * (n - 1) / n if kind == "label_allreduce" else (n - 1) / n
-            comm_ms += 1e3 * factor * nbytes / (link_gbs * 1e9) + cnt * latency_us * 1e-3 * (2 if kind in ("scans_allgather", "points_alltoall") else 1)
+        comm_ms = _comm_ms(events_per_step, n, link_gbs, latency_us)
         received = sum((nbytes / n if kind == "points_alltoall" else nbytes) for kind, (cnt, nbytes) in events_per_step.items())
         t = replicated + sharded / n + comm_ms
-        out["ranks"][str(n)] = {"comm_ms": round(comm_ms, 3), "step_ms": round(t, 3), "speedup": round(step_ms / t, 3), "bytes_received_per_rank_per_step": int(received)}
+        row = {"comm_ms": round(comm_ms, 3), "step_ms": round(t, 3), "speedup": round(step_ms / t, 3), "bytes_received_per_rank_per_step": int(received)}
+        if g and n % 2 == 0:
+            swap_ms = 1e3 * step1.get("swap_bytes", 0) / (link_gbs * 1e9) + 2 * latency_us * 1e-3
+            comm1 = _comm_ms(ev1_one_session, n // 2, link_gbs, latency_us) + swap_ms
+            comm2 = _comm_ms(ev2, n, link_gbs, latency_us)
+            tg = g["replicated_ms"] / 2.0 + g["sharded_ms"] / n + comm1 + g["rest_replicated_ms"] + g["rest_sharded_ms"] / n + comm2
+            rec = (sum((b / (n // 2) if k == "points_alltoall" else b) for k, (c, b) in ev1_one_session.items()) + step1.get("swap_bytes", 0) +
+                   sum((b / n if k == "points_alltoall" else b) for k, (c, b) in ev2.items()))
+            row = {"comm_ms": round(comm1 + comm2, 3), "step_ms": round(tg, 3), "speedup": round(step_ms / tg, 3), "bytes_received_per_rank_per_step": int(rec),
+                   "without_session_groups": row}
+        out["ranks"][str(n)] = row
     return out

@@ -164,6 +164,7 @@ class Removerter:
         self.ops, self.P = ops, params
         self.central_sess_, self.query_sess_ = central, query
         self.query_side = query_side
+        self.on_stage = None
         self.outputs = {}        # name -> cloud handle, the *.pcd maps of the output protocol
         self.timings = {}
 
@@ -171,6 +172,8 @@ class Removerter:
     def _tick(self, name, t0):
         self.ops.sync()
         self.timings[name] = self.timings.get(name, 0.0) + (time.perf_counter() - t0)
+        if self.on_stage is not None:      # bench.py: per-stage snapshots of the kernel-class profile and of the comm meter
+            self.on_stage(name)
 
     def octreeDownsampling(self, cloud, leaf):          # utility.cpp:204-219
         return self.ops.voxel(cloud, leaf)
@@ -194,6 +197,7 @@ class Removerter:
 
     # ------------------------------------------------------------------ Step 0
     def makeGlobalMap(self):                            # Removerter.cpp:213-252 (+ Session.cpp:186-202)
+        t0 = time.perf_counter()
         sess = (self.central_sess_, self.query_sess_)
         for s in sess:
             s.map_global_orig_ = self.ops.merge_to_global(s.keyframe_scans_, s.keyframe_poses)
@@ -201,6 +205,7 @@ class Removerter:
             s.map_global_curr_ = m
             self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_curr_
             s.map_global_orig_ = None   # only ever read by makeGlobalMap
+        self._tick("make_global_map", t0)
 
     # ------------------------------------------------------------------ Step 1
     def removeOnce(self, target, source, res_alpha, ops=None):    # Removerter.cpp:882-905
@@ -263,7 +268,39 @@ class Removerter:
         for s in (C, Q):
             self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_orig_noisy_
 
+    def _rankGroups(self):
+        """dist.ShardedOps.session_groups(): (group ops, which session this rank's group works on) when the ranks split into a central and a query group"""
+        f = getattr(self.ops, "session_groups", None)
+        return f() if f is not None and self.query_side is None else None
+
+    def _sessionsOnRankGroups(self, gops, g):
+        """makeGlobalMap + all of Step 1 (remove / revert passes and the HD kNN map) of ONE session on this rank's group, the other session's on the
+        other group at the same time; then rank pairs swap the finished maps, after which every rank holds what the plain order leaves behind."""
+        t0 = time.perf_counter()
+        C, Q = self.central_sess_, self.query_sess_
+        mine, other = (C, Q) if g == 0 else (Q, C)
+        mine.map_global_curr_ = gops.voxel(gops.merge_to_global(mine.keyframe_scans_, mine.keyframe_poses), self.P.downsample_voxel_size)
+        mine.map_global_orig_noisy_ = mine.map_global_curr_
+        self._removeHighDynamicOf(mine, gops)
+        give = [mine.map_global_orig_noisy_, mine.map_global_curr_static_, mine.map_global_curr_dynamic_]
+        if not self.P.gpu_skip_hd_knn:
+            k, thr = self.P.num_nn_points_within, self.P.dist_nn_points_within
+            _, mine.keyframe_scans_dynamic_ = gops.knn_partition(mine.map_global_curr_static_, mine.keyframe_scans_, mine.keyframe_poses, k, thr)  # Session.cpp:487-504
+            give.append(gops.merge_voxel_batch([(mine.keyframe_scans_dynamic_, mine.keyframe_poses)], [], 0.05)[0])
+        got = gops.swap_clouds_with_peer(give)
+        other.map_global_orig_noisy_, other.map_global_curr_static_, other.map_global_curr_dynamic_ = got[:3]
+        other.map_global_curr_ = other.map_global_curr_static_
+        for s in (C, Q):
+            self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_orig_noisy_
+        if not self.P.gpu_skip_hd_knn:
+            hd = {id(mine): give[3], id(other): got[3]}
+            self.outputs["central_sess_high_dyn"], self.outputs["query_sess_high_dyn"] = hd[id(C)], hd[id(Q)]
+        self._tick("remove_high_dynamic", t0)
+
     def removeHighDynamicPoints(self):                  # Removerter.cpp:1580-1604
+        groups = self._rankGroups()
+        if groups is not None:
+            return self._sessionsOnRankGroups(*groups)
         t0 = time.perf_counter()
         C, Q = self.central_sess_, self.query_sess_
         if self.query_side is not None:
@@ -408,6 +445,6 @@ class Removerter:
                             query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
 
     def run(self):
-        if self.query_side is None:
-            self.makeGlobalMap()         # with `query_side` it is part of the two side-by-side chains (removeHighDynamicPoints)
+        if self.query_side is None and self._rankGroups() is None:
+            self.makeGlobalMap()         # otherwise part of the two sessions' separate chains (removeHighDynamicPoints)
         self.run_steps_1_to_3()

@@ -36,3 +36,18 @@ class StagedDist:
     @staticmethod
     def barrier(group=None):
         dist.barrier(group=group)
+
+    # rank groups (dist.ShardedOps.session_groups) and the pairwise swap of their results
+    new_group = staticmethod(dist.new_group)
+    get_rank = staticmethod(dist.get_rank)
+
+    @staticmethod
+    def send(t, dst):
+        dist.send(t.cpu().contiguous(), dst)
+
+    @staticmethod
+    def recv(t, src):
+        c = torch.empty(t.shape, dtype=t.dtype)
+        dist.recv(c, src)
+        t.copy_(c)
+

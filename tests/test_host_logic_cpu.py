@@ -78,7 +78,7 @@ def test_sessions_side_by_side_on_two_op_sets_equal_the_plain_run(orc, three_res
         assert_clouds_equal(pts, want_scans[k][0], k)
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, session_groups=True, three_res=False):
     import sys
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -92,19 +92,23 @@ def _worker(rank, world, port, q):
     C, Q = _tiny_pair()
     sops = ShardedOps(OracleOps(), dist, rank, world)
     sops.VOXEL_SHARD_MIN = 0          # the tiny maps of this test would otherwise stay replicated
-    out, scans = _run(sops, C, Q)
+    sops.SESSION_GROUPS = session_groups
+    out, scans = _run(sops, C, Q, **(dict(gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5]) if three_res else {}))
+    assert (sops.session_groups() is not None) == (session_groups and world % 2 == 0)
     q.put((rank, out, {k: (np.asarray(p), np.asarray(o)) for k, (p, o) in scans.items()}))
     dist.barrier()
     dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("world", [2, 3])      # 4 keyframes per session: equal blocks (2 + 2) and unequal ones (2 + 1 + 1)
-def test_keyframe_sharding_over_gloo_matches_single_process(orc, world):
+# 4 keyframes per session: equal blocks (2 + 2) and unequal ones (2 + 1 + 1).  An even world splits into a central and a query rank group for
+# Step 1 (ShardedOps.session_groups: world 2 = two groups of one rank, world 4 = two groups of two); (2, False) keeps the unsplit path covered
+@pytest.mark.parametrize("world,session_groups,three_res", [(2, True, False), (3, True, False), (4, True, False), (4, True, True), (2, False, False)])
+def test_keyframe_sharding_over_gloo_matches_single_process(orc, world, session_groups, three_res):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, session_groups, three_res)) for r in range(world)]
     for p in procs:
         p.start()
     import queue
@@ -123,7 +127,7 @@ def test_keyframe_sharding_over_gloo_matches_single_process(orc, world):
         p.join(timeout=60)
         assert p.exitcode == 0
     C, Q = _tiny_pair()
-    ref = orc.pipeline_run(orc.make_params(), C, Q)
+    ref = orc.pipeline_run(orc.make_params(use_self_removert=three_res, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,)), C, Q)
     for rank, out, scans in results:       # every rank must hold the full, identical result
         _check_against_oracle_pipeline(out, scans, ref)
 
@@ -290,3 +294,26 @@ def test_comm_meter_counts_what_the_sharded_pipeline_would_exchange(orc):
     assert m["sharded_ms"] == 80.0 + 10.0 + 4.0 and m["replicated_ms"] == 16.0
     assert m["ranks"]["8"]["step_ms"] < m["ranks"]["2"]["step_ms"] < 110.0
     assert m["ranks"]["8"]["bytes_received_per_rank_per_step"] < m["ranks"]["2"]["bytes_received_per_rank_per_step"]
+
+
+def test_scaling_model_prices_the_session_rank_groups():
+    """scaling_model(step1=...): for an even number of ranks makeGlobalMap + Step 1 run on two rank groups -- a rank does the replicated Step-1 work
+    of one session instead of two and exchanges its session's collectives among half the ranks, then swaps the finished maps with its partner"""
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.dist import scaling_model
+    cls = {"vote_map_cull": 80.0, "voxel": 20.0, "partition": 4.0, "knn_query": 10.0}
+    ev = {"label_allreduce": (24.0, 24 * 7e6), "voxel_allgather": (10.0, 3e8), "points_alltoall": (8.0, 1.6e9), "scans_allgather": (0.0, 0.0)}
+    step1 = {"class_ms": {"vote_map_cull": 60.0, "voxel": 12.0, "partition": 3.0}, "wall_ms": 80.0, "events": {"label_allreduce": (18.0, 18 * 7e6), "voxel_allgather": (4.0, 2e8),
+             "points_alltoall": (2.0, 1e8), "scans_allgather": (0.0, 0.0)}, "sharded_voxel_fraction": 0.25, "swap_bytes": 3.3e8}
+    plain = scaling_model(cls, 120.0, ev, ranks=(2, 3, 4, 8), sharded_voxel_fraction=0.5)
+    m = scaling_model(cls, 120.0, ev, ranks=(2, 3, 4, 8), sharded_voxel_fraction=0.5, step1=step1)
+    assert m["ranks"]["3"] == plain["ranks"]["3"], "an odd world does not split"
+    g = m["session_groups"]
+    assert g["step1_sharded_ms"] == 60.0 + 0.25 * 12.0 and g["step1_replicated_ms"] == 80.0 - 63.0
+    for n in ("2", "4", "8"):
+        assert m["ranks"][n]["without_session_groups"] == plain["ranks"][n]
+        assert m["ranks"][n]["step_ms"] < plain["ranks"][n]["step_ms"], "half of 17 ms of replicated Step-1 work outweighs a 2 ms swap"
+    # two ranks: each group is one rank -- no Step-1 collective at all, only the swap
+    r2 = m["ranks"]["2"]
+    rest_comm = r2["comm_ms"] - (1e3 * 3.3e8 / 150e9 + 0.05)
+    assert rest_comm > 0 and rest_comm < plain["ranks"]["2"]["comm_ms"]
