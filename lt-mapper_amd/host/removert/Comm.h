@@ -15,6 +15,7 @@
 #include <cstddef>
 #include <cstdint>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "ltm.h"
@@ -41,6 +42,15 @@ public:
     virtual void barrier() = 0;
     // a rank died: release the others instead of letting them wait for an exchange that will never complete
     virtual void abort() {}
+
+    // ---- session groups.  makeGlobalMap + Step 1 (Removerter.cpp:1584-1604) of the two sessions are independent: with an even world the even
+    // ranks form the central session's group and the odd ranks the query session's, each sharding ITS session's keyframes world/2 ways, and rank
+    // pairs (2i, 2i+1) swap the finished maps afterwards (same split as lt-mapper_amd/dist.py ShardedOps.session_groups).
+    // This rank's endpoint in its group; null when the world does not split (odd or 1, or LTM_SESSION_GROUPS=0)
+    virtual std::shared_ptr<Comm> sessionGroup() { return nullptr; }
+    // exchange with rank() ^ 1: a table of host integers (same length on both sides), then device bytes (sizes agreed through the table)
+    virtual void swapU64WithPeer(ltm_ctx*, const std::vector<uint64_t>&, std::vector<uint64_t>&) { throw std::runtime_error("Comm::swapU64WithPeer: this endpoint has no partner"); }
+    virtual void swapWithPeer(ltm_ctx*, const void*, size_t, void*, size_t) { throw std::runtime_error("Comm::swapWithPeer: this endpoint has no partner"); }
 };
 
 // contiguous block of keyframes [kb, ke) of rank `rank` (same rule as lt-mapper_amd/dist.py shard_range)
@@ -50,6 +60,8 @@ inline void shardRange(size_t n, int rank, int world, size_t* kb, size_t* ke)
     *ke = n * (size_t)(rank + 1) / (size_t)world;
 }
 
+// does a world of this size split into two session groups (even, >= 2, not switched off with LTM_SESSION_GROUPS=0)
+bool sessionGroupsEnabled(int world);
 // K endpoints of one in-process group; endpoint r is used by rank thread r only
 std::vector<std::shared_ptr<Comm>> makeLocalComms(int world);
 // K endpoints over devices devs[0..K) (ncclCommInitAll); throws if RCCL cannot initialise

@@ -77,6 +77,8 @@ public:
     void resetCurrrentMapAsStatic(const Session& _sess);
     void selfRemovert(const Session& _sess, int _repeat);
     void removeHighDynamicPoints(void);
+    void removeHighDynamicPointsOnSessionGroups(void);   // even worlds: one session per rank group, then a swap between rank pairs (Comm.h)
+    CloudPtr group_orig_noisy_;                          // set by makeGlobalMap() while this rank's session group is entered
 
     void filterStrongND(Session& _sess_src, Session& _sess_cleaner);
     void iremoveOnceForND(const Session& _target_sess, const Session& _source_sess, float _res_alpha);

@@ -79,6 +79,14 @@ public:
     explicit Session(std::shared_ptr<Device> dev);
 
     std::shared_ptr<Device> dev_;
+    // The communicator this session's per-keyframe stages shard over: the world's, or -- between enterSessionGroup() and leaveSessionGroup(),
+    // i.e. during makeGlobalMap + Step 1 of an even world -- this rank's session group (Comm.h).  kf_begin_ / kf_end_ / poses_local_h_ follow it.
+    std::shared_ptr<Comm> group_comm_;
+    Comm* comm() const { return group_comm_ ? group_comm_.get() : dev_->comm.get(); }
+    int rank() const { return comm() ? comm()->rank() : 0; }
+    int world() const { return comm() ? comm()->world() : 1; }
+    void enterSessionGroup(std::shared_ptr<Comm> group);
+    void leaveSessionGroup();
     std::string sess_type_;
     float kDownsampleVoxelSize;
     std::string scan_dir_, pose_path_;
@@ -158,6 +166,7 @@ public:
     std::vector<CloudPtr> octreeDownsamplingBatch(const std::vector<CloudPtr>& src, float leaf) const;
     CloudPtr concat(const std::vector<CloudPtr>& parts) const;
     void uploadPoses();
+    void setKeyframeBlock();        // kf_begin_ / kf_end_ / poses_local_h_ of rank() in world()
 };
 
 } // namespace ltremovert

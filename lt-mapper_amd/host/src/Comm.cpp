@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <condition_variable>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <stdexcept>
@@ -26,6 +27,10 @@ struct LocalGroup
     std::vector<std::vector<uint8_t>> stage;      // one staging buffer per rank
     std::vector<uint64_t> scalars;
     std::vector<std::vector<uint64_t>> a2a_sizes;  // allToAllV: every rank's send table
+    // a failure anywhere must release every rank, whichever group's barrier it is parked in: the world group knows its session groups and they
+    // know it
+    std::vector<std::shared_ptr<LocalGroup>> subs;
+    LocalGroup* parent = nullptr;
     explicit LocalGroup(int w) : world(w), stage((size_t)w), scalars((size_t)w, 0), a2a_sizes((size_t)w) {}
 
     void barrier()
@@ -37,11 +42,17 @@ struct LocalGroup
         cv.wait(lk, [&] { return generation != gen || failed; });
         if (failed) throw std::runtime_error("LocalComm: another rank failed");
     }
-    void fail()
+    void failHere()
     {
         std::lock_guard<std::mutex> lk(m);
         failed = true;
         cv.notify_all();
+    }
+    void fail()
+    {
+        LocalGroup* top = parent ? parent : this;
+        top->failHere();
+        for (auto& s : top->subs) s->failHere();
     }
 };
 
@@ -54,9 +65,40 @@ class LocalComm : public Comm
 {
     std::shared_ptr<LocalGroup> g_;
     int rank_;
+    std::shared_ptr<Comm> session_group_;      // this rank's endpoint in its session group (world endpoints of an even world only)
 
 public:
     LocalComm(std::shared_ptr<LocalGroup> g, int r) : g_(std::move(g)), rank_(r) {}
+    void setSessionGroup(std::shared_ptr<Comm> c) { session_group_ = std::move(c); }
+    std::shared_ptr<Comm> sessionGroup() override { return session_group_; }
+
+    void swapU64WithPeer(ltm_ctx*, const std::vector<uint64_t>& mine, std::vector<uint64_t>& theirs) override
+    {
+        if (!session_group_) throw std::runtime_error("LocalComm::swapU64WithPeer: the world does not split into session groups");
+        try {
+            g_->a2a_sizes[(size_t)rank_] = mine;
+            g_->barrier();
+            theirs = g_->a2a_sizes[(size_t)(rank_ ^ 1)];
+            g_->barrier();
+            if (theirs.size() != mine.size()) throw std::runtime_error("LocalComm::swapU64WithPeer: the two sides' tables differ in length");
+        } catch (...) { g_->fail(); throw; }
+    }
+
+    // every rank of the world takes part at the same point of the pipeline (all pairs swap together), so the world barrier orders the staging buffers
+    void swapWithPeer(ltm_ctx* ctx, const void* send_dev, size_t send_bytes, void* recv_dev, size_t recv_bytes) override
+    {
+        if (!session_group_) throw std::runtime_error("LocalComm::swapWithPeer: the world does not split into session groups");
+        try {
+            std::vector<uint8_t>& mine = g_->stage[(size_t)rank_];
+            mine.resize(send_bytes);
+            if (send_bytes) check(ctx, ltm_buffer_copy(ctx, mine.data(), send_dev, send_bytes, 1), "ltm_buffer_copy d2h");
+            g_->barrier();
+            const std::vector<uint8_t>& theirs = g_->stage[(size_t)(rank_ ^ 1)];
+            if (theirs.size() != recv_bytes) throw std::runtime_error("LocalComm::swapWithPeer: the partner sends a different size than announced");
+            if (recv_bytes) check(ctx, ltm_buffer_copy(ctx, recv_dev, theirs.data(), recv_bytes, 0), "ltm_buffer_copy h2d");
+            g_->barrier();
+        } catch (...) { g_->fail(); throw; }
+    }
     int rank() const override { return rank_; }
     int world() const override { return g_->world; }
     const char* backend() const override { return "local"; }
@@ -139,13 +181,27 @@ public:
 
 } // namespace
 
+bool sessionGroupsEnabled(int world)
+{
+    const char* e = std::getenv("LTM_SESSION_GROUPS");
+    return world >= 2 && world % 2 == 0 && !(e && std::string(e) == "0");
+}
+
 std::vector<std::shared_ptr<Comm>> makeLocalComms(int world)
 {
     if (world < 1) throw std::runtime_error("makeLocalComms: world must be >= 1");
     auto g = std::make_shared<LocalGroup>(world);
-    std::vector<std::shared_ptr<Comm>> out;
-    for (int r = 0; r < world; ++r) out.push_back(std::make_shared<LocalComm>(g, r));
-    return out;
+    std::vector<std::shared_ptr<LocalComm>> ends;
+    for (int r = 0; r < world; ++r) ends.push_back(std::make_shared<LocalComm>(g, r));
+    if (sessionGroupsEnabled(world)) {
+        for (int color = 0; color < 2; ++color) {      // even ranks: central session's group, odd ranks: query session's
+            auto sg = std::make_shared<LocalGroup>(world / 2);
+            sg->parent = g.get();
+            g->subs.push_back(sg);
+            for (int r = color; r < world; r += 2) ends[(size_t)r]->setSessionGroup(std::make_shared<LocalComm>(sg, r / 2));
+        }
+    }
+    return std::vector<std::shared_ptr<Comm>>(ends.begin(), ends.end());
 }
 
 } // namespace ltremovert

@@ -45,13 +45,59 @@ class RcclComm : public Comm
     std::shared_ptr<RcclGroup> g_;
     int rank_;
     uint64_t* scratch_ = nullptr;      // world uint64 on the device for the size exchange
+    uint64_t* swap_scratch_ = nullptr; // 2 x swap_cap_ uint64 for the table exchange with the partner rank
+    size_t swap_cap_ = 0;
+    std::shared_ptr<Comm> session_group_;
 
     ncclComm_t comm() const { return g_->comms[(size_t)rank_]; }
     static hipStream_t stream(ltm_ctx* ctx) { return static_cast<hipStream_t>(ltm_stream(ctx)); }
 
 public:
     RcclComm(std::shared_ptr<RcclGroup> g, int r) : g_(std::move(g)), rank_(r) {}
-    ~RcclComm() override { if (scratch_) { (void)hipSetDevice(g_->devs[(size_t)rank_]); (void)hipFree(scratch_); } }
+    ~RcclComm() override
+    {
+        if (scratch_ || swap_scratch_) (void)hipSetDevice(g_->devs[(size_t)rank_]);
+        if (scratch_) (void)hipFree(scratch_);
+        if (swap_scratch_) (void)hipFree(swap_scratch_);
+    }
+    void setSessionGroup(std::shared_ptr<Comm> c) { session_group_ = std::move(c); }
+    std::shared_ptr<Comm> sessionGroup() override { return session_group_; }
+
+    // rank pairs (2i, 2i+1): one grouped send + receive per side; the pairs use different xGMI links and swap at the same time
+    void swapU64WithPeer(ltm_ctx* ctx, const std::vector<uint64_t>& mine, std::vector<uint64_t>& theirs) override
+    {
+        if (!session_group_) throw std::runtime_error("RcclComm::swapU64WithPeer: the world does not split into session groups");
+        const size_t n = mine.size();
+        theirs.assign(n, 0);
+        if (n == 0) return;
+        LTM_HIPRT(hipSetDevice(g_->devs[(size_t)rank_]));
+        if (swap_cap_ < n) {
+            if (swap_scratch_) LTM_HIPRT(hipFree(swap_scratch_));
+            swap_scratch_ = nullptr;
+            LTM_HIPRT(hipMalloc(reinterpret_cast<void**>(&swap_scratch_), 2 * n * sizeof(uint64_t)));
+            swap_cap_ = n;
+        }
+        const int peer = rank_ ^ 1;
+        LTM_HIPRT(hipMemcpyAsync(swap_scratch_, mine.data(), n * sizeof(uint64_t), hipMemcpyHostToDevice, stream(ctx)));
+        LTM_NCCL(ncclGroupStart());
+        LTM_NCCL(ncclSend(swap_scratch_, n, ncclUint64, peer, comm(), stream(ctx)));
+        LTM_NCCL(ncclRecv(swap_scratch_ + n, n, ncclUint64, peer, comm(), stream(ctx)));
+        LTM_NCCL(ncclGroupEnd());
+        LTM_HIPRT(hipMemcpyAsync(theirs.data(), swap_scratch_ + n, n * sizeof(uint64_t), hipMemcpyDeviceToHost, stream(ctx)));
+        LTM_HIPRT(hipStreamSynchronize(stream(ctx)));
+    }
+
+    void swapWithPeer(ltm_ctx* ctx, const void* send_dev, size_t send_bytes, void* recv_dev, size_t recv_bytes) override
+    {
+        if (!session_group_) throw std::runtime_error("RcclComm::swapWithPeer: the world does not split into session groups");
+        if (send_bytes == 0 && recv_bytes == 0) return;
+        LTM_HIPRT(hipSetDevice(g_->devs[(size_t)rank_]));
+        const int peer = rank_ ^ 1;
+        LTM_NCCL(ncclGroupStart());
+        if (send_bytes) LTM_NCCL(ncclSend(send_dev, send_bytes, ncclChar, peer, comm(), stream(ctx)));
+        if (recv_bytes) LTM_NCCL(ncclRecv(recv_dev, recv_bytes, ncclChar, peer, comm(), stream(ctx)));
+        LTM_NCCL(ncclGroupEnd());
+    }
     int rank() const override { return rank_; }
     int world() const override { return (int)g_->comms.size(); }
     const char* backend() const override { return "rccl"; }
@@ -132,9 +178,18 @@ std::vector<std::shared_ptr<Comm>> makeRcclComms(const std::vector<int>& devs)
     g->devs = devs;
     g->comms.assign(devs.size(), nullptr);
     LTM_NCCL(ncclCommInitAll(g->comms.data(), (int)devs.size(), devs.data()));
-    std::vector<std::shared_ptr<Comm>> out;
-    for (size_t r = 0; r < devs.size(); ++r) out.push_back(std::make_shared<RcclComm>(g, (int)r));
-    return out;
+    std::vector<std::shared_ptr<RcclComm>> ends;
+    for (size_t r = 0; r < devs.size(); ++r) ends.push_back(std::make_shared<RcclComm>(g, (int)r));
+    if (sessionGroupsEnabled((int)devs.size())) {
+        for (size_t color = 0; color < 2; ++color) {      // a communicator of their own for the even and for the odd ranks
+            auto sg = std::make_shared<RcclGroup>();
+            for (size_t r = color; r < devs.size(); r += 2) sg->devs.push_back(devs[r]);
+            sg->comms.assign(sg->devs.size(), nullptr);
+            LTM_NCCL(ncclCommInitAll(sg->comms.data(), (int)sg->devs.size(), sg->devs.data()));
+            for (size_t r = color; r < devs.size(); r += 2) ends[r]->setSessionGroup(std::make_shared<RcclComm>(sg, (int)(r / 2)));
+        }
+    }
+    return std::vector<std::shared_ptr<Comm>>(ends.begin(), ends.end());
 }
 
 } // namespace ltremovert

@@ -143,6 +143,19 @@ void Removerter::makeGlobalMap(Session& _sess)
 // lt-mapper_amd/removerter.py's makeGlobalMap (tests/test_gpu_cli.py compares the two hosts' kernel-class launch counts)
 void Removerter::makeGlobalMap(void)
 {
+    if (std::shared_ptr<Comm> group = dev_->comm ? dev_->comm->sessionGroup() : nullptr) {
+        // Session groups (Comm.h): this rank's group merges + grids ITS session only; the group stays entered until removeHighDynamicPoints()
+        // has finished the session's Step 1 and the rank pairs have swapped the results.  The map files are written there as well.
+        Session& mine = dev_->rank() % 2 == 0 ? central_sess_ : query_sess_;
+        mine.enterSessionGroup(group);
+        mine.mergeScansWithinGlobalCoord();
+        LTM_INFO(" Map pointcloud (having redundant points) have: " << mine.map_global_orig_->size() << " points.");
+        LTM_INFO(" Downsampling leaf size is " << kDownsampleVoxelSize << " m.");
+        mine.map_global_curr_ = mine.octreeDownsampling(mine.map_global_orig_, kDownsampleVoxelSize);
+        mine.map_global_orig_.reset();
+        group_orig_noisy_ = mine.map_global_curr_;
+        return;
+    }
     Session* ss[2] = {&central_sess_, &query_sess_};
     for (Session* s : ss) {
         s->mergeScansWithinGlobalCoord();
@@ -183,7 +196,7 @@ std::pair<CloudPtr, CloudPtr> Removerter::votePartition(const Session& tgt, cons
     }
     ++viz_pass_;
     ltm_cloud kept = 0, flagged = 0;
-    if (dev_->world() == 1) {
+    if (src.world() == 1) {      // the ranks that share the SOURCE session's keyframes: the world, or the session's rank group during Step 1
         ltmCheck(ctx, ltm_visibility_partition(ctx, map->h, scans->h, src.poses_h_, res, 0.1f, mode, &kept, &flagged, nullptr),
                  "ltm_visibility_partition");
         return {tgt.wrap(kept), tgt.wrap(flagged)};
@@ -198,7 +211,7 @@ std::pair<CloudPtr, CloudPtr> Removerter::votePartition(const Session& tgt, cons
     ltm_poses ph = 0; size_t kb = 0, ke = 0;
     src.stageArgs(scans, &ph, &kb, &ke);
     if (M) ltmCheck(ctx, ltm_visibility_vote(ctx, map->h, scans->h, ph, kb, ke, res, 0.1f, mode, static_cast<uint8_t*>(labels)), "ltm_visibility_vote");
-    dev_->comm->allReduceMaxU8(ctx, labels, M);
+    src.comm()->allReduceMaxU8(ctx, labels, M);
     ltmCheck(ctx, ltm_partition_by_labels(ctx, map->h, static_cast<const uint8_t*>(labels), &kept, &flagged), "ltm_partition_by_labels");
     ltmCheck(ctx, ltm_buffer_free(ctx, labels), "ltm_buffer_free");
     return {tgt.wrap(kept), tgt.wrap(flagged)};
@@ -307,8 +320,67 @@ void Removerter::saveCurrentStaticAndDynamicPointCloudGlobal(const Session& _ses
     saveMap(central_map_static_save_dir_ + "/" + _sess.sess_type_ + "StaticMapMapsideGlobalResX" + _postfix + "ResX" + r + ".pcd", _sess.map_global_curr_static_);   // doubled "ResX": sic (:335)
 }
 
+// Step 1 with session groups: the remove / revert passes and the HD kNN map of THIS rank's session on its group, then the swap of the finished
+// maps with the partner rank of the other group -- every rank ends with what the one-after-the-other order leaves behind (the scans of the
+// HD kNN, only ever merged into the HD map, stay with the group that made them)
+void Removerter::removeHighDynamicPointsOnSessionGroups(void)
+{
+    const bool central = dev_->rank() % 2 == 0;
+    Session& mine = central ? central_sess_ : query_sess_;
+    Session& other = central ? query_sess_ : central_sess_;
+    const bool self = gpu_use_self_removert_ && !remove_resolution_list_.empty();
+    if (kFlagSaveMapPointcloud) saveMap(save_pcd_directory_ + "OriginalNoisy" + mine.sess_type_ + "MapGlobal.pcd", group_orig_noisy_);
+    if (self) selfRemovert(mine, repeat_removert_iter_);
+    else removeOnce(mine, mine, 2.5);
+    std::vector<CloudPtr> give = {group_orig_noisy_, mine.map_global_curr_static_, mine.map_global_curr_dynamic_};
+    if (!gpu_skip_hd_knn_) {
+        mine.extractHighDynPointsViaKnnDiff(mine.map_global_curr_static_);
+        give.push_back(mine.mergeVoxel(mine.keyframe_scans_dynamic_, 0.05f));
+    }
+    mine.leaveSessionGroup();
+    group_orig_noisy_.reset();
+
+    ltm_ctx* ctx = dev_->ctx;
+    Comm& comm = *dev_->comm;
+    std::vector<uint64_t> n_mine, n_theirs;
+    for (const CloudPtr& c : give) n_mine.push_back(c->size());
+    comm.swapU64WithPeer(ctx, n_mine, n_theirs);
+    size_t total = 0;
+    for (uint64_t v : n_theirs) total += v;
+    CloudPtr send = mine.concat(give);
+    ltm_cloud hr = 0;
+    ltmCheck(ctx, ltm_cloud_alloc(ctx, total, &hr), "ltm_cloud_alloc");
+    CloudPtr recv = other.wrap(hr);
+    const void *sp = nullptr, *rp = nullptr;
+    ltmCheck(ctx, ltm_cloud_device_ptr(ctx, send->h, &sp), "ltm_cloud_device_ptr");
+    ltmCheck(ctx, ltm_cloud_device_ptr(ctx, recv->h, &rp), "ltm_cloud_device_ptr");
+    comm.swapWithPeer(ctx, sp, send->size() * sizeof(PointType), const_cast<void*>(rp), total * sizeof(PointType));
+    ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+    std::vector<CloudPtr> got;
+    size_t at = 0;
+    for (uint64_t n : n_theirs) {
+        ltm_cloud h = 0;
+        ltmCheck(ctx, ltm_cloud_from_device(ctx, static_cast<const PointType*>(rp) + at, (size_t)n, &h), "ltm_cloud_from_device");
+        got.push_back(other.wrap(h));
+        at += (size_t)n;
+    }
+    other.map_global_curr_static_ = got[1];
+    other.map_global_curr_dynamic_ = got[2];
+    other.map_global_curr_ = other.map_global_curr_static_;
+    // the files the other group's chain would have written on a rank that writes (rank 0 belongs to the central group)
+    if (kFlagSaveMapPointcloud) saveMap(save_pcd_directory_ + "OriginalNoisy" + other.sess_type_ + "MapGlobal.pcd", got[0]);
+    if (self) saveCurrentStaticAndDynamicPointCloudGlobal(other, "_MVM");
+    if (gpu_skip_hd_knn_) return;
+    const CloudPtr& hd_c = central ? give[3] : got[3];
+    const CloudPtr& hd_q = central ? got[3] : give[3];
+    saveMap(save_pcd_directory_ + "central_sess_high_dyn.pcd", hd_c);
+    saveMap(save_pcd_directory_ + "query_sess_high_dyn.pcd", hd_q);
+    LTM_INFO(" high dynamic maps are saved. ");
+}
+
 void Removerter::removeHighDynamicPoints(void)                                     // Removerter.cpp:1580-1604
 {
+    if (group_orig_noisy_) return removeHighDynamicPointsOnSessionGroups();       // makeGlobalMap() entered this rank's session group
     if (gpu_use_self_removert_ && !remove_resolution_list_.empty()) {
         selfRemovert(central_sess_, repeat_removert_iter_);
         selfRemovert(query_sess_, repeat_removert_iter_);

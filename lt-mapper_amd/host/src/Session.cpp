@@ -210,17 +210,39 @@ void Session::uploadPoses()
         pi.insert(pi.end(), keyframe_inverse_poses_[k].begin(), keyframe_inverse_poses_[k].end());
     }
     ltmCheck(dev_->ctx, ltm_poses_create(dev_->ctx, keyframe_poses_.size(), p.data(), pi.data(), &poses_h_), "ltm_poses_create");
-    // this rank's block of keyframes (Comm.h shardRange): every per-keyframe loop of the reference runs over it
+    setKeyframeBlock();
+}
+
+// this rank's block of keyframes (Comm.h shardRange) among the ranks of comm(): every per-keyframe loop of the reference runs over it
+void Session::setKeyframeBlock()
+{
     if (poses_local_h_) { ltm_poses_free(dev_->ctx, poses_local_h_); poses_local_h_ = 0; }
-    shardRange(keyframe_poses_.size(), dev_->rank(), dev_->world(), &kf_begin_, &kf_end_);
-    if (dev_->world() > 1)
-        ltmCheck(dev_->ctx, ltm_poses_create(dev_->ctx, kf_end_ - kf_begin_, p.data() + 16 * kf_begin_, pi.data() + 16 * kf_begin_, &poses_local_h_), "ltm_poses_create");
+    shardRange(keyframe_poses_.size(), rank(), world(), &kf_begin_, &kf_end_);
+    if (world() > 1) {
+        std::vector<double> p, pi;
+        for (size_t k = kf_begin_; k < kf_end_; ++k) {
+            p.insert(p.end(), keyframe_poses_[k].begin(), keyframe_poses_[k].end());
+            pi.insert(pi.end(), keyframe_inverse_poses_[k].begin(), keyframe_inverse_poses_[k].end());
+        }
+        ltmCheck(dev_->ctx, ltm_poses_create(dev_->ctx, kf_end_ - kf_begin_, p.data(), pi.data(), &poses_local_h_), "ltm_poses_create");
+    }
+}
+
+void Session::enterSessionGroup(std::shared_ptr<Comm> group)
+{
+    group_comm_ = std::move(group);
+    setKeyframeBlock();
+}
+void Session::leaveSessionGroup()
+{
+    group_comm_.reset();
+    setKeyframeBlock();
 }
 
 ScansPtr Session::wrap_shard(ltm_scanset h) const
 {
     ScansPtr s = wrap_scans(h);
-    if (dev_->world() > 1) { s->shard = true; s->kb = kf_begin_; s->n_total = keyframe_poses_.size(); }
+    if (world() > 1) { s->shard = true; s->kb = kf_begin_; s->n_total = keyframe_poses_.size(); }
     return s;
 }
 
@@ -239,7 +261,7 @@ void Session::stageArgs(const ScansPtr& scans, ltm_poses* poses, size_t* kb, siz
 ScansPtr Session::gatherScans(const ScansPtr& scans) const
 {
     if (!scans->shard) return scans;
-    Comm& comm = *dev_->comm;
+    Comm& comm = *this->comm();
     ltm_ctx* ctx = dev_->ctx;
     size_t nk = 0, np = 0;
     ltmCheck(ctx, ltm_scanset_info(ctx, scans->h, &nk, &np), "ltm_scanset_info");
@@ -372,10 +394,10 @@ CloudPtr Session::mergeScansToGlobal(const ScansPtr& scans) const
 }
 CloudPtr Session::mergeVoxel(const ScansPtr& scans, float leaf) const
 {
-    if (dev_->world() == 1 || !scans->shard) return octreeDownsampling(mergeScansToGlobal(scans), leaf);
-    Comm& comm = *dev_->comm;
+    if (world() == 1 || !scans->shard) return octreeDownsampling(mergeScansToGlobal(scans), leaf);
+    Comm& comm = *this->comm();
     ltm_ctx* ctx = dev_->ctx;
-    const int w = dev_->world(), me = dev_->rank();
+    const int w = world(), me = rank();
     // this rank's keyframes in the global frame
     ltm_cloud hl = 0;
     ltmCheck(ctx, ltm_merge_to_global(ctx, scans->h, poses_local_h_, &hl), "ltm_merge_to_global");
@@ -463,13 +485,13 @@ CloudPtr Session::octreeDownsampling(const CloudPtr& src, float leaf) const
     // Multi-GPU: the (replicated) input's Morton key space is cut into `world` contiguous ranges of equal point count; every rank
     // sorts and reduces its own range and the centroid lists, all-gathered in rank order, ARE the single-GPU output
     // (ltm_voxel_centroid_shard).  Small clouds stay replicated: the exchange would cost more than the sort.
-    if (dev_->world() > 1 && src->size() >= kVoxelShardMin) {
+    if (world() > 1 && src->size() >= kVoxelShardMin) {
         ltm_cloud piece = 0;
-        ltmCheck(ctx, ltm_voxel_centroid_shard(ctx, src->h, leaf, (uint32_t)dev_->rank(), (uint32_t)dev_->world(), &piece), "ltm_voxel_centroid_shard");
+        ltmCheck(ctx, ltm_voxel_centroid_shard(ctx, src->h, leaf, (uint32_t)rank(), (uint32_t)world(), &piece), "ltm_voxel_centroid_shard");
         CloudPtr mine = wrap(piece);
         const size_t n = mine->size();
         std::vector<uint64_t> sizes;
-        dev_->comm->allGatherU64(ctx, n, sizes);
+        comm()->allGatherU64(ctx, n, sizes);
         size_t total = 0;
         for (uint64_t& v : sizes) { total += v; v *= sizeof(PointType); }
         ltmCheck(ctx, ltm_cloud_alloc(ctx, total, &h), "ltm_cloud_alloc");
@@ -477,7 +499,7 @@ CloudPtr Session::octreeDownsampling(const CloudPtr& src, float leaf) const
         const void *s = nullptr, *d = nullptr;
         ltmCheck(ctx, ltm_cloud_device_ptr(ctx, piece, &s), "ltm_cloud_device_ptr");
         ltmCheck(ctx, ltm_cloud_device_ptr(ctx, h, &d), "ltm_cloud_device_ptr");
-        dev_->comm->allGatherV(ctx, s, n * sizeof(PointType), const_cast<void*>(d), sizes);
+        comm()->allGatherV(ctx, s, n * sizeof(PointType), const_cast<void*>(d), sizes);
         ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");      // `mine` is released on return
         return out;
     }
@@ -489,7 +511,7 @@ std::vector<CloudPtr> Session::octreeDownsamplingBatch(const std::vector<CloudPt
     std::vector<CloudPtr> out(src.size());
     std::vector<size_t> batch;
     for (size_t i = 0; i < src.size(); ++i) {
-        if (dev_->world() > 1 && src[i]->size() >= kVoxelShardMin) out[i] = octreeDownsampling(src[i], leaf);      // sharded + all-gathered
+        if (world() > 1 && src[i]->size() >= kVoxelShardMin) out[i] = octreeDownsampling(src[i], leaf);      // sharded + all-gathered
         else batch.push_back(i);
     }
     if (!batch.empty()) {
