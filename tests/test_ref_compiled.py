@@ -370,3 +370,12 @@ def test_reference_process_files_to_files(ref, orc, tmp_path):
     O = orc.pipeline_run(orc.make_params(k=2, knn_thr=0.01), C, Q)
     fp.compare_output_tree(out, O, [sess[0]["names"][k] for k in c_kf], assert_clouds_equal)
     assert sorted(os.listdir(out)) == sorted([m + ".pcd" for m in fp.MAP_FILES if O.cloud(m) is not None] + [d for d, _ in fp.SCAN_DIRS] + ["map_static", "map_dynamic"])
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_fuzz_tool_cases_against_reference_compiled(ref, seed):
+    """tools/fuzz_ref_vs_oracle.py (240 seeded cases, 333 M points: profiles/r4_fuzz_ref_vs_oracle_240.json) stays runnable: three of its draws"""
+    from tools import fuzz_ref_vs_oracle as fz
+    r = fz.run_case(fz.draw(seed))
+    assert r["ok"], r["differences"]
+    assert r["outputs_compared"] >= 25 and r["points_compared"] > 10_000
