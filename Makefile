@@ -12,7 +12,7 @@ all: hip oracle host
 hip: $(PKG)/libltm_hip.so
 $(PKG)/csrc/ltm_kernels.o: $(PKG)/csrc/ltm_kernels.hip $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_device_math.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(PKG)/csrc/ltm_api.o: $(PKG)/csrc/ltm_api.cpp $(PKG)/csrc/ltm_kernels.h include/ltm.h
+$(PKG)/csrc/ltm_api.o: $(PKG)/csrc/ltm_api.cpp $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_pclsort.h include/ltm.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
 $(PKG)/libltm_hip.so: $(PKG)/csrc/ltm_kernels.o $(PKG)/csrc/ltm_api.o
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^

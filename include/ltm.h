@@ -273,6 +273,11 @@ int ltm_debug_selfcheck(ltm_ctx*, uint64_t* mismatches3, int* fast_math_enabled)
  * *max_err_rad = largest error of its binary32 evaluation.  Returns 1 if the kernels use it for this field of view (vfov/2 + 2 deg
  * <= 45 deg and error <= 1e-6 rad), 0 if they keep the generic polynomial on [0, 1], < 0 on invalid arguments. */
 int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad);
+/* Host arithmetic only: the point order ltm_voxel_grid_scanset's default (PCL) path gives one keyframe whose points have the leaf indices
+ * leaf_idx[0..n) -- the permutation std::sort with pcl::VoxelGrid's leaf-index-only comparator leaves behind (voxel_grid.hpp), computed by
+ * lt-mapper_amd/csrc/ltm_pclsort.h (use_std_sort == 0) or by std::sort itself (!= 0); the two must agree (tests/test_abi.py). */
+int ltm_debug_pcl_sort_order(const uint32_t* leaf_idx, size_t n, uint32_t* order_out, int use_std_sort, uint32_t* heap_sort_fallbacks /* nullable: how
+                             often the restatement went into introsort's heap-sort fallback (0 for std::sort, which does not say) */);
 /* the voxel grid's sort key (host arithmetic only, needs no device): for a cloud with bounding box [mn, mx] and leaf size `leaf`, the
  * octree frame (depth, lattice origin) and the mask of the interleaved Morton-code bits (x = bit 3L+2, y = 3L+1, z = 3L of level L)
  * that the radix sort looks at -- the others are functions of more significant bits for every key inside the box and are left out

@@ -103,6 +103,7 @@ SIGNATURES = {
     "ltm_debug_viz_images": (_i, [_vp, _u64, _u64, _u64, _sz, _f, _i, _f, _f, _f, _f, _vp, _vp, _vp, _vp]),
     "ltm_debug_project": (_i, [_vp, _vp, _sz, _f, _vp, _vp]),
     "ltm_debug_elevation_fit": (_i, [_f, C.POINTER(_f), C.POINTER(C.c_double)]),
+    "ltm_debug_pcl_sort_order": (_i, [C.POINTER(C.c_uint32), C.c_size_t, C.POINTER(C.c_uint32), _i, C.POINTER(C.c_uint32)]),
     "ltm_debug_voxel_key_bits": (_i, [C.POINTER(_f), C.POINTER(_f), _f, _pu64, C.POINTER(C.c_uint), C.POINTER(C.c_double)]),
     "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
     "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),

@@ -2,6 +2,7 @@
 // per-stage orchestration of the gfx950 kernels in ltm_kernels.hip.  No CPU fallback: every stage runs
 // on the device or fails with an error code.
 #include "ltm.h"
+#include "ltm_pclsort.h"
 #include "ltm_kernels.h"
 
 #include <hip/hip_runtime_api.h>
@@ -2316,19 +2317,25 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                 LTM_HIP(hipMemcpyAsync(hk, keys.p, n * 8, hipMemcpyDeviceToHost, c->stream));
                 sync(c);
                 t2 = now();
-                struct Entry { uint32_t idx, cloud_point_index; };
+                // in place in the pinned key buffer: the 8 bytes of a 64-bit key (keyframe id | leaf index) become the (leaf index, point index) pair
+                // PCL sorts.  ltm_pclsort::sort performs std::sort's element moves without its branch mispredictions (ltm_pclsort.h: checked
+                // against std::sort itself); LTM_VOXELGRID_STDSORT=1 calls the library's std::sort instead
+                using Entry = ltm_pclsort::Entry;
+                static_assert(sizeof(Entry) == sizeof(uint64_t), "a pair replaces a key in place");
+                const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
+                const bool use_std_sort = std_env && atoi(std_env) != 0;
                 std::atomic<size_t> next{0};
                 auto work = [&] {
-                    std::vector<Entry> e;
+                    Entry* e = reinterpret_cast<Entry*>(hk);
                     for (;;) {
                         const size_t k = next.fetch_add(1);
                         if (k >= nk) return;
                         const size_t a = s.off[k], b = s.off[k + 1];
                         if (frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
-                        e.resize(b - a);
-                        for (size_t i = a; i < b; ++i) e[i - a] = Entry{(uint32_t)hk[i], (uint32_t)i};
-                        std::sort(e.begin(), e.end(), [](const Entry& x, const Entry& y) { return x.idx < y.idx; });
-                        for (size_t i = a; i < b; ++i) hi[i] = e[i - a].cloud_point_index;
+                        for (size_t i = a; i < b; ++i) { const uint32_t leaf = (uint32_t)hk[i]; e[i] = Entry{leaf, (uint32_t)i}; }
+                        if (use_std_sort) std::sort(e + a, e + b, ltm_pclsort::Less());
+                        else ltm_pclsort::sort(e + a, e + b);
+                        for (size_t i = a; i < b; ++i) hi[i] = e[i].cloud_point_index;
                     }
                 };
                 // one keyframe per task; a scans_updated set of 500 keyframes x 107 k points is ~2.5 s of single-thread std::sort, so the host decides what
@@ -2350,7 +2357,7 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
             } catch (...) { pinned_free(c, hk); pinned_free(c, hi); throw; }
             pinned_free(c, hk); pinned_free(c, hi);
             if (timing)
-                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down %.1f ms, std::sort on host threads %.1f ms, order up + gather %.1f ms\n",
+                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down %.1f ms, the sort on host threads %.1f ms, order up + gather %.1f ms\n",
                         n, nk, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
         } else {
             const size_t stb = sort_temp_bytes(n);
@@ -2719,6 +2726,23 @@ int ltm_debug_occlusion_stats(ltm_ctx* c, uint64_t* pairs, uint64_t* first_shell
         if (projected) *projected = c->occl_far_live;
         if (reset) { c->occl_pairs = 0; c->occl_near = 0; c->occl_far_live = 0; }
     });
+}
+
+// Host arithmetic only (no device, no context): the order ltm_voxel_grid_scanset's PCL-order path gives the points of one keyframe, through
+// ltm_pclsort::sort (use_std_sort == 0) or through the C++ library's std::sort (!= 0) -- tests/test_abi.py requires the two to agree.
+int ltm_debug_pcl_sort_order(const uint32_t* leaf_idx, size_t n, uint32_t* order_out, int use_std_sort, uint32_t* heap_sort_fallbacks)
+{
+    if ((!leaf_idx || !order_out) && n) return LTM_E_INVALID;
+    try {
+        std::vector<ltm_pclsort::Entry> e(n);
+        for (size_t i = 0; i < n; ++i) e[i] = ltm_pclsort::Entry{leaf_idx[i], (uint32_t)i};
+        const unsigned long before = ltm_pclsort::heap_sort_fallbacks();
+        if (use_std_sort) std::sort(e.begin(), e.end(), ltm_pclsort::Less());
+        else ltm_pclsort::sort(e.data(), e.data() + n);
+        if (heap_sort_fallbacks) *heap_sort_fallbacks = (uint32_t)(ltm_pclsort::heap_sort_fallbacks() - before);
+        for (size_t i = 0; i < n; ++i) order_out[i] = e[i].cloud_point_index;
+    } catch (...) { return LTM_E_NOMEM; }
+    return LTM_OK;
 }
 
 int ltm_debug_elevation_fit(float vfov_deg, float* c4, double* max_err_rad)

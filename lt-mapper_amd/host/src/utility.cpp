@@ -1,5 +1,6 @@
 // utility.cpp -- host-side helpers of the MI355X build of `removert` (mirror of ltremovert/src/utility.cpp without
 // ROS/PCL/OpenCV).  File formats only; no point arithmetic of the hot path happens here.
+#include "ltm_pclsort.h"
 #include "removert/utility.h"
 
 #include <algorithm>
@@ -345,20 +346,22 @@ void voxelGridFilter(const Cloud& in, float leaf, Cloud& out)
         minb[d] = (int)std::floor(mn[d] * inv);
         divb[d] = (int)std::floor(mx[d] * inv) - minb[d] + 1;
     }
-    std::vector<std::pair<uint32_t, uint32_t>> keyed(in.size());
+    std::vector<ltm_pclsort::Entry> keyed(in.size());
     for (size_t i = 0; i < in.size(); ++i) {
         const int i0 = (int)(std::floor(in[i].x * inv) - (float)minb[0]), i1 = (int)(std::floor(in[i].y * inv) - (float)minb[1]),
                   i2 = (int)(std::floor(in[i].z * inv) - (float)minb[2]);
-        keyed[i] = {(uint32_t)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]), (uint32_t)i};
+        keyed[i] = ltm_pclsort::Entry{(uint32_t)(i0 + i1 * divb[0] + i2 * divb[0] * divb[1]), (uint32_t)i};
     }
-    std::sort(keyed.begin(), keyed.end(), [](const std::pair<uint32_t, uint32_t>& a, const std::pair<uint32_t, uint32_t>& b) { return a.first < b.first; });
+    // std::sort's permutation for the leaf-index-only comparator, without its branch mispredictions (csrc/ltm_pclsort.h, checked against
+    // std::sort itself in tests/test_abi.py; the library's device hand-over uses the same routine)
+    ltm_pclsort::sort(keyed.data(), keyed.data() + keyed.size());
     Cloud res;
     size_t a = 0;
     while (a < keyed.size()) {
         size_t b = a;
         float sx = 0, sy = 0, sz = 0, si = 0;
-        while (b < keyed.size() && keyed[b].first == keyed[a].first) {
-            const PointType& p = in[keyed[b].second];
+        while (b < keyed.size() && keyed[b].idx == keyed[a].idx) {
+            const PointType& p = in[keyed[b].cloud_point_index];
             sx += p.x; sy += p.y; sz += p.z; si += p.intensity;
             ++b;
         }

@@ -91,3 +91,75 @@ def test_elevation_polynomial_fit_of_the_bounded_error_projection(ltm):
     assert used[50.0] == 1 and used[26.9] == 1 and used[30.0] == 1, "the shipped sensors (os1-64 50 deg, hdl-64e 26.9 deg) use the fitted form"
     assert used[60.0] == 0 and used[70.0] == 0 and used[86.0] == 0, "3e-6 rad and worse: not good enough for the band"
     assert lib.ltm_debug_elevation_fit(ctypes.c_float(-1.0), c, ctypes.byref(err)) < 0
+
+
+def _pcl_order(ltm, keys, use_std_sort, fallbacks=None):
+    import numpy as np
+    keys = np.ascontiguousarray(keys, dtype=np.uint32)
+    out = np.empty(len(keys), dtype=np.uint32)
+    fb = ctypes.c_uint32(0)
+    rc = ltm.load_library().ltm_debug_pcl_sort_order(keys.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), len(keys),
+                                                     out.ctypes.data_as(ctypes.POINTER(ctypes.c_uint32)), int(use_std_sort), ctypes.byref(fb))
+    assert rc == 0
+    if fallbacks is not None:
+        fallbacks.append(fb.value)
+    return out
+
+
+def test_pcl_sort_order_is_exactly_what_std_sort_leaves(ltm):
+    """lt-mapper_amd/csrc/ltm_pclsort.h restates libstdc++'s introsort for (leaf index, point index) pairs compared by leaf index only -- the
+    permutation pcl::VoxelGrid sums its voxels in -- without std::sort's branch mispredictions.  It must give the SAME permutation as std::sort
+    (both reached through the C ABI, host arithmetic only): random sizes and key ranges with many duplicates, presorted / reversed / organ-pipe /
+    constant inputs, sizes around the block and threshold boundaries, and realistic keyframe sizes."""
+    import numpy as np
+    rng = np.random.default_rng(20250926)
+    n_cases = 0
+    sizes = list(range(0, 40)) + [63, 64, 65, 127, 128, 129, 191, 192, 193, 255, 256, 257, 258, 300, 511, 512, 513, 1000, 4095, 4096, 4097] + [int(v) for v in rng.integers(300, 30000, 120)]
+    for n in sizes:
+        for rng_span in (3, max(n // 8, 1), max(2 * n // 3, 1), 1 << 31):
+            keys = rng.integers(0, rng_span, n, dtype=np.uint64).astype(np.uint32)
+            variants = [keys]
+            if n_cases % 5 == 0:
+                s = np.sort(keys)
+                noisy = s.copy()
+                if n > 4:
+                    i, j = rng.integers(0, n, (2, max(n // 50, 1)))
+                    noisy[i], noisy[j] = s[j], s[i]
+                organ = np.minimum(np.arange(n), n - np.arange(n)).astype(np.uint32)
+                variants += [s, s[::-1].copy(), noisy, organ, np.full(n, 7, np.uint32)]
+            for k in variants:
+                a, b = _pcl_order(ltm, k, True), _pcl_order(ltm, k, False)
+                assert (a == b).all(), f"n={n} span={rng_span}: the permutations differ at {int(np.flatnonzero(a != b)[0])}"
+                assert (np.diff(k[a].astype(np.int64)) >= 0).all() and len(set(a.tolist())) == n
+                n_cases += 1
+    for n in (107_000, 131_072, 260_000):      # a scan under a 5 cm grid: ~1.5 points per leaf
+        keys = rng.integers(0, 2 * n // 3, n, dtype=np.uint64).astype(np.uint32)
+        assert (_pcl_order(ltm, keys, True) == _pcl_order(ltm, keys, False)).all()
+        n_cases += 1
+    assert n_cases > 1000
+
+
+def test_pcl_sort_order_follows_std_sort_into_its_heap_sort_fallback(ltm):
+    """tests/golden/stdsort_adversary_keys.npz: keys frozen by McIlroy's adversary ("A Killer Adversary for Quicksort", 1999) played against
+    libstdc++'s std::sort itself (the comparator decides the keys while std::sort runs) -- inputs on which THAT std::sort runs out of its depth
+    limit 2 floor(log2 n) and finishes a segment with heap sort.  The restatement must take the same turn (it reports that it did) and leave
+    the same permutation; Musser's median-of-3 killer and a saw-tooth ride along."""
+    import numpy as np
+    adv = np.load(os.path.join(ROOT, "tests", "golden", "stdsort_adversary_keys.npz"))
+    for name in adv.files:
+        keys = adv[name]
+        fb = []
+        a, b = _pcl_order(ltm, keys, True), _pcl_order(ltm, keys, False, fb)
+        assert (a == b).all(), name
+        assert fb[0] >= 1, f"{name}: the adversarial input no longer reaches the heap-sort fallback (another C++ library?)"
+    for n in (300, 2000, 20000, 120000):
+        k = n // 2
+        killer = np.zeros(n, np.uint32)
+        i = np.arange(1, k + 1)
+        odd = i[i % 2 == 1]
+        killer[odd - 1] = odd
+        killer[odd[odd < n]] = (k + odd)[odd < n]
+        killer[k + i - 1] = 2 * i
+        saw = (np.arange(n) % 17 * 1000 + np.arange(n) // 17).astype(np.uint32)
+        for keys in (killer, killer[::-1].copy(), saw):
+            assert (_pcl_order(ltm, keys, True) == _pcl_order(ltm, keys, False)).all(), n

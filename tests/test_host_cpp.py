@@ -98,7 +98,7 @@ def test_ros_wrapper_compiles_and_links_against_api_stubs(tmp_path):
     for f in ("utility.cpp", "RosParamServer.cpp", "Session.cpp", "Removerter.cpp", "Comm.cpp", "removert_main_ros.cpp"):
         assert f in cm, f"{f} missing from the catkin target"
     exe = str(tmp_path / "removert_removert")
-    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "tests", "ros_stubs"), "-I", host, "-I", os.path.join(ROOT, "include"),
+    cmd = ["g++", "-O1", "-std=c++17", "-Wall", "-pthread", "-I", os.path.join(ROOT, "tests", "ros_stubs"), "-I", host, "-I", os.path.join(ROOT, "include"), "-I", os.path.join(ROOT, "lt-mapper_amd", "csrc"),
            "-o", exe] + src + ["-L", os.path.join(ROOT, "lt-mapper_amd"), "-lltm_hip", "-Wl,-rpath," + os.path.join(ROOT, "lt-mapper_amd"), "-Wl,-rpath,/opt/rocm/lib"]
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stderr[-3000:]

@@ -21,7 +21,7 @@ def kernels_sha():
 
 def product_sha():
     """device code + the C ABI orchestration: what the RESULTS of the library depend on"""
-    return _sha(("ltm_kernels.hip", "ltm_device_math.h", "ltm_kernels.h", "ltm_api.cpp"))
+    return _sha(("ltm_kernels.hip", "ltm_device_math.h", "ltm_kernels.h", "ltm_api.cpp", "ltm_pclsort.h"))
 
 
 def oracle_sha():

@@ -4,6 +4,7 @@
 //   A  per-thread std::vector scratch (what the library did), threads created per call
 //   B  in place in the one shared buffer (no allocation inside the timed region)
 //   C  B + every thread pinned to its own physical core (first hardware thread of each core, from sysfs)
+//   P  B with ltm_pclsort::sort (the same permutation without std::sort's branch mispredictions, lt-mapper_amd/csrc/ltm_pclsort.h)
 #include <algorithm>
 #include <atomic>
 #include <chrono>
@@ -20,7 +21,9 @@
 #include <pthread.h>
 #include <sched.h>
 
-struct Entry { uint32_t idx, cloud_point_index; };
+#include "../../lt-mapper_amd/csrc/ltm_pclsort.h"
+
+using Entry = ltm_pclsort::Entry;
 
 static std::vector<int> physical_cores()
 {
@@ -76,7 +79,8 @@ int main(int argc, char** argv)
                 } else {
                     Entry* s = reinterpret_cast<Entry*>(hk.data());
                     for (size_t i = a; i < b; ++i) s[i] = Entry{(uint32_t)hk[i], (uint32_t)i};
-                    std::sort(s + a, s + b, [](const Entry& x, const Entry& y) { return x.idx < y.idx; });
+                    if (variant == 'P') ltm_pclsort::sort(s + a, s + b);
+                    else std::sort(s + a, s + b, [](const Entry& x, const Entry& y) { return x.idx < y.idx; });
                     for (size_t i = a; i < b; ++i) hi[i] = s[i].cloud_point_index;
                 }
             }
@@ -92,7 +96,7 @@ int main(int argc, char** argv)
     ref = hi;
     for (size_t nt : {8, 16, 24, 32, 48, 64, 128, 256}) {
         if (nt > 2 * std::thread::hardware_concurrency()) continue;
-        for (char v : {'A', 'B', 'C'}) {
+        for (char v : {'A', 'B', 'C', 'P'}) {
             printf("%c threads %3zu:", v, nt);
             for (int r = 0; r < reps; ++r) {
                 const double ms = run(v, nt);
