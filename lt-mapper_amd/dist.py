@@ -20,6 +20,8 @@ Everything else (merge, the tiny weak->strong ND split) is replicated.  The coll
 torch.distributed calls (backend "nccl" = RCCL on ROCm; "gloo" in the CPU tests), so the same code is exercised
 on CPU with world_size 2.  `ops` is any object with the stage interface of removerter.HipOps.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -59,7 +61,7 @@ class ShardedOps:
     # runs one after the other): with an even world the even ranks take the central session and the odd ranks the query session, each group
     # sharding ITS session's keyframes world/2 ways.  A rank then does the replicated part (partitions, re-grids, host round trips) of one
     # session instead of two and its label all-reduces span half the ranks; the price is one swap of the finished maps between rank pairs.
-    SESSION_GROUPS = True
+    SESSION_GROUPS = os.environ.get("LTM_SESSION_GROUPS", "1") != "0"      # the switch the C++ host reads as well (Comm.cpp)
 
     def __init__(self, ops, dist, rank, world, group=None, peer=None):
         self.ops, self.dist, self.rank, self.world, self.group = ops, dist, rank, world, group
