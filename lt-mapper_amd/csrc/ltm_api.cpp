@@ -2309,39 +2309,53 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
             auto now = [] { return std::chrono::steady_clock::now(); };
             auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
             const auto t0 = now();
-            uint64_t* hk = static_cast<uint64_t*>(pinned_alloc(c, n * 8));
+            // The pinned buffer receives the 64-bit keys (keyframe id << 32 | leaf index) and is read as the (leaf index, point index) pairs PCL
+            // sorts: on this little-endian host a key's low word IS the pair's first member, and the high word -- the keyframe id, which the
+            // keyframe-by-keyframe sort does not need -- is overwritten with the point index.  ltm_pclsort::sort performs std::sort's element moves
+            // without its branch mispredictions (ltm_pclsort.h: checked against std::sort itself); LTM_VOXELGRID_STDSORT=1 calls std::sort.
+            using Entry = ltm_pclsort::Entry;
+            static_assert(sizeof(Entry) == sizeof(uint64_t) && offsetof(Entry, idx) == 0 && offsetof(Entry, cloud_point_index) == 4, "a pair overlays a key");
+            Entry* he = static_cast<Entry*>(pinned_alloc(c, n * 8));
             uint32_t* hi = static_cast<uint32_t*>(pinned_alloc(c, n * 4));
             const auto t1 = now();
             auto t2 = t1, t3 = t1;
+            // the keys come down in a few chunks of whole keyframes, an event behind each: the first keyframes are being sorted while the rest is
+            // still on the link (67 M keys = 0.54 GB take 10 ms; the sort of 500 keyframes takes 20 ms on 64 threads)
+            const size_t G = std::min<size_t>(8, std::max<size_t>(nk, 1));
+            std::vector<size_t> chunk_kf(G + 1);
+            for (size_t g = 0; g <= G; ++g) chunk_kf[g] = nk * g / G;
+            std::vector<hipEvent_t> ev(G, nullptr);
+            auto drop_events = [&] { for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } };
             try {
-                LTM_HIP(hipMemcpyAsync(hk, keys.p, n * 8, hipMemcpyDeviceToHost, c->stream));
-                sync(c);
-                t2 = now();
-                // in place in the pinned key buffer: the 8 bytes of a 64-bit key (keyframe id | leaf index) become the (leaf index, point index) pair
-                // PCL sorts.  ltm_pclsort::sort performs std::sort's element moves without its branch mispredictions (ltm_pclsort.h: checked
-                // against std::sort itself); LTM_VOXELGRID_STDSORT=1 calls the library's std::sort instead
-                using Entry = ltm_pclsort::Entry;
-                static_assert(sizeof(Entry) == sizeof(uint64_t), "a pair replaces a key in place");
+                for (size_t g = 0; g < G; ++g) {
+                    LTM_HIP(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming));
+                    const size_t a = s.off[chunk_kf[g]], b = s.off[chunk_kf[g + 1]];
+                    if (b > a) LTM_HIP(hipMemcpyAsync(he + a, keys.as<uint64_t>() + a, (b - a) * 8, hipMemcpyDeviceToHost, c->stream));
+                    LTM_HIP(hipEventRecord(ev[g], c->stream));
+                }
                 const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
                 const bool use_std_sort = std_env && atoi(std_env) != 0;
                 std::atomic<size_t> next{0};
+                std::atomic<bool> failed{false};
                 auto work = [&] {
-                    Entry* e = reinterpret_cast<Entry*>(hk);
+                    if (hipSetDevice(c->device) != hipSuccess) { failed = true; return; }
+                    size_t g = 0;
                     for (;;) {
-                        const size_t k = next.fetch_add(1);
-                        if (k >= nk) return;
+                        const size_t k = next.fetch_add(1);      // keyframes are handed out in ascending order: so are the chunks waited for
+                        if (k >= nk || failed) return;
+                        while (k >= chunk_kf[g + 1]) ++g;
+                        if (hipEventSynchronize(ev[g]) != hipSuccess) { failed = true; return; }
                         const size_t a = s.off[k], b = s.off[k + 1];
                         if (frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
-                        for (size_t i = a; i < b; ++i) { const uint32_t leaf = (uint32_t)hk[i]; e[i] = Entry{leaf, (uint32_t)i}; }
-                        if (use_std_sort) std::sort(e + a, e + b, ltm_pclsort::Less());
-                        else ltm_pclsort::sort(e + a, e + b);
-                        for (size_t i = a; i < b; ++i) hi[i] = e[i].cloud_point_index;
+                        for (size_t i = a; i < b; ++i) he[i].cloud_point_index = (uint32_t)i;
+                        if (use_std_sort) std::sort(he + a, he + b, ltm_pclsort::Less());
+                        else ltm_pclsort::sort(he + a, he + b);
+                        for (size_t i = a; i < b; ++i) hi[i] = he[i].cloud_point_index;
                     }
                 };
-                // one keyframe per task; a scans_updated set of 500 keyframes x 107 k points is ~2.5 s of single-thread std::sort, so the host decides what
-                // the exact order costs: ~100 ms on the 256-thread GPU box, where 64, 128, 192 and 256 threads measured the same (87-105 ms, more
-                // threads only noisier: profiles/r4_voxel_grid_scanset_pcl_order_threads.txt) against 5 ms for the all-device input order
-                // (LTM_VOXELGRID_THREADS overrides the cap of 64)
+                // one keyframe per task.  A scans_updated set of 500 keyframes x 107-134 k points is ~1 s of host CPU time with ltm_pclsort (2.5 s
+                // with std::sort): 20 ms on 64 threads of the GPU box (profiles/r4_hostsort_pclsort_vs_stdsort.txt); LTM_VOXELGRID_THREADS
+                // overrides the cap of 64
                 const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
                 const char* tenv = getenv("LTM_VOXELGRID_THREADS");
                 const size_t cap = tenv && atoi(tenv) > 0 ? (size_t)atoi(tenv) : 64;
@@ -2350,15 +2364,17 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                 for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
                 work();
                 for (std::thread& t : pool) t.join();
-                t3 = now();
+                if (failed) throw Err{LTM_E_DEVICE, "voxel_grid_scanset: waiting for the keys of a keyframe chunk failed"};
+                t2 = t3 = now();
                 LTM_HIP(hipMemcpyAsync(idx2.p, hi, n * 4, hipMemcpyHostToDevice, c->stream));
                 LTM_HIP(gather_u64_by_u32(keys.as<uint64_t>(), idx2.as<uint32_t>(), n, keys2.as<uint64_t>(), c->stream));
                 sync(c);
-            } catch (...) { pinned_free(c, hk); pinned_free(c, hi); throw; }
-            pinned_free(c, hk); pinned_free(c, hi);
+            } catch (...) { (void)hipStreamSynchronize(c->stream); drop_events(); pinned_free(c, he); pinned_free(c, hi); throw; }
+            drop_events();
+            pinned_free(c, he); pinned_free(c, hi);
             if (timing)
-                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down %.1f ms, the sort on host threads %.1f ms, order up + gather %.1f ms\n",
-                        n, nk, ms(t0, t1), ms(t1, t2), ms(t2, t3), ms(t3, now()));
+                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down (in %zu chunks) overlapped with the sort on host threads %.1f ms, order up + gather %.1f ms\n",
+                        n, nk, ms(t0, t1), G, ms(t1, t2), ms(t3, now()));
         } else {
             const size_t stb = sort_temp_bytes(n);
             DevBuf stemp(c, stb);
