@@ -2319,9 +2319,13 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
             uint32_t* hi = static_cast<uint32_t*>(pinned_alloc(c, n * 4));
             const auto t1 = now();
             auto t2 = t1, t3 = t1;
-            // the keys come down in a few chunks of whole keyframes, an event behind each: the first keyframes are being sorted while the rest is
-            // still on the link (67 M keys = 0.54 GB take 10 ms; the sort of 500 keyframes takes 20 ms on 64 threads)
-            const size_t G = std::min<size_t>(8, std::max<size_t>(nk, 1));
+            // The keys come down in ONE piece and the sort starts when they are there (67 M keys = 0.54 GB: 10 ms; the sort of 500 keyframes:
+            // 20 ms on 64 threads).  LTM_VOXELGRID_CHUNKS=G > 1 sends them in G chunks of whole keyframes with an event behind each, so that the
+            // first keyframes are sorted while the rest is still on the link -- measured SLOWER on the GPU box (33-35 ms against 10 + 20.5 ms,
+            // profiles/r4_voxel_grid_scanset_chunked_keys.txt): 64 threads waiting on events spin, and spinning threads eat the 16 CPUs' worth of
+            // time the container has.  Kept as a switch for hosts without such a quota.
+            const char* genv = getenv("LTM_VOXELGRID_CHUNKS");
+            const size_t G = std::min<size_t>(genv && atoi(genv) > 0 ? (size_t)atoi(genv) : 1, std::max<size_t>(nk, 1));
             std::vector<size_t> chunk_kf(G + 1);
             for (size_t g = 0; g <= G; ++g) chunk_kf[g] = nk * g / G;
             std::vector<hipEvent_t> ev(G, nullptr);
@@ -2333,6 +2337,7 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                     if (b > a) LTM_HIP(hipMemcpyAsync(he + a, keys.as<uint64_t>() + a, (b - a) * 8, hipMemcpyDeviceToHost, c->stream));
                     LTM_HIP(hipEventRecord(ev[g], c->stream));
                 }
+                if (G == 1) { sync(c); t2 = now(); }       // the calling thread waits once; no worker ever waits
                 const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
                 const bool use_std_sort = std_env && atoi(std_env) != 0;
                 std::atomic<size_t> next{0};
@@ -2344,7 +2349,7 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                         const size_t k = next.fetch_add(1);      // keyframes are handed out in ascending order: so are the chunks waited for
                         if (k >= nk || failed) return;
                         while (k >= chunk_kf[g + 1]) ++g;
-                        if (hipEventSynchronize(ev[g]) != hipSuccess) { failed = true; return; }
+                        if (G > 1 && hipEventSynchronize(ev[g]) != hipSuccess) { failed = true; return; }
                         const size_t a = s.off[k], b = s.off[k + 1];
                         if (frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
                         for (size_t i = a; i < b; ++i) he[i].cloud_point_index = (uint32_t)i;
@@ -2365,7 +2370,8 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                 work();
                 for (std::thread& t : pool) t.join();
                 if (failed) throw Err{LTM_E_DEVICE, "voxel_grid_scanset: waiting for the keys of a keyframe chunk failed"};
-                t2 = t3 = now();
+                t3 = now();
+                if (G > 1) t2 = t1;
                 LTM_HIP(hipMemcpyAsync(idx2.p, hi, n * 4, hipMemcpyHostToDevice, c->stream));
                 LTM_HIP(gather_u64_by_u32(keys.as<uint64_t>(), idx2.as<uint32_t>(), n, keys2.as<uint64_t>(), c->stream));
                 sync(c);
@@ -2373,8 +2379,8 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
             drop_events();
             pinned_free(c, he); pinned_free(c, hi);
             if (timing)
-                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down (in %zu chunks) overlapped with the sort on host threads %.1f ms, order up + gather %.1f ms\n",
-                        n, nk, ms(t0, t1), G, ms(t1, t2), ms(t3, now()));
+                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down (%zu chunk%s) %.1f ms, the sort on host threads %s%.1f ms, order up + gather %.1f ms\n",
+                        n, nk, ms(t0, t1), G, G > 1 ? "s" : "", ms(t1, t2), G > 1 ? "(keys arriving meanwhile) " : "", ms(t2, t3), ms(t3, now()));
         } else {
             const size_t stb = sort_temp_bytes(n);
             DevBuf stemp(c, stb);
