@@ -2343,7 +2343,7 @@ int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset*
                 std::atomic<size_t> next{0};
                 std::atomic<bool> failed{false};
                 auto work = [&] {
-                    if (hipSetDevice(c->device) != hipSuccess) { failed = true; return; }
+                    if (G > 1 && hipSetDevice(c->device) != hipSuccess) { failed = true; return; }      // only a thread that waits for an event talks to the runtime
                     size_t g = 0;
                     for (;;) {
                         const size_t k = next.fetch_add(1);      // keyframes are handed out in ascending order: so are the chunks waited for
