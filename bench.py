@@ -351,7 +351,7 @@ def main():
                        "remove_resolution_list": P.remove_resolution_list if three_res else [2.5], "self_removert": three_res,
                        "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points_last_pair": [M_c, M_q],
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
-                       "parallelism": f"keyframe-sharded x{world} (label all-reduce + scan all-gather)" if world > 1 else
+                       "parallelism": (f"keyframe-sharded x{world} (label all-reduce, key-range all-to-all for the merges" + (", one rank group per session in Step 1" if world % 2 == 0 and os.environ.get("LTM_SESSION_GROUPS", "1") != "0" else "") + ")") if world > 1 else
                                       ("single GPU, the two sessions' merge + Step-1 chains side by side on two contexts (--overlap-sessions experiment)" if args.overlap_sessions else "single GPU"),
                        "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
