@@ -26,9 +26,15 @@ def _bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).reshape(-1, 4).view(np.uint32)
 
 
-def draw(seed):
+def draw(seed, real_sensors=False):
     rng = np.random.default_rng(seed)
     three = bool(rng.integers(0, 2))
+    if real_sensors:      # the BASELINE sensors at their full resolution, few keyframes (the reference-compiled build is serial)
+        case = dict(seed=int(seed), sensor=str(rng.choice(["os1-64", "hdl-64e"])), scene=str(rng.choice(["lot", "street"])), n_kf=int(rng.integers(3, 7)),
+                    spacing=float(rng.choice([1.0, 2.0, 4.0])), three=three, k=int(rng.integers(1, 4)), thr=float(rng.choice([0.01, 0.02, 0.1])),
+                    voxel=float(rng.choice([0.05, 0.1])), tilt_deg=float(rng.choice([0.0, 3.0])), z_drift=float(rng.choice([0.0, 0.05])),
+                    origin=[float(v) for v in (rng.choice([0.0, 1.0]) * rng.uniform(-5e4, 5e4, 3) * [1, 1, 0.002])], extrinsic=bool(rng.integers(0, 2)))
+        return case
     case = dict(seed=int(seed), sensor=str(rng.choice(["tiny", "tiny", "small"])), scene=str(rng.choice(["lot", "street"])),
                 n_kf=int(rng.integers(3, 9) if three else rng.integers(3, 14)), spacing=float(rng.choice([0.5, 1.0, 2.0, 4.0])), three=three,
                 k=int(rng.integers(1, 5)), thr=float(rng.choice([0.005, 0.01, 0.02, 0.05, 0.1, 0.25])), voxel=float(rng.choice([0.05, 0.05, 0.1, 0.2])),
@@ -57,7 +63,8 @@ def run_case(case):
         ext[:3, :3] = (np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]) @ np.array([[cy, 0, sy], [0, 1, 0], [-sy, 0, cy]]) @ np.array([[1, 0, 0], [0, cx, -sx], [0, sx, cx]]))
         ext[:3, 3] = rng.uniform(-0.5, 0.5, 3)
     res = (2.5, 2.0, 1.5) if case["three"] else (2.5,)
-    kw = dict(k=case["k"], knn_thr=case["thr"], voxel=case["voxel"], lidar2base=ext, use_self_removert=case["three"], res_list=res)
+    kw = dict(k=case["k"], knn_thr=case["thr"], voxel=case["voxel"], lidar2base=ext, use_self_removert=case["three"], res_list=res,
+              vfov=26.9 if case["sensor"] == "hdl-64e" else 50.0)        # the yaml's sequence_vfov for that sensor (config/params_ltmapper.yaml)
     R = ref_py.Removerter(ref_py.make_params(**kw)).pipeline_run(C, Q)
     O = orc.pipeline_run(orc.make_params(**kw), C, Q)
     bad, n_pts, n_out = [], 0, 0
@@ -99,11 +106,12 @@ def main():
     ap.add_argument("--seed", type=int, default=20250926)
     ap.add_argument("--jobs", type=int, default=max(1, (os.cpu_count() or 2) - 1))
     ap.add_argument("--out", default=None)
+    ap.add_argument("--real-sensors", action="store_true", help="os1-64 / hdl-64e at full resolution, 3-6 keyframes per session")
     args = ap.parse_args()
     from oracle import ref_py
     if not ref_py.available():
         ref_py.build()
-    cases = [draw(args.seed + i) for i in range(args.n)]
+    cases = [draw(args.seed + i, args.real_sensors) for i in range(args.n)]
     t0 = time.time()
     with ProcessPoolExecutor(max_workers=args.jobs) as ex:
         results = list(ex.map(run_case, cases))
