@@ -102,7 +102,8 @@ def _worker(rank, world, port, q, session_groups=True, three_res=False):
 
 # 4 keyframes per session: equal blocks (2 + 2) and unequal ones (2 + 1 + 1).  An even world splits into a central and a query rank group for
 # Step 1 (ShardedOps.session_groups: world 2 = two groups of one rank, world 4 = two groups of two); (2, False) keeps the unsplit path covered
-@pytest.mark.parametrize("world,session_groups,three_res", [(2, True, False), (3, True, False), (4, True, False), (4, True, True), (2, False, False)])
+@pytest.mark.parametrize("world,session_groups,three_res", [(2, True, False), (3, True, False), (4, True, False), (4, True, True), (2, False, False),
+                                                            (6, False, False), (6, True, True)])     # more ranks than keyframes: empty blocks
 def test_keyframe_sharding_over_gloo_matches_single_process(orc, world, session_groups, three_res):
     import torch.multiprocessing as mp
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
