@@ -20,6 +20,16 @@ def test_host_selftest_pcd_yaml_pose_voxelgrid(tmp_path):
     assert "all checks passed" in r.stdout
 
 
+def test_local_comm_exchanges_session_groups_and_failure_release():
+    """lt-mapper_amd/host/src/comm_selftest.cpp: LocalComm on CPU threads (host memory as "device" memory): label MAX all-reduce, all-gather(-v),
+    all-to-all-v, the session groups of even worlds with their pair swap, LTM_SESSION_GROUPS=0, and a failing rank releasing the ranks parked in
+    the world's and in either group's barrier"""
+    _build()
+    r = subprocess.run([os.path.join(HOST, "comm_selftest")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "all checks passed" in r.stdout
+
+
 def test_cli_usage_and_loud_failure_without_gpu(tmp_path):
     import torch
     _build()
