@@ -62,6 +62,10 @@ WORKLOADS = {
 }
 CASCADE_SESSIONS = {"lot-cascade-6x500": 6, "lot-cascade-4x50-small": 4}
 
+VALU_CLASSES = ("vote_map_cull", "vote_map_exact", "reproject_map")      # projection kernels: bound by VALU issue, not HBM
+DOMINANT_KERNEL = {"vote_map_cull": "k_vote_map_cull", "vote_map_exact": "k_map_rimg_blockmin", "reproject_map": "k_map_rimg_blockmin", "knn_query": "k_knn_fast",
+                   "knn_query_p2": "k_knn_slow_sorted", "voxel": "rocprim onesweep + k_voxel_centroids_packed", "merge": "k_transform_scans"}
+
 # kernel class (ltm_profile_read) -> kernels behind it; bytes are the algorithmic bytes of DESIGN.md section 4
 CLASS_KERNELS = {
     "vote_map_cull": "k_vote_map_cull", "vote_map_exact": "k_map_rimg_blockmin", "reproject_map": "k_map_rimg_blockmin",
@@ -80,14 +84,17 @@ def parse_args():
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default=DEFAULT_WORKLOAD, choices=sorted(WORKLOADS))
-    ap.add_argument("--cpu-stride", type=int, default=10, help="cpu_baseline, single thread: visit every s-th keyframe in per-keyframe loops (round 4: 10, "
-                                                               "i.e. 50 of 500 keyframes per session; ~2 min of the default run on the GPU box's host)")
+    ap.add_argument("--cpu-stride", type=int, default=50, help="cpu_baseline, single thread: visit every s-th keyframe in per-keyframe loops (50 = 10 of 500 "
+                                                               "keyframes per session: ~50 s on the GPU box's host; round 4 ran stride 10 = 165 s of a 187 s driver run)")
     ap.add_argument("--cpu-stride-allcore", type=int, default=10, help="cpu_baseline, all cores: keyframe stride")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-baseline-now", action="store_true", help="non-default workloads: time the sampled CPU leg in this run (minutes to hours on the big "
+                                                                    "configurations) instead of quoting profiles/cpu_baseline_<workload>.json (tools/cpu_baseline_sampled.py)")
     ap.add_argument("--no-t-total", action="store_true", help="skip the files -> files measurement through ltm_run (default workload, one GPU)")
     ap.add_argument("--cpu-allcore", action="store_true", help="cpu_baseline: also time the oracle on all host cores now (every keyframe when the box has "
                                                                "many cores: ~3 min on 256); without it the committed measurement is quoted")
     ap.add_argument("--verbose", action="store_true")
+    ap.add_argument("--extra-out", default=None, help="sidecar file for everything the printed line does not carry (default profiles/bench_extra_latest.json)")
     ap.add_argument("--overlap-sessions", action="store_true", help="EXPERIMENT (one GPU, pair workloads): merge + grid and Step 1 of the query session on a second "
                     "context / stream / host thread beside the central session's (removerter.Removerter query_side).  Kernel times of overlapping launches "
                     "are inflated by each other, so the roofline figures of such a line describe the overlap, not the kernels")
@@ -260,73 +267,80 @@ def main():
 
     groups = traffic_groups(pmc, prof, args.steps)
 
+    steps = max(args.steps, 1)
+    step_kernel_ms = sum(v["ms"] for v in prof.values()) / steps
+
     def class_roofline(cls, v):
+        """one kernel class of the step against the resource that bounds it.  HBM-bound classes: `frac` = compulsory bytes / class time / 8 TB/s (SURVEY 8d's
+        `achieved`); VALU-bound classes (the projection kernels): `frac` = SQ_INSTS_VALU x 64 lanes / class time / nominal VALU lane rate.  Beside it, always:
+        hbm_algorithmic_frac (SURVEY 8d's formula: one map read per keyframe -- may exceed 1 for the projection kernels, which read the map once per launch),
+        hbm_compulsory_frac (bytes the launch must move as designed), hbm_measured_frac and traffic_over_compulsory from the PMC passes (null without them)"""
         if not v["launches"] or v["ms"] <= 0:
             return None
-        achieved = v["bytes"] / (v["ms"] * 1e-3) / 1e9
-        g = next((g for g in groups if cls in g["classes"]), None)
-        # frac = MEASURED HBM traffic of the class's kernel group over its time against the peak (null without counter data for these
-        # sources); the algorithmic figure stands beside it and may exceed 1 where caches serve the re-reads (vote / exact-image kernels)
-        r = {"class": cls, "kernels": CLASS_KERNELS.get(cls, cls), "bound": "valu" if cls in ("vote_map_cull", "vote_map_exact", "reproject_map") else "hbm",
-             "frac": g["hbm_measured_frac"] if g else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-             "hbm_algorithmic_GBs": round(achieved, 1), "hbm_algorithmic_frac": round(achieved / HBM_PEAK_GBS, 4),
-             "ms_per_step": round(v["ms"] / args.steps, 3), "launches_per_step": round(v["launches"] / max(args.steps, 1), 2),
-             "algorithmic_bytes_per_step": round(v["bytes"] / args.steps, 1), "units_per_step": round(v["units"] / args.steps, 1)}
-        if g:     # measured HBM traffic of the kernel group this class belongs to (shared with the other classes of the group)
-            r.update(traffic_group=g["group"], traffic=g["traffic_bytes_per_step"], traffic_over_algorithmic=g["traffic_over_algorithmic"], frac_scope="group")
-        # one group fraction copied to six classes says nothing about the class.  Where the class's kernels are its own, `frac` is the
-        # class's measured traffic over the class's time; classes that also run rocPRIM kernels keep the group figure as `frac` and report
-        # their own kernels' share beside it
-        own, names = class_own_traffic(pmc, cls)
-        if own is not None:
-            ms = v["ms"] / max(args.steps, 1)
-            own_frac = round(own / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if ms else None
-            alg = v["bytes"] / max(args.steps, 1)
-            r.update(class_kernels_counted=names, class_traffic=round(own, 1), class_traffic_over_algorithmic=round(own / alg, 3) if alg else None)
-            if cls in CLASSES_WITH_LIBRARY_KERNELS:
-                r.update(class_frac_own_kernels_only=own_frac, library_kernels_not_attributable=CLASSES_WITH_LIBRARY_KERNELS[cls])
-            else:
-                r.update(frac=own_frac, frac_scope="class", traffic=round(own, 1), traffic_over_algorithmic=round(own / alg, 3) if alg else None)
+        ms = v["ms"] / steps
+        sec = ms * 1e-3
+        alg, comp = v["bytes"] / steps, v.get("bytes_c", v["bytes"]) / steps
+        bound = "valu" if cls in VALU_CLASSES else "hbm"
+        r = {"class": cls, "kernels": CLASS_KERNELS.get(cls, cls), "bound": bound, "ms_per_step": round(ms, 3), "launches_per_step": round(v["launches"] / steps, 2),
+             "units_per_step": round(v["units"] / steps, 1), "algorithmic_bytes_per_step": round(alg, 1), "compulsory_bytes_per_step": round(comp, 1),
+             "hbm_algorithmic_frac": round(alg / sec / (HBM_PEAK_GBS * 1e9), 4), "hbm_compulsory_frac": round(comp / sec / (HBM_PEAK_GBS * 1e9), 4),
+             "valu_frac": None, "traffic": None, "traffic_scope": None, "hbm_measured_frac": None, "traffic_over_compulsory": None}
+        share = 1.0
+        if cls in SHARED_KERNEL_CLASSES:
+            tot = sum(prof[c]["ms"] for c in SHARED_KERNEL_CLASSES if c in prof)
+            share = v["ms"] / tot if tot else 1.0
+        own, names = class_own_counter(pmc, cls, "traffic", share)
+        if own is not None and cls not in CLASSES_WITH_LIBRARY_KERNELS:
+            r.update(traffic=round(own, 1), traffic_scope="class", class_kernels_counted=names)
+        else:     # rocPRIM's scans / sorts serve several classes: the group's traffic against the group's compulsory bytes and time
+            g = next((g for g in groups if cls in g["classes"]), None)
+            if g:
+                r.update(traffic=g["traffic_bytes_per_step"], traffic_scope="group: " + g["group"], hbm_measured_frac=g["hbm_measured_frac"],
+                         traffic_over_compulsory=g["traffic_over_compulsory"])
+                if own is not None:
+                    r.update(class_own_kernels_traffic=round(own, 1), library_kernels_not_attributable=CLASSES_WITH_LIBRARY_KERNELS.get(cls))
+        if r["traffic_scope"] == "class":
+            r.update(hbm_measured_frac=round(own / sec / (HBM_PEAK_GBS * 1e9), 4), traffic_over_compulsory=round(own / comp, 3) if comp else None)
+        wave_insts, _ = class_own_counter(pmc, cls, "valu", share)
+        if wave_insts is not None:
+            r["valu_frac"] = round(wave_insts * 64.0 / sec / valu_peak, 4)
+            if v["units"]:
+                r["valu_insts_per_unit"] = round(wave_insts * 64.0 / (v["units"] / steps), 2)
+        r["frac"] = r["valu_frac"] if bound == "valu" else r["hbm_compulsory_frac"]
         return r
 
-    # dominant kernel: k_vote_map_cull (profile class "vote_map_cull"; falls back to the exact kernel if culling is disabled)
-    cls = "vote_map_cull" if prof.get("vote_map_cull", {}).get("launches") else "vote_map_exact"
-    vm = prof.get(cls, dict(ms=0.0, launches=0, units=0.0, bytes=0.0))
-    roofline = None
-    if vm["launches"]:
-        avg_s = vm["ms"] * 1e-3 / vm["launches"]
-        hbm_alg = vm["bytes"] / (vm["ms"] * 1e-3) / 1e9
-        pps = vm["units"] / (vm["ms"] * 1e-3)
-        vpp = pmc.get("valu_insts_per_point") if cls == "vote_map_cull" else None
-        traffic = pmc.get("hbm_bytes_per_launch") if cls == "vote_map_cull" else None
-        lane_insts = vpp * pps if vpp else None
-        roofline = {"bound": "valu", "kernel": "k_vote_map_cull" if cls == "vote_map_cull" else "k_map_rimg_blockmin",
-                    "achieved": round(lane_insts / 1e12, 3) if lane_insts else None, "peak": round(valu_peak / 1e12, 3), "unit": "T VALU lane-instructions/s",
-                    "frac": round(lane_insts / valu_peak, 4) if lane_insts else None,
-                    "frac_definition": "SQ_INSTS_VALU x 64 lanes per second of kernel time / (256 CU x 4 SIMD x 32 lanes x clock): the fraction of the nominal "
-                                       "VALU issue slots the kernel fills.  null when profiles/pmc_latest.json was not collected for exactly this kernel source",
-                    "frac_of_measured_valu_ceiling": round(lane_insts / (64.0 * VALU_MEASURED_CEILING_WAVE_INSTS), 4) if lane_insts else None,
-                    "traffic": traffic, "traffic_source": pmc.get("source"),
-                    "hbm_measured_frac": round(traffic / avg_s / (HBM_PEAK_GBS * 1e9), 4) if traffic else None,
-                    "hbm_algorithmic": {"achieved": round(hbm_alg, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm_alg / HBM_PEAK_GBS, 4),
-                                        "bytes_per_launch": round(vm["bytes"] / vm["launches"], 1),
-                                        "definition": "16 B x (points of the map tiles the launch reads: whole-tile-culled tiles excluded) + 8 B x R x C per keyframe image "
-                                                      "(SURVEY 8d: one map read per keyframe + range|index image)",
-                                        "note": "NOT a bound for this kernel and allowed to exceed 1: SURVEY 8d counts one read of the map per keyframe, the kernel fetches "
-                                                "a map tile once per eight keyframes (XCD-local L2 reuse) out of a map that fits the Infinity Cache -- "
-                                                "compare `traffic`"},
-                    "launches_per_step": vm["launches"] // max(args.steps, 1),
-                    "avg_launch_ms": round(vm["ms"] / vm["launches"], 4),
-                    "point_projections_per_s": round(pps, 1),
-                    "valu_insts_per_point": vpp,
-                    "valu_peak_lane_insts_per_s": valu_peak,
-                    "why_valu": "SQ counters (tools/pmc_sq.sh, profiles/) show the waves waiting to ISSUE, not on memory; measured HBM traffic is several times "
-                                "below the algorithmic bytes; the ceiling tools/ubench/valu_rate.hip sustains on this chip is ~0.9 of the nominal peak"}
     rooflines = [r for r in (class_roofline(k, v) for k, v in sorted(prof.items(), key=lambda kv: -kv[1]["ms"])) if r]
+    # the dominant kernel of THIS workload's step (configs[1]: k_vote_map_cull; the street's single-res step: k_map_rimg_blockmin; ...)
+    roofline = None
+    if rooflines:
+        d = rooflines[0]
+        v = prof[d["class"]]
+        avg_ms = v["ms"] / v["launches"]
+        per_launch = 1.0 / (v["launches"] / steps)
+        if d["bound"] == "valu":
+            lane = d["valu_frac"] * valu_peak if d["valu_frac"] is not None else None
+            ach, peak, unit = (round(lane / 1e12, 3) if lane else None), round(valu_peak / 1e12, 3), "T VALU lane-inst/s"
+        else:
+            ach, peak, unit = round(d["compulsory_bytes_per_step"] / (d["ms_per_step"] * 1e-3) / 1e9, 1), HBM_PEAK_GBS, "GB/s"
+        roofline = {"kernel": DOMINANT_KERNEL.get(d["class"], d["kernels"]), "class": d["class"], "bound": d["bound"], "achieved": ach, "peak": peak, "unit": unit, "frac": d["frac"],
+                    "traffic": round(d["traffic"] * per_launch, 1) if d["traffic"] is not None and d["traffic_scope"] == "class" else None,
+                    "avg_launch_ms": round(avg_ms, 4), "launches_per_step": round(v["launches"] / steps, 2),
+                    "share_of_step": round(d["ms_per_step"] / step_kernel_ms, 3) if step_kernel_ms else None,
+                    "valu_frac": d["valu_frac"], "hbm_algorithmic_frac": d["hbm_algorithmic_frac"], "hbm_compulsory_frac": d["hbm_compulsory_frac"],
+                    "hbm_measured_frac": d["hbm_measured_frac"], "traffic_over_compulsory": d["traffic_over_compulsory"],
+                    "algorithmic_bytes_per_launch": round(d["algorithmic_bytes_per_step"] * per_launch, 1),
+                    "compulsory_bytes_per_launch": round(d["compulsory_bytes_per_step"] * per_launch, 1),
+                    "pmc": bool(pmc.get("all_kernels")), "pmc_source": pmc.get("source"),
+                    "definitions": "DESIGN.md section 4: frac is the fraction of the bound named in `bound`; hbm_algorithmic_frac uses SURVEY 8d's bytes (one map read per keyframe) and may "
+                                   "exceed 1 for a projection kernel, which reads the map once per launch (hbm_compulsory_frac); traffic = PMC HBM bytes per launch"}
 
     cpu_baseline = None
-    if rank == 0 and world == 1 and not args.no_cpu_baseline and n_sessions == 2:
-        cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k, knn_thr, voxel)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        if args.workload == DEFAULT_WORKLOAD or args.cpu_baseline_now:
+            if n_sessions == 2:
+                cpu_baseline = run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k, knn_thr, voxel)
+        else:
+            cpu_baseline = quoted_cpu_baseline(args.workload)
     t_total = None
     if rank == 0 and world == 1 and not args.no_t_total and args.workload == DEFAULT_WORKLOAD:
         t_total = run_t_total(sess_t, n_kf)
@@ -334,7 +348,7 @@ def main():
     if rank == 0:
         M_c = len(last.outputs["OriginalNoisyCentralMapGlobal"])
         M_q = len(last.outputs["OriginalNoisyQueryMapGlobal"])
-        out = {
+        full = {
             "metric": "keyframe-pairs/sec (removert+diff)", "value": round(value, 3), "unit": "keyframe-pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
             # the same region -- makeGlobalMap + Steps 1-3, loaded sessions resident, no output files, warm -- timed by the C++ host itself
@@ -345,13 +359,13 @@ def main():
             "cxx_host_one_shot_steps123_ms": (round(1e3 * t_total["configs[1] 2x500 3-res"]["T_steps123_s"], 1)
                                               if t_total and isinstance(t_total.get("configs[1] 2x500 3-res"), dict) and t_total["configs[1] 2x500 3-res"].get("T_steps123_s") else None),
             "higher_is_better": True, "scaling": "strong" if world > 1 else "weak", "vs_baseline": None,
-            "dtype": "f32 (+f64 rigid transforms, u64 range|index atomics)", "data": "synthetic (tools/synth.py synth-v1, seed 20250224)",
+            "dtype": "f32", "dtype_detail": "f32 (+f64 rigid transforms, u64 range|index atomics)", "data": "synthetic (tools/synth.py synth-v1, seed 20250224)",
             "config": {"workload": args.workload, "sessions": f"{scene} 01 vs 02" if n_sessions == 2 else f"{scene} cascade 01 -> 02..{n_sessions:02d} ({n_sessions - 1} chained pair runs)",
                        "keyframes_per_session": n_kf, "keyframe_pairs_per_step": pairs_per_step, "sensor": sensor,
                        "remove_resolution_list": P.remove_resolution_list if three_res else [2.5], "self_removert": three_res,
                        "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points_last_pair": [M_c, M_q],
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
-                       "parallelism": (f"keyframe-sharded x{world} (label all-reduce, key-range all-to-all for the merges" + (", one rank group per session in Step 1" if world % 2 == 0 and os.environ.get("LTM_SESSION_GROUPS", "1") != "0" else "") + ")") if world > 1 else
+                       "parallelism": (f"keyframe-sharded x{world} (label all-reduce, key-range all-to-all for the merges" + (", one rank group per session in Step 1" if dist_session_groups(world) else "") + ")") if world > 1 else
                                       ("single GPU, the two sessions' merge + Step-1 chains side by side on two contexts (--overlap-sessions experiment)" if args.overlap_sessions else "single GPU"),
                        "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
@@ -370,9 +384,76 @@ def main():
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
             "synth_generation_s": round(t_gen, 2),
         }
-        print(json.dumps(out))
+        extra_path = write_extra(full, args)
+        print(json.dumps(slim_line(full, extra_path)))
+        sys.stdout.flush()
     if dist is not None:
         dist.destroy_process_group()
+
+
+def dist_session_groups(world):
+    """does the torch.distributed host split an even world into two session groups?  (dist.ShardedOps._session_groups_on: opt-in over RCCL)"""
+    e = os.environ.get("LTM_SESSION_GROUPS")
+    return world >= 2 and world % 2 == 0 and e is not None and e not in ("0", "False")
+
+
+EXTRA_DEFAULT = os.path.join("profiles", "bench_extra_latest.json")
+
+
+def write_extra(full, args):
+    """everything the printed line does not carry (per-class rooflines, traffic groups, t_total, scaling model, stage times, prose) goes to a sidecar
+    file: the driver keeps the last ~8 KB of stdout and could not parse round 4's 21 KB line"""
+    path = args.extra_out or os.path.join(ROOT, EXTRA_DEFAULT)
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        with open(path, "w") as f:
+            json.dump(full, f, indent=1)
+        return os.path.relpath(path, ROOT)
+    except Exception as e:
+        print(f"bench.py: sidecar {path} not written: {e!r}", file=sys.stderr)
+        return None
+
+
+def _num(d, *keys):
+    return {k: d.get(k) for k in keys if k in d} if isinstance(d, dict) else None
+
+
+def slim_line(full, extra_path):
+    """the ONE printed JSON line: contract fields, the dominant kernel's roofline (numbers only), the CPU baseline (numbers + one short sentence),
+    a per-class table of numbers, and the path of the sidecar.  Stays well below 6000 bytes (tests/test_bench_line.py)"""
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "cxx_host_ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    out = {k: full.get(k) for k in keep}
+    cfg = full.get("config") or {}
+    out["config"] = {k: cfg.get(k) for k in ("workload", "keyframes_per_session", "keyframe_pairs_per_step", "sensor", "remove_resolution_list", "knn", "voxel",
+                                             "map_points_last_pair", "parallelism") if k in cfg}
+    if isinstance(out["config"].get("parallelism"), str):
+        out["config"]["parallelism"] = out["config"]["parallelism"][:120]
+    out["roofline"] = _num(full.get("roofline"), "kernel", "class", "bound", "achieved", "peak", "unit", "frac", "traffic", "avg_launch_ms", "launches_per_step",
+                           "share_of_step", "valu_frac", "hbm_algorithmic_frac", "hbm_compulsory_frac", "hbm_measured_frac", "traffic_over_compulsory", "pmc")
+    cb = full.get("cpu_baseline")
+    if isinstance(cb, dict):
+        o = _num(cb, "value", "unit", "cores", "kind", "measured_s", "keyframe_stride", "extrapolated_step_s", "host_cores", "cgroup_cpu_quota_cpus")
+        o["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:200]
+        ac = cb.get("all_cores")
+        if isinstance(ac, dict):
+            o["all_cores"] = _num(ac, "value", "cores", "cgroup_cpu_quota_cpus", "measured_s")
+        rc = cb.get("reference_compiled")
+        if isinstance(rc, dict) and "port_speedup_over_reference_compiled" in rc:
+            o["port_speedup_over_reference_compiled"] = rc["port_speedup_over_reference_compiled"]
+        out["cpu_baseline"] = o
+    else:
+        out["cpu_baseline"] = None
+    # per kernel class: ms per step, bound, fraction of that bound, measured traffic / compulsory bytes
+    out["classes"] = [{"c": r.get("class"), "ms": r.get("ms_per_step"), "b": r.get("bound"), "frac": r.get("frac"), "hbm_c": r.get("hbm_compulsory_frac"),
+                       "t_over_c": r.get("traffic_over_compulsory")} for r in (full.get("rooflines") or [])[:16]]
+    tt = full.get("t_total")
+    if isinstance(tt, dict) and isinstance(tt.get("configs[1] 2x500 3-res"), dict):
+        out["t_total_s"] = _num(tt["configs[1] 2x500 3-res"], "T_total_s", "T_step0_s", "T_steps123_s")
+    pf = full.get("parity_fullsize")
+    if isinstance(pf, dict):
+        out["parity_fullsize_matches_sources"] = pf.get("matches_sources")
+    out["extra"] = extra_path
+    return out
 
 
 def kernels_sha():
@@ -397,6 +478,9 @@ TRAFFIC_GROUPS = [
 # rocPRIM's scans / sorts serve several classes and cannot be told apart by caller: classes that contain them also report the group figure
 CLASS_OWN_KERNELS = {
     "vote_map_cull": ["k_vote_map_cull"],
+    # one kernel, two classes (ND votes and reprojections): its counters are split between them by their share of its event time (SHARED_KERNEL_CLASSES)
+    "vote_map_exact": ["k_map_rimg_blockmin", "k_map_rimg_lds", "k_pair_shell_select", "k_coarse_max"],
+    "reproject_map": ["k_map_rimg_blockmin", "k_map_rimg_lds", "k_pair_shell_select", "k_coarse_max"],
     "vote_scan": ["k_scan_rimg", "k_image_max", "k_scan_qbound", "k_image_bounds"],
     "vote_compare": ["k_compare_flag"],
     "partition": ["k_partition_scatter"],
@@ -409,13 +493,15 @@ CLASS_OWN_KERNELS = {
     "knn_query": ["k_knn_fast", "k_knn_query_cloud", "k_knn_query_scans"],
     "knn_query_p2": ["k_knn_slow", "k_knn_queue_scatter"],
 }
+SHARED_KERNEL_CLASSES = ("vote_map_exact", "reproject_map")
 # (vote_fill is not listed: k_fill_u64 / k_fill_u32 also initialise images, tables and flags of other stages, so their counters are not the class's own)
 CLASSES_WITH_LIBRARY_KERNELS = {"partition": "rocprim scan", "reproject_gather": "rocprim scan", "voxel": "rocprim radix sort", "voxel_scanset": "rocprim radix sort + scan",
                                 "voxel_grid_scanset": "rocprim radix sort + scan", "knn_build": "rocprim radix sort", "knn_query_p2": "rocprim scan"}
 
 
-def class_own_traffic(pmc, cls):
-    """measured HBM bytes per step of the kernels that belong to `cls` alone (None without counter data for these sources)"""
+def class_own_counter(pmc, cls, what, share=1.0):
+    """per step, over the kernels that belong to `cls` alone: what = "traffic" -> measured HBM bytes ((2 FETCH_SIZE + WRITE_SIZE) KiB, MI355X_MICROARCH.md),
+    what = "valu" -> SQ_INSTS_VALU wave-instructions.  (None, []) without counter data collected for these sources and this workload"""
     allk = pmc.get("all_kernels")
     subs = CLASS_OWN_KERNELS.get(cls)
     if not allk or not subs:
@@ -423,9 +509,14 @@ def class_own_traffic(pmc, cls):
     mine = [k for k in allk if any(sub in k or sub in k + "(" for sub in subs)]
     if not mine:
         return None, []
+    names = sorted(k.split("::")[-1] for k in mine)
+    if what == "valu":
+        if not all("SQ_INSTS_VALU" in allk[k] for k in mine):
+            return None, names
+        return share * sum(allk[k]["SQ_INSTS_VALU"].get("sum", 0.0) for k in mine), names
     fetch = sum(allk[k].get("FETCH_SIZE", {}).get("sum", 0.0) for k in mine)
     write = sum(allk[k].get("WRITE_SIZE", {}).get("sum", 0.0) for k in mine)
-    return (2.0 * fetch + write) * 1024.0, sorted(k.split("::")[-1] for k in mine)
+    return share * (2.0 * fetch + write) * 1024.0, names
 
 
 def traffic_groups(pmc, prof, steps):
@@ -442,9 +533,11 @@ def traffic_groups(pmc, prof, steps):
             left.pop(k)
         traffic = (2.0 * fetch + write) * 1024.0       # per step: the counter passes run --steps 1 --warmup 0
         alg = sum(prof[c]["bytes"] for c in classes if c in prof) / max(steps, 1)
+        comp = sum(prof[c].get("bytes_c", prof[c]["bytes"]) for c in classes if c in prof) / max(steps, 1)
         ms = sum(prof[c]["ms"] for c in classes if c in prof) / max(steps, 1)
         out.append({"group": name, "classes": classes, "kernels_matched": len(mine), "traffic_bytes_per_step": round(traffic, 1),
                     "algorithmic_bytes_per_step": round(alg, 1), "traffic_over_algorithmic": round(traffic / alg, 3) if alg else None,
+                    "compulsory_bytes_per_step": round(comp, 1), "traffic_over_compulsory": round(traffic / comp, 3) if comp else None,
                     "ms_per_step": round(ms, 3), "hbm_measured_frac": round(traffic / (ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4) if ms else None})
     return out
 
@@ -508,20 +601,38 @@ def run_t_total(sess_t, n_kf):
 
 
 def load_pmc(workload):
-    """PMC figures of the dominant kernel (rocprofv3 cannot run inside this process): profiles/pmc_latest.json is regenerated by
-    tools/collect_profiles.sh, which stamps it with the commit and a hash of the kernel sources; it is used only if that hash
-    equals the sources this run was built from and the workload matches -- otherwise traffic / VALU counts are null, never stale."""
-    path = os.path.join(ROOT, "profiles", "pmc_latest.json")
+    """PMC counters per kernel of one step of `workload` (rocprofv3 cannot run inside this process): profiles/pmc_<workload>.json (the default
+    workload's also as profiles/pmc_latest.json) are written by tools/collect_profiles.sh, stamped with the commit and a hash of the kernel sources;
+    a file is used only if that hash equals the sources this run was built from and the workload matches -- otherwise traffic / VALU
+    fractions are null, never stale."""
+    tried = []
+    for name in (f"pmc_{workload}.json", "pmc_latest.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            d = json.load(open(path))
+        except Exception:
+            continue
+        if d.get("workload") != workload or d.get("kernels_sha") != kernels_sha():
+            tried.append(f"profiles/{name}: {d.get('workload')} / {d.get('kernels_sha')}")
+            continue
+        return {"all_kernels": d.get("all_kernels"),
+                "source": f"profiles/{name} (commit {d.get('commit')}, kernel sources {d.get('kernels_sha')}): separate rocprofv3 --pmc passes of one step; "
+                          "(2*FETCH_SIZE + WRITE_SIZE)*1024 bytes, SQ_INSTS_VALU*64 lane-instructions"}
+    return {"source": f"no counter file for workload {workload} / kernel sources {kernels_sha()} (ignored: {'; '.join(tried) or 'none found'})"}
+
+
+def quoted_cpu_baseline(workload):
+    """configs[2..4]: the sampled single-thread CPU leg of SURVEY 8d costs minutes to an hour of host time on these sizes, which the GPU box's budget cannot
+    carry: tools/cpu_baseline_sampled.py runs it (the same oracle, the same generator and seed, a stated keyframe sample) on a host without GPU and commits
+    profiles/cpu_baseline_<workload>.json; the line quotes it together with the host it was measured on"""
+    from tools import provenance
+    path = os.path.join(ROOT, "profiles", f"cpu_baseline_{workload}.json")
     try:
         d = json.load(open(path))
     except Exception:
-        return {}
-    if d.get("workload") != workload or d.get("kernels_sha") != kernels_sha():
-        return {"source": f"profiles/pmc_latest.json ignored: collected for workload {d.get('workload')} / kernel sources {d.get('kernels_sha')}, "
-                          f"this run is {workload} / {kernels_sha()}"}
-    return {"hbm_bytes_per_launch": d.get("hbm_bytes_per_launch"), "valu_insts_per_point": d.get("valu_insts_per_point"), "all_kernels": d.get("all_kernels"),
-            "source": f"profiles/pmc_latest.json (commit {d.get('commit')}, kernel sources {d.get('kernels_sha')}): separate rocprofv3 --pmc passes, "
-                      "(2*FETCH_SIZE + WRITE_SIZE)*1024 / launches; SQ_INSTS_VALU*64 / point-projections"}
+        return None
+    d = dict(d, quoted_from=f"profiles/cpu_baseline_{workload}.json", same_oracle_sources=d.get("oracle_sha") == provenance.oracle_sha())
+    return d
 
 
 def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel=0.05):
@@ -637,7 +748,9 @@ def run_cpu_baseline(sess_t, three_res, n_kf, args, knn_k=2, knn_thr=0.01, voxel
                        "labels_identical": bool((lab_r == lab_o).all())}
     except Exception as e:          # the checker's checker must never break the bench line
         ref_cmp = {"kind": "reference", "error": repr(e)[:200]}
-    out = {"value": one["value"], "unit": "keyframe-pairs/s", "cores": 1, "kind": "port", "reference_compiled": ref_cmp,
+    out = {"value": one["value"], "unit": "keyframe-pairs/s", "cores": 1, "kind": "port", "reference_compiled": ref_cmp, "keyframe_stride": one["keyframe_stride"],
+           "sample_short": f"CPU oracle (port), 1 thread, full-size sessions, every {one['keyframe_stride']}th keyframe ({one['keyframes_visited_per_session']} of {n_kf}) in per-keyframe "
+                           f"loops scaled up, whole-map stages in full",
            "sample": f"oracle/libltm_oracle.so (sort-based voxel grid + kd-tree: faster than the PCL-based reference), full-size sessions, every "
                      f"{one['keyframe_stride']}th keyframe ({one['keyframes_visited_per_session']} of {n_kf} per session) in the per-keyframe loops (votes, "
                      f"reprojections, kNN queries) scaled x{n_kf / one['keyframes_visited_per_session']:.1f}; voxel grids and kd-tree builds timed in full; "

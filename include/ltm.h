@@ -307,6 +307,10 @@ int ltm_profile_reset(ltm_ctx*);
 /* returns number of classes; fills up to cap entries.  units = class-specific work count
  * (point-projections for vote_map), bytes = algorithmic bytes, ms = sum of event durations */
 int ltm_profile_read(ltm_ctx*, const char** names, double* ms, uint64_t* launches, double* units, double* bytes, int cap);
+/* same class order as ltm_profile_read: the COMPULSORY bytes of each class's launches as this library issues them -- a projection
+ * launch (map2RangeImg for a batch of keyframes, utility.cpp:92-142 under the loops Removerter.cpp:555 / Session.cpp:354) reads its map
+ * once for the whole batch, where SURVEY.md 8d's figure counts one map read per keyframe; equal to `bytes` for every other class */
+int ltm_profile_read_compulsory(ltm_ctx*, double* bytes_c, int cap);
 
 #ifdef __cplusplus
 }

@@ -113,6 +113,7 @@ SIGNATURES = {
     "ltm_rimg_size": (None, [_f, _f, _f, C.POINTER(_i), C.POINTER(_i)]),
     "ltm_profile_enable": (_i, [_vp, _i]),
     "ltm_profile_reset": (_i, [_vp]),
+    "ltm_profile_read_compulsory": (_i, [_vp, C.POINTER(C.c_double), _i]),
     "ltm_profile_read": (_i, [_vp, C.POINTER(C.c_char_p), C.POINTER(C.c_double), _pu64, C.POINTER(C.c_double),
                               C.POINTER(C.c_double), _i]),
 }
@@ -467,7 +468,9 @@ class Context:
         n = self.lib.ltm_profile_read(self.h, names, ms, launches, units, nbytes, cap)
         if n < 0:
             self._ck(n)
-        return {names[i].decode(): dict(ms=ms[i], launches=int(launches[i]), units=units[i], bytes=nbytes[i]) for i in range(min(n, cap))}
+        nb_c = (C.c_double * cap)()
+        self._ck(min(self.lib.ltm_profile_read_compulsory(self.h, nb_c, cap), 0))
+        return {names[i].decode(): dict(ms=ms[i], launches=int(launches[i]), units=units[i], bytes=nbytes[i], bytes_c=nb_c[i]) for i in range(min(n, cap))}
 
 
 class _Handle:

@@ -120,14 +120,16 @@ struct Cloud {
 struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> off; uint64_t* off_dev = nullptr; size_t nkf() const { return off.size() - 1; } };
 struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; float* approx_dev = nullptr; };
 
-struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0; };
+// bytes = SURVEY 8(d)'s algorithmic bytes (one map read per keyframe); bytes_c = the compulsory bytes of the launch as this design issues it (a projection
+// launch reads its map ONCE for all the keyframes of the batch): equal to `bytes` for every class but the projection kernels
+struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes = 0, bytes_c = 0; };
 // scan2RangeImg depends only on (scan set, image shape, keyframe range): the remove / revert / remove passes of one
 // resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
 struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; float* qbound; float q_thr; };
 struct Pending { int cls; hipEvent_t a, b; };
 // a vote launch whose algorithmic bytes depend on the number of (tile, keyframe) workgroups that survive the whole-tile cull:
 // counted on the device into slot `slot` of ctx->live_counts, folded into the class totals when the profile is collected
-struct PendingLive { int cls; int slot; double max_pts; double image_bytes; };
+struct PendingLive { int cls; int slot; double max_pts; double image_bytes; double map_pts; double image_bytes_c; };
 struct PinnedBlock { void* p; size_t bytes; bool in_use; };
 // pipelined scan-set upload: device array of `cap` points filled front to back, two pinned staging buffers in flight
 struct UploadState { float4* d = nullptr; size_t cap = 0, n = 0; std::vector<uint64_t> off{0}; void* stage[2] = {nullptr, nullptr}; size_t stage_sz[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int next = 0; };
@@ -245,11 +247,11 @@ hipEvent_t get_event(ltm_ctx* c)
 }
 struct ProfScope {   // HIP-event bracket around one kernel class on the context's stream
     ltm_ctx* c; int cls = -1; hipEvent_t a = nullptr;
-    ProfScope(ltm_ctx* c_, const char* name, double units, double bytes) : c(c_)
+    ProfScope(ltm_ctx* c_, const char* name, double units, double bytes, double bytes_c = -1.0) : c(c_)
     {
         if (!c->prof_on) return;
         cls = prof_class(c, name);
-        c->prof[cls].launches++; c->prof[cls].units += units; c->prof[cls].bytes += bytes;
+        c->prof[cls].launches++; c->prof[cls].units += units; c->prof[cls].bytes += bytes; c->prof[cls].bytes_c += bytes_c < 0.0 ? bytes : bytes_c;
         a = get_event(c);
         LTM_HIP(hipEventRecord(a, c->stream));
     }
@@ -274,6 +276,7 @@ void prof_collect(ltm_ctx* c)
             const double pts = std::min(p.max_pts, (double)live[(size_t)p.slot] * 4096.0);
             c->prof[p.cls].units += pts;
             c->prof[p.cls].bytes += 16.0 * pts + p.image_bytes;
+            c->prof[p.cls].bytes_c += 16.0 * std::min(pts, p.map_pts) + p.image_bytes_c;      // the map tiles at most once per launch
         }
         c->pending_live.clear();
     }
@@ -767,17 +770,18 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
             // class name = kernel: k_vote_map_cull for mode 0 (when enabled), k_map_rimg_blockmin otherwise
             // algorithmic bytes = map tiles read + images written.  Tiles that the whole-tile range cull drops are never read, so
             // (measurement only, when profiling is on) they are counted by the same predicate and left out.
-            double pts = (double)map.n * nb, bytes = 16.0 * pts + (double)nb * 8.0 * npx;
+            // compulsory bytes of the launch as designed: the map once, per keyframe the range|index image written (8 B) and, culled form, the bound image read (4 B)
+            double pts = (double)map.n * nb, bytes = 16.0 * pts + (double)nb * 8.0 * npx, bytes_c = 16.0 * map.n + (double)nb * (cull ? 12.0 : 8.0) * npx;
             const bool count_live = cull && c->prof_on && tile_cull_enabled() && smax && c->pending_live.size() < (size_t)kLiveSlots;
             if (count_live) {      // no host round trip here: the count is read when the profile is collected
                 if (!c->live_counts) LTM_HIP(hipMalloc(reinterpret_cast<void**>(&c->live_counts), sizeof(unsigned long long) * kLiveSlots));
                 const int slot = (int)c->pending_live.size();
                 LTM_HIP(hipMemsetAsync(c->live_counts + slot, 0, sizeof(unsigned long long), c->stream));
                 LTM_HIP(count_live_tiles(ps.approx_dev, kb, nb, tb.as<float>(), n_tiles, smax, thr, c->live_counts + slot, c->stream));
-                c->pending_live.push_back(PendingLive{prof_class(c, "vote_map_cull"), slot, pts, (double)nb * 8.0 * npx});
-                pts = 0.0; bytes = 0.0;      // added by prof_collect
+                c->pending_live.push_back(PendingLive{prof_class(c, "vote_map_cull"), slot, pts, (double)nb * 8.0 * npx, (double)map.n, (double)nb * 12.0 * npx});
+                pts = 0.0; bytes = 0.0; bytes_c = 0.0;      // added by prof_collect
             }
-            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, bytes);
+            ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, bytes, bytes_c);
             if (cull) {
                 LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, qbound, tb.as<float>(), smax, thr, mode,
                                               map_img.as<uint64_t>(), c->stream));
@@ -2464,7 +2468,7 @@ int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, siz
                 const size_t nb = std::min(KB, kf_end - kb);
                 LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, nb * npx, c->stream));
                 {
-                    ProfScope ps(c, "reproject_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx));
+                    ProfScope ps(c, "reproject_map", (double)map.n * nb, (double)nb * (16.0 * map.n + 8.0 * npx), 16.0 * map.n + (double)nb * 8.0 * npx);
                     exact_map_images(c, map, p, kb, nb, g, img.as<uint64_t>());
                 }
                 ProfScope ps(c, "reproject_gather", (double)(nb * npx), (double)(nb * npx) * 12);
@@ -2528,6 +2532,10 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
                                                     pos.as<uint32_t>(), q1.as<uint64_t>(), count.as<uint32_t>(), temp.p, tb, c->stream));
                 uint32_t und = 0;
                 d2h(c, &und, count.p, 4);
+                if (c->prof_on) {      // the exact search's own floor: every undecided query is read again and must see its k neighbours (SURVEY 8d's per-query bytes)
+                    ProfClass& pc = c->prof[(size_t)prof_class(c, "knn_query_p2")];
+                    pc.units += (double)und; pc.bytes += (double)und * (16.0 + 16.0 * k + 1.0); pc.bytes_c += (double)und * (16.0 + 16.0 * k + 1.0);
+                }
                 if (und) {
                     DevBuf q2(c, (size_t)und * 8);
                     LTM_HIP(knn_two_phase_exact_sorted(s.d, s.off_dev, kf_begin, kf_end, first, p.pose_dev, c->B2L, c->b2l_identity, index.sorted, index.Mt, index.g, index.table,
@@ -2800,6 +2808,15 @@ int ltm_profile_read(ltm_ctx* c, const char** names, double* ms, uint64_t* launc
         if (units) units[i] = c->prof[i].units;
         if (bytes) bytes[i] = c->prof[i].bytes;
     }
+    return n;
+}
+int ltm_profile_read_compulsory(ltm_ctx* c, double* bytes_c, int cap)
+{
+    if (!c) return LTM_E_INVALID;
+    const int rc = guarded(c, [&] { prof_collect(c); });
+    if (rc != LTM_OK) return rc;
+    const int n = (int)c->prof.size();
+    for (int i = 0; i < n && i < cap; ++i) if (bytes_c) bytes_c[i] = c->prof[i].bytes_c;
     return n;
 }
 

@@ -61,7 +61,17 @@ class ShardedOps:
     # runs one after the other): with an even world the even ranks take the central session and the odd ranks the query session, each group
     # sharding ITS session's keyframes world/2 ways.  A rank then does the replicated part (partitions, re-grids, host round trips) of one
     # session instead of two and its label all-reduces span half the ranks; the price is one swap of the finished maps between rank pairs.
-    SESSION_GROUPS = os.environ.get("LTM_SESSION_GROUPS", "1") != "0"      # the switch the C++ host reads as well (Comm.cpp)
+    # LTM_SESSION_GROUPS (the switch the C++ host reads as well, Comm.cpp): "0" off, "1" on; unset = on for every backend that has run it under test
+    # (gloo worlds 2/4/6, logical ranks) and OFF over RCCL ("nccl"), whose group + pair-swap path no multi-GPU hardware has executed yet
+    SESSION_GROUPS = os.environ.get("LTM_SESSION_GROUPS")
+
+    def _session_groups_on(self):
+        if self.SESSION_GROUPS is not None:
+            return str(self.SESSION_GROUPS) not in ("0", "False")
+        try:
+            return self.dist.get_backend() != "nccl"
+        except Exception:
+            return True
 
     def __init__(self, ops, dist, rank, world, group=None, peer=None):
         self.ops, self.dist, self.rank, self.world, self.group = ops, dist, rank, world, group
@@ -71,7 +81,7 @@ class ShardedOps:
 
     def session_groups(self):
         """(ops bound to this rank's session group, 0 = central / 1 = query) or None when the world does not split"""
-        if not self.SESSION_GROUPS or self.group is not None or self.world < 2 or self.world % 2:
+        if self.group is not None or self.world < 2 or self.world % 2 or not self._session_groups_on():
             return None
         if self._session_groups is None:     # every rank creates both groups, in the same order (torch.distributed.new_group is collective)
             pgs = [self.dist.new_group(ranks=list(range(g, self.world, 2))) for g in (0, 1)]

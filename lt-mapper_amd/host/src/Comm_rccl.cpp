@@ -1,5 +1,6 @@
 // Comm_rccl.cpp -- RcclComm: one rank per GPU of the node, collectives over xGMI (see Comm.h).  The only host file that talks to
 // HIP / RCCL directly; everything else goes through the C ABI.
+#include <cstdlib>
 #include "removert/Comm.h"
 
 #include <hip/hip_runtime_api.h>
@@ -180,7 +181,10 @@ std::vector<std::shared_ptr<Comm>> makeRcclComms(const std::vector<int>& devs)
     LTM_NCCL(ncclCommInitAll(g->comms.data(), (int)devs.size(), devs.data()));
     std::vector<std::shared_ptr<RcclComm>> ends;
     for (size_t r = 0; r < devs.size(); ++r) ends.push_back(std::make_shared<RcclComm>(g, (int)r));
-    if (sessionGroupsEnabled((int)devs.size())) {
+    // over RCCL the split is opt-in (LTM_SESSION_GROUPS=1): the two extra communicators and the pair swap have run under LocalComm and gloo only --
+    // no multi-GPU hardware has executed them yet; tests/test_gpu_multi.py runs both settings where two devices exist
+    const char* sg_env = std::getenv("LTM_SESSION_GROUPS");
+    if (sg_env && std::string(sg_env) == "1" && sessionGroupsEnabled((int)devs.size())) {
         for (size_t color = 0; color < 2; ++color) {      // a communicator of their own for the even and for the odd ranks
             auto sg = std::make_shared<RcclGroup>();
             for (size_t r = color; r < devs.size(); r += 2) sg->devs.push_back(devs[r]);
