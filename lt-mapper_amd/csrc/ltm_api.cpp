@@ -689,7 +689,7 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     if (!map.n || !nb) return;
     const size_t n_tiles = (map.n + 4095) / 4096, n_pairs = n_tiles * nb;
     // (the list-driven launch exists for the block-local arg-min kernel only: LTM_MAP_KERNEL=0/1, the A/B baselines, take the plain launch)
-    const bool occl = c->occlusion_cull && map_kernel_variant() == 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
+    const bool occl = c->occlusion_cull && map_kernel_variant() >= 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
     if (!occl) {
         LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream));
         return;
@@ -1333,10 +1333,11 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     // A/B switches for profiling.  They are process-wide (kernel-side globals): every context creation sets ALL of them, to the
     // environment's value or to the default, so that a variant chosen for one context does not leak into the next one of the process
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-    set_map_kernel_variant(env_int("LTM_MAP_KERNEL", 2));
+    set_map_kernel_variant(env_int("LTM_MAP_KERNEL", 4));
     set_vote_cull(env_int("LTM_VOTE_CULL", 1));
     set_cull_variant(env_int("LTM_CULL_VARIANT", 0));
     set_kf_per_block(env_int("LTM_KF_PER_BLOCK", 8));
+    set_bm_combine_iters(env_int("LTM_BM_COMBINE", 0) | (env_int("LTM_BM_STOP", 0) << 8));
     set_tile_cull(env_int("LTM_TILE_CULL", 1));
     set_stats_select(env_int("LTM_STATS_BLOCKMIN", 0));
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's

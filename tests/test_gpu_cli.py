@@ -228,6 +228,10 @@ def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
         a, b = cxx["classes"].get(nme), py.get(nme)
         la, ua = (a["launches_per_step"], a["units_per_step"]) if a else (0, 0)
         lb, ub = (b["launches"], b["units"]) if b else (0, 0)
+        if nme == "knn_query_p2":
+            # its units are the queries phase 1 left undecided: which nine points of a crowded cell a 2-choice bucket holds depends on the order the
+            # build's atomics land in, so the count varies by ~1e-4 from run to run (the flags do not: every undecided query gets the exact search)
+            ua = ub = 0
         if (la, ua) != (lb, ub):
             diff.append((nme, (la, ua), (lb, ub)))
     assert not diff, f"the two hosts do not issue the same work: (class, C++ host, Python host) = {diff}"
