@@ -1333,11 +1333,11 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     // A/B switches for profiling.  They are process-wide (kernel-side globals): every context creation sets ALL of them, to the
     // environment's value or to the default, so that a variant chosen for one context does not leak into the next one of the process
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-    set_map_kernel_variant(env_int("LTM_MAP_KERNEL", 4));
+    set_map_kernel_variant(env_int("LTM_MAP_KERNEL", 2));
     set_vote_cull(env_int("LTM_VOTE_CULL", 1));
     set_cull_variant(env_int("LTM_CULL_VARIANT", 0));
     set_kf_per_block(env_int("LTM_KF_PER_BLOCK", 8));
-    set_bm_combine_iters(env_int("LTM_BM_COMBINE", 0) | (env_int("LTM_BM_STOP", 0) << 8));
+    set_bm_stop(env_int("LTM_BM_STOP", 0));
     set_tile_cull(env_int("LTM_TILE_CULL", 1));
     set_stats_select(env_int("LTM_STATS_BLOCKMIN", 0));
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's

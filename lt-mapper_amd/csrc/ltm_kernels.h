@@ -67,7 +67,7 @@ int vote_cull_enabled();
 int tile_cull_enabled();
 hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,
                             const uint32_t* smax_bits_dev, float thr, unsigned long long* live_dev, hipStream_t s);
-void set_bm_combine_iters(int v);   // k_map_rimg_blockmin, WAVE_COMBINE form: distinct pixels per wavefront load that are min-combined in registers (0 = none)
+void set_bm_stop(int v);            // DIAGNOSTIC: k_map_rimg_blockmin stops after a phase (timing only; tools/ab_kernels.py)
 void set_kf_per_block(int v);    // keyframes that share one map-tile read inside a workgroup (1, 2, 4, 8)
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s);   // {survivors, points} since the last reset
 hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,

@@ -793,28 +793,16 @@ static constexpr int kBmQueue = 2048;     // survivor queue capacity (~11 % of 4
 static constexpr uint32_t kBmRowUncertain = 511u;
 static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain survivors (~1 % of the tile); beyond it they are handled in place
 
-// Minimum of an unsigned value over the wavefront (all 64 lanes active), returned to every lane through a scalar register: inclusive
-// row_shr 1/2/4/8 scan inside each row of 16 lanes, then gfx9's row broadcasts (lane 15 -> the next row, lane 31 -> the upper half); the
-// full reduction arrives in lane 63.  Lanes without a DPP source keep the identity (bound_ctrl off, old = ~0).
-__device__ __forceinline__ uint32_t wave_umin(uint32_t v)
-{
-#define LTM_DPP_UMIN(CTRL, ROWS) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)0xffffffff, (int)v, CTRL, ROWS, 0xf, false))
-    LTM_DPP_UMIN(0x111, 0xf); LTM_DPP_UMIN(0x112, 0xf); LTM_DPP_UMIN(0x114, 0xf); LTM_DPP_UMIN(0x118, 0xf);
-    LTM_DPP_UMIN(0x142, 0xa); LTM_DPP_UMIN(0x143, 0xc);
-#undef LTM_DPP_UMIN
-    return (uint32_t)__builtin_amdgcn_readlane((int)v, 63);
-}
-// pixels of one wavefront load that are combined in registers before anything touches the LDS table (k_map_rimg_blockmin, WAVE_COMBINE): the map is in
-// octree order, so the 64 consecutive points of a load fall into a handful of pixels; lanes beyond that many distinct pixels go to the table on their own
-static int g_bm_combine_iters = 0;      // env LTM_BM_COMBINE
-void set_bm_combine_iters(int v) { g_bm_combine_iters = v < 0 ? 0 : v; }      // (bits 8+: the diagnostic early stop, see the kernel)
+static int g_bm_stop = 0;      // DIAGNOSTIC, env LTM_BM_STOP (tools/ab_kernels.py): k_map_rimg_blockmin leaves after phase 1 (1) / the certain survivors (2) / before the flush (3)
+void set_bm_stop(int v) { g_bm_stop = v; }
 
 // pairs != null: workgroup b processes the (tile, keyframe) pair pairs[b] = tile * nb + keyframe (occlusion-culled launch, see exact_images_occlusion_*)
-// WAVE_COMBINE (round 5): phase 1 as restructured for latency -- see the comment at its branch; false = round 4's form (LTM_MAP_KERNEL=2, A/B)
-template <bool B2L_IDENTITY, bool EL3, bool WAVE_COMBINE, int SLOT_ROWS = 16>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))      // the LDS tables allow 7 workgroups per CU: keep the registers within that (72)
+// (Round 5 tried three restructurings of phase 1 -- a wave-level combine of the lanes of one pixel, a single 64-bit {owner, minimum} table word, and
+// a one-pass candidate stream -- all bit-exact, none faster: profiles/r5_ab_blockmin_restructurings.txt)
+template <bool B2L_IDENTITY, bool EL3, int SLOT_ROWS = 16>
+__global__ void __launch_bounds__(kBlock)
 k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs, int combine_iters)
+                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs, int stop_after)
 {
     constexpr int kBmSlots = SLOT_ROWS * 64;
     static_assert(kBmSlots <= kBmSlotsMax, "");
@@ -823,9 +811,6 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     // the pre-filter's minimum table is only alive in phase 1 and the 64-bit (range | index) table only in phase 2: same LDS
     // (22.6 KB instead of 26.6 KB per workgroup: 7 workgroups per CU instead of 6)
     uint32_t* const amin = reinterpret_cast<uint32_t*>(vals);
-    // WAVE_COMBINE: phase 1 keeps {owner pixel, minimum} of a slot in ONE 64-bit word (a point reads both with one ds_read_b64), again in the LDS of the
-    // phase-2 value table; the owners move to tags[] when phase 1 is over
-    uint2* const tagmin = reinterpret_cast<uint2*>(vals);
     __shared__ uint32_t queue[kBmQueue];
     __shared__ uint16_t uqueue[kBmUQueue];
     __shared__ uint32_t qcount, ucount;
@@ -842,8 +827,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     }
     if (!tk.valid) return;
-    if (WAVE_COMBINE) { for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; tagmin[s] = make_uint2(kEmptyTag, 0x7f800000u); } }
-    else { for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; amin[s] = 0x7f800000u; } }
+    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) { tags[s] = kEmptyTag; amin[s] = 0x7f800000u; }
     if (threadIdx.x == 0) { qcount = 0; ucount = 0; }
     __syncthreads();
     const RimgGeom g = make_geom(gg);
@@ -865,106 +849,8 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     // Only full tiles run the pre-filter: the one partial tile at the end of the map takes the exact path as a whole (phase 2),
     // which keeps bounds tests and clamped indices out of these loops.
     const bool full_tile = nloc == per_block;
-    if (WAVE_COMBINE && full_tile) {
-        // Round 5 (the kernel waited -- SQ_WAIT_ANY 0.55, VALU 0.46 -- on per-point dependent LDS round trips: tag read -> CAS -> minimum read ->
-        // atomic, inside divergent branches, and the 64 lanes of a load hammer the same two or three table words).  Now:
-        //  * the slot is a pure function of the pixel, ownership is read in phase 1b, so nothing in phase 1a waits for a claim;
-        //  * per load of 64 consecutive points the lanes of one pixel are min-combined in registers (ballot match on the pixel + a DPP reduction,
-        //    kBmCombineIters pixels at most, the rest on their own) and ONE lane per pixel touches the table;
-        //  * the table reads of a group of four points go out together, before anything branches on them; points are prefetched one group ahead.
-        const uint32_t lane = threadIdx.x & 63u;
-        // software pipeline without a second register set: the next group's points are requested as soon as this group's coordinates have been
-        // consumed, and arrive while the combine loops and the table traffic of this group run
-        float4 pt[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) pt[u] = mapb[(uint32_t)u * kBlock + threadIdx.x];
-#pragma unroll
-        for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
-            bool ok = true;
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int j = j0 + u;
-                const float3 p = xform_approx(ap, pt[u], ok);
-                if (j0 + 4 < kPtsPerThread) pt[u] = mapb[(uint32_t)(j0 + 4 + u) * kBlock + threadIdx.x];
-                const CullCand cc = cull_candidates<EL3>(g, p, row_scale, col_scale, steep_clamps);
-                const bool cert = packable & ok & !cc.unusual & !cc.multi & !(cc.r2 < rmin2);
-                const float r_lo = cull_r_lo(cc.r2);
-                rec[j] = ((cert ? (uint32_t)cc.rb : kBmRowUncertain) << 11) | (uint32_t)(cc.cb & 2047);
-                rlo[j] = cert ? r_lo : -1.0f;          // -1: no table entry can beat it (uncertain pixel)
-                // (the two words ARE the record: without this the compiler carries row, column, range and the certainty mask of all 16 points separately
-                // into phase 1b -- three registers per point instead of two, and registers decide the occupancy here)
-                asm volatile("" : "+v"(rec[j]), "+v"(rlo[j]));
-                // the point's pixel (~0 = not certain: takes no part in phase 1a) and its table slot; both table words are requested now and arrive
-                // while the lanes of the wavefront sort out who speaks for which pixel (stale by then at worst: the minimum only decreases, a claimed
-                // tag never changes, and an empty one is re-examined by the CAS)
-                const uint32_t px = cert ? (uint32_t)(cc.rb * g.cols + cc.cb) : 0xffffffffu;
-                const uint32_t sl = (uint32_t)(((cc.rb & (SLOT_ROWS - 1)) << 6) | (cc.cb & 63));
-                const uint2 ta = tagmin[sl];      // one 64-bit LDS read: {owner pixel, minimum of the range upper bounds}
-                uint32_t tg = ta.x;
-                const uint32_t am = ta.y;
-                // upper bound of the exact range (r_lo = r_approx * (1 - 1.5e-6))
-                const uint32_t hi = cert ? f2u(r_lo * (1.0f + 3.5e-6f)) : 0xffffffffu;
-                uint64_t todo = __builtin_amdgcn_ballot_w64(cert);
-                uint32_t lv = 0xffffffffu;      // the pixel's combined bound in the lane that speaks for the pixel, ~0 (never a range: NaNs are not certain) in the others
-                for (int it = 0; it < (combine_iters & 255) && todo; ++it) {
-                    const int leader = __builtin_ctzll(todo);
-                    const uint32_t lpx = (uint32_t)__builtin_amdgcn_readlane((int)px, leader);      // a certain lane's pixel: never ~0
-                    const bool mine = px == lpx;
-                    const uint64_t match = __builtin_amdgcn_ballot_w64(mine);
-                    const uint32_t m = wave_umin(mine ? hi : 0xffffffffu);
-                    lv = (lane == (uint32_t)leader) ? m : lv;
-                    todo &= ~match;
-                }
-                lv = ((todo >> lane) & 1ull) ? hi : lv;      // more distinct pixels than iterations: these lanes go on their own
-                if (lv != 0xffffffffu) {      // the speaking lanes only
-                    if (tg == kEmptyTag) {
-                        const uint32_t old = atomicCAS(&tagmin[sl].x, kEmptyTag, px);
-                        tg = (old == kEmptyTag) ? px : old;
-                    }
-                    if (tg == px && lv < am) atomicMin(&tagmin[sl].y, lv);
-                }
-            }
-        }
-        __syncthreads();
-        // ---- phase 1b: a point survives unless its pixel is certain, owns its slot and some point of the tile is provably nearer in the same pixel
-        const uint32_t lane_word = threadIdx.x << 20;
-#pragma unroll
-        for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
-            uint32_t tg[4], pxq[4];
-            float am[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t row = (rec[j0 + u] >> 11) & 511u, col = rec[j0 + u] & 2047u;
-                const uint32_t slot = ((row & (uint32_t)(SLOT_ROWS - 1)) << 6) | (col & 63u);
-                pxq[u] = __umul24(row, (uint32_t)g.cols) + col;
-                const uint2 ta = tagmin[slot];
-                tg[u] = ta.x;
-                am[u] = u2f(ta.y);
-            }
-            bool sv[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) sv[u] = !((tg[u] == pxq[u]) & (rlo[j0 + u] > am[u]));
-            __builtin_amdgcn_sched_barrier(0);      // four table reads in flight, not sixteen: the records of all 16 points are live here and registers decide the occupancy
-            const uint64_t b0 = __builtin_amdgcn_ballot_w64(sv[0]), b1 = __builtin_amdgcn_ballot_w64(sv[1]),
-                           b2 = __builtin_amdgcn_ballot_w64(sv[2]), b3 = __builtin_amdgcn_ballot_w64(sv[3]);
-            const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
-            const uint32_t total = n0 + n1 + n2 + n3;
-            if (!total) continue;
-            uint32_t base = 0;
-            if (lane == 0u) base = atomicAdd(&qcount, total);
-            base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-            if (base + total > (uint32_t)kBmQueue) continue;          // overflow, decided on the scalar unit: the whole tile goes exact in phase 2
-            const uint64_t bal[4] = {b0, b1, b2, b3};
-            const uint32_t off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                if (!sv[u]) continue;
-                const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-                queue[base + off[u] + below] = ((rec[j0 + u] & 0xfffffu) | lane_word) | ((uint32_t)((j0 + u) * kBlock) << 20);
-            }
-        }
-    } else if (full_tile) {
-        // ---- round 4's phase 1a (four points per lane in flight, as in k_vote_map_cull)
+    if (full_tile) {
+        // ---- phase 1a (four points per lane in flight, as in k_vote_map_cull)
 #pragma unroll
         for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
             float4 pt[4];
@@ -1031,19 +917,9 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         }
     }
     __syncthreads();
-    const int stop_after = combine_iters >> 8;      // DIAGNOSTIC (LTM_BM_STOP, tools/ab_kernels.py): leave after phase 1 (1) / after the certain survivors (2); the image is wrong then
+    // stop_after: DIAGNOSTIC (LTM_BM_STOP): the image is wrong then
     if (stop_after == 1) return;
-    if (WAVE_COMBINE && full_tile) {      // the owners of phase 1 stay the owners of phase 2 (same slot function): out of the combined words before those become values
-        static_assert(kBmSlots % kBlock == 0, "");
-        uint32_t own[kBmSlots / kBlock];
-#pragma unroll
-        for (int q = 0; q < kBmSlots / kBlock; ++q) own[q] = tagmin[q * kBlock + threadIdx.x].x;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kBmSlots / kBlock; ++q) { tags[q * kBlock + threadIdx.x] = own[q]; vals[q * kBlock + threadIdx.x] = ~0ull; }
-    } else {
-        for (int s = threadIdx.x; s < kBmSlots; s += kBlock) vals[s] = ~0ull;        // amin is dead from here on
-    }
+    for (int s = threadIdx.x; s < kBmSlots; s += kBlock) vals[s] = ~0ull;        // amin is dead from here on
     __syncthreads();
     // ---- phase 2: survivors.  Certain pixel: only the exact range; the others are re-queued densely and get the full exact projection
     const uint32_t nq = full_tile ? qcount : (uint32_t)kBmQueue + 1u;
@@ -1088,214 +964,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
 }
 
 
-// ---------------------------------------------------------------------------------------------------------------
-// k_map_rimg_stream (round 5): the same exact arg-min image through the same workgroup-local pre-filter, organised around what the
-// phase timings of k_map_rimg_blockmin showed (tools/ab_kernels.py with LTM_BM_STOP: 7.4 of 9.6 ms per full-map launch are phase 1, and
-// phase 1 is instruction-bound, not latency-bound -- min-combining the lanes of a load in registers and taking every LDS wait out of
-// phase 1a changed nothing, profiles/r5_ab_blockmin_*.txt).  So this form issues fewer instructions per point:
-//   * a point is examined ONCE.  While it publishes its bound it also reads the pixel's current minimum; the minimum only decreases, so
-//     a point that is already beaten then (~85 % of them: with n points in a pixel the i-th is a running minimum with probability 1/i)
-//     is dropped on the spot.  Only the others -- running minima, points without a table slot, points whose pixel is not certain --
-//     become CANDIDATES; after the barrier the candidates alone (~20 %) are tested against the final minima.  Round 4 kept a record of
-//     all 16 points of a lane in registers (32 VGPRs) and ran the second test, with its table read and queue arithmetic, for every point;
-//   * bounds on SQUARED ranges (r_e^2 within r2 (1 -+ 3e-6), validated by ltm_debug_cull_check): no square root in phase 1;
-//   * candidates go to a queue segment of their own wavefront (count in a scalar register, no LDS atomic), the second test compacts the
-//     segment in place (a wavefront's LDS operations execute in order and survivors never outnumber the entries read), and phase 2 walks
-//     the same segment: no cross-wave queue traffic at all;
-//   * the second test needs the candidate's squared range again: recomputed from the point (16 B from L1/L2 + 12 FMAs for 20 % of the
-//     points) instead of being carried.
-// Exactness argument unchanged: a point is dropped only if its pixel is certain, owns its slot, and lo2(P) > hi2(B) for a point B of the
-// same exact pixel, i.e. B is strictly nearer; whatever survives gets the reference arithmetic.
-static constexpr int kStSegment = 512;     // candidate capacity per wavefront (1024 points each); beyond it the whole tile takes the exact path
-
-template <bool B2L_IDENTITY, bool EL3, int SLOT_ROWS = 16>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(7, 8)))
-k_map_rimg_stream(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                  uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs, int diag)
-{
-    constexpr int kSlots = SLOT_ROWS * 64;
-    static_assert(kSlots <= kBmSlotsMax && kSlots % kBlock == 0, "");
-    __shared__ uint64_t vals[kSlots];          // phase 1: {owner pixel, minimum of the squared-range upper bounds} per slot; phase 2: (range | index) minima
-    __shared__ uint32_t tags[kSlots];          // phase 2: owner pixel per slot (moved out of the combined words)
-    __shared__ uint32_t queue[(kBlock / 64) * kStSegment];
-    __shared__ uint16_t uqueue[kBmUQueue];
-    __shared__ uint32_t ucount, overflow;
-    uint2* const tagmin = reinterpret_cast<uint2*>(vals);
-    const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
-    TileKf tk;
-    if (pairs) {      // occlusion-culled launch: see k_map_rimg_blockmin
-        const uint32_t seg = (n_pairs + 7u) >> 3, at = (blockIdx.x & 7u) * seg + (blockIdx.x >> 3);
-        if ((blockIdx.x >> 3) >= seg || at >= n_pairs) return;
-        const uint32_t pr = pairs[at];
-        tk.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr / nb)); tk.kfb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr % nb)); tk.valid = true;
-    } else {
-        tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
-    }
-    if (!tk.valid) return;
-    for (int s = threadIdx.x; s < kSlots; s += kBlock) { tags[s] = kEmptyTag; tagmin[s] = make_uint2(kEmptyTag, 0x7f800000u); }
-    if (threadIdx.x == 0) { ucount = 0; overflow = 0; }
-    __syncthreads();
-    const RimgGeom g = make_geom(gg);
-    const uint32_t npx = (uint32_t)(g.rows * g.cols);
-    const uint32_t block_base = tk.tile * per_block;
-    const float4* __restrict__ mapb = map + block_base;
-    const uint32_t nloc = min(per_block, M - block_base);
-    const uint32_t kf = kb + tk.kfb;
-    uint64_t* __restrict__ imgk = img + (size_t)tk.kfb * npx;
-    const float* __restrict__ ap = approx_poses + 16 * (size_t)kf;
-    const float row_scale = g.frows * (57.29577951308232f / g.vfov), col_scale = g.fcols * (57.29577951308232f / g.hfov);
-    const bool packable = g.rows < (int)kBmRowUncertain && g.cols <= 2048;
-    const float rmin = cull_min_range<B2L_IDENTITY>(b2l_h), rmin2 = rmin * rmin;
-    const bool steep_clamps = g.vfov < 88.0f;
-    const uint32_t lane = threadIdx.x & 63u;
-    uint32_t* const wq = queue + (threadIdx.x >> 6) * kStSegment;       // this wavefront's segment
-    uint32_t wcount = 0;                                                 // uniform per wavefront: lives in a scalar register
-    bool wover = false;
-    // Only full tiles run the pre-filter: the one partial tile at the end of the map takes the exact path as a whole.
-    const bool full_tile = nloc == per_block;
-    if (full_tile) {
-        // ---- phase 1a: every point once, four per lane in flight, the next group's points requested before this group's arithmetic
-        float4 nxt[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) nxt[u] = mapb[(uint32_t)u * kBlock + threadIdx.x];
-        const uint32_t lane_word = threadIdx.x << 20;
-#pragma unroll
-        for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
-            float4 pt[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                pt[u] = nxt[u];
-                if (j0 + 4 < kPtsPerThread) nxt[u] = mapb[(uint32_t)(j0 + 4 + u) * kBlock + threadIdx.x];
-            }
-            // per point across the table read: the record (row | column, row 511 = pixel not certain), the squared range, the table word -- the
-            // pixel index and the slot are recomputed from the record where a (rare) table update needs them: registers decide the occupancy here
-            uint32_t rc[4];
-            float r2[4];
-            uint2 ta[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                bool ok;
-                const float3 p = xform_approx(ap, pt[u], ok);
-                const CullCand cc = cull_candidates<EL3>(g, p, row_scale, col_scale, steep_clamps);
-                const bool cert = packable & ok & !cc.unusual & !cc.multi & !(cc.r2 < rmin2);
-                r2[u] = cc.r2;
-                rc[u] = ((cert ? (uint32_t)cc.rb : kBmRowUncertain) << 11) | (uint32_t)(cc.cb & 2047);
-                ta[u] = tagmin[((cc.rb & (SLOT_ROWS - 1)) << 6) | (cc.cb & 63)];      // one 64-bit LDS read per point; the four of a group go out together
-                asm volatile("" : "+v"(rc[u]), "+v"(r2[u]));      // the record IS these two words (otherwise row, column, certainty and range travel separately)
-            }
-            bool cand[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const uint32_t row = rc[u] >> 11, col = rc[u] & 2047u;
-                const bool cert = row != kBmRowUncertain;
-                const uint32_t px = __umul24(row, (uint32_t)g.cols) + col;
-                uint32_t tg = ta[u].x;
-                if (cert && tg == kEmptyTag) {      // first point of its pixel in this tile (a few per cent of the points)
-                    const uint32_t old = atomicCAS(&tagmin[((row & (uint32_t)(SLOT_ROWS - 1)) << 6) | (col & 63u)].x, kEmptyTag, px);
-                    tg = (old == kEmptyTag) ? px : old;
-                }
-                const bool own = cert & (tg == px);
-                // the minimum as it was when this point looked (+inf for a slot that was still empty): it can only have decreased since
-                const uint32_t hi2 = f2u(r2[u] * (1.0f + 3.2e-6f));
-                if (own && hi2 < ta[u].y) atomicMin(&tagmin[((row & (uint32_t)(SLOT_ROWS - 1)) << 6) | (col & 63u)].y, hi2);
-                cand[u] = !own | !(r2[u] * (1.0f - 3.2e-6f) > u2f(ta[u].y));
-            }
-            const uint64_t b0 = __builtin_amdgcn_ballot_w64(cand[0]), b1 = __builtin_amdgcn_ballot_w64(cand[1]),
-                           b2 = __builtin_amdgcn_ballot_w64(cand[2]), b3 = __builtin_amdgcn_ballot_w64(cand[3]);
-            const uint32_t n0 = (uint32_t)__popcll(b0), n1 = (uint32_t)__popcll(b1), n2 = (uint32_t)__popcll(b2), n3 = (uint32_t)__popcll(b3);
-            const uint32_t total = n0 + n1 + n2 + n3;
-            if (wcount + total > (uint32_t)kStSegment) wover = true;      // decided on the scalar unit
-            if (total && !wover) {
-                const uint64_t bal[4] = {b0, b1, b2, b3};
-                const uint32_t off[4] = {0u, n0, n0 + n1, n0 + n1 + n2};
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                    if (!cand[u]) continue;
-                    const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(bal[u] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)bal[u], 0u));
-                    wq[wcount + off[u] + below] = (rc[u] | lane_word) | ((uint32_t)((j0 + u) * kBlock) << 20);
-                }
-                wcount += total;
-            }
-        }
-        if (wover && lane == 0u) overflow = 1u;
-    }
-    __syncthreads();
-    const int stop_after = diag;      // DIAGNOSTIC (LTM_BM_STOP, tools/ab_kernels.py): leave after phase 1 (1) / the certain survivors (2) / before the flush (3); the image is wrong then
-    const bool exact_all = !full_tile || overflow != 0u;
-    if (!exact_all) {
-        // ---- phase 1b: the candidates of this wavefront against the final minima; survivors are compacted in place
-        uint32_t kept = 0;
-        for (uint32_t base = 0; base < wcount; base += 64u) {
-            const bool in = base + lane < wcount;
-            const uint32_t e = in ? wq[base + lane] : 0u;
-            const uint32_t row = (e >> 11) & 511u, col = e & 2047u;
-            bool sv = in;
-            if (in && row != kBmRowUncertain) {
-                bool ok;
-                const float3 p = xform_approx(ap, mapb[e >> 20], ok);
-                const float r2 = __builtin_fmaf(p.z, p.z, __builtin_fmaf(p.x, p.x, p.y * p.y));      // cull_candidates' r2, operation for operation
-                const uint2 t = tagmin[((row & (uint32_t)(SLOT_ROWS - 1)) << 6) | (col & 63u)];
-                sv = (t.x != __umul24(row, (uint32_t)g.cols) + col) | !(r2 * (1.0f - 3.2e-6f) > u2f(t.y));
-            }
-            const uint64_t b = __builtin_amdgcn_ballot_w64(sv);
-            if (sv) wq[kept + __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u))] = e;
-            kept += (uint32_t)__popcll(b);
-        }
-        wcount = kept;
-    }
-    __syncthreads();
-    if (stop_after == 1) return;
-    {   // the owners of phase 1 stay the owners of phase 2 (same slot function): out of the combined words before those become values
-        uint32_t own[kSlots / kBlock];
-#pragma unroll
-        for (int q = 0; q < kSlots / kBlock; ++q) own[q] = tagmin[q * kBlock + threadIdx.x].x;
-        __syncthreads();
-#pragma unroll
-        for (int q = 0; q < kSlots / kBlock; ++q) { tags[q * kBlock + threadIdx.x] = exact_all ? kEmptyTag : own[q]; vals[q * kBlock + threadIdx.x] = ~0ull; }
-    }
-    __syncthreads();
-    if (full_tile && threadIdx.x == 0 && (blockIdx.x & 63u) == 0u) {   // sampled diagnostic (this wavefront's quarter of the tile, scaled)
-        atomicAdd(&g_cull_stats[2], (unsigned long long)(exact_all ? nloc : 4u * wcount));
-        atomicAdd(&g_cull_stats[3], (unsigned long long)nloc);
-    }
-    // ---- phase 2: survivors.  Certain pixel: only the exact range; the others are re-queued densely and get the full exact projection
-    const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
-    if (__builtin_expect(exact_all, 0)) {      // partial tile or a segment overflow: a superset is always correct (min is idempotent)
-        for (uint32_t li = threadIdx.x; li < nloc; li += kBlock)
-            exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
-    } else {
-        for (uint32_t q = lane; q < wcount; q += 64u) {
-            const uint32_t e = wq[q];
-            const uint32_t li = e >> 20;
-            const int row = (int)((e >> 11) & 511u), col = (int)(e & 2047u);
-            const uint32_t i = block_base + li;
-            if (row == (int)kBmRowUncertain) {
-                const uint32_t up = atomicAdd(&ucount, 1u);
-                if (up < (uint32_t)kBmUQueue) uqueue[up] = (uint16_t)li;
-                else exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, i, Tinv, b2l_h, g, vals, tags, imgk);
-                continue;
-            }
-            const uint32_t pxl = (uint32_t)(row * g.cols + col);
-            const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
-            const int slot = table_claim<SLOT_ROWS, 64>(tags, row, col, pxl);
-            if (slot >= 0) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
-            else img_min_u64(imgk + pxl, v);
-        }
-        __syncthreads();
-        if (stop_after == 2) return;
-        const uint32_t nu = min(ucount, (uint32_t)kBmUQueue);
-        for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
-            exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
-    }
-    __syncthreads();
-    if (stop_after == 3) return;
-    for (int s = threadIdx.x; s < kSlots; s += kBlock) {
-        const uint32_t t = tags[s];
-        if (t != kEmptyTag && vals[s] != ~0ull) img_min_u64(imgk + t, vals[s]);
-    }
-}
-
-static int g_map_kernel_variant = 4;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction, 2: + workgroup-local arg-min pre-filter (round 4's form), 3: the pre-filter with wave-combined table updates (round 5)
+static int g_map_kernel_variant = 2;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction, 2: + workgroup-local arg-min pre-filter
 void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
 int map_kernel_variant() { return g_map_kernel_variant; }
 
@@ -1307,20 +976,10 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
         const unsigned kfg = (unsigned)g_kf_per_block;
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-#define LTM_LAUNCH_BM(ID, E, W) k_map_rimg_blockmin<ID, E, W><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, g_bm_combine_iters)
+#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, g_bm_stop)
         const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
-        if (g_map_kernel_variant >= 4) {
-#define LTM_LAUNCH_ST(ID, E) k_map_rimg_stream<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, g_bm_combine_iters >> 8)
-            if (!b2l_identity) { if (el3) LTM_LAUNCH_ST(false, true); else LTM_LAUNCH_ST(false, false); }
-            else { if (el3) LTM_LAUNCH_ST(true, true); else LTM_LAUNCH_ST(true, false); }
-#undef LTM_LAUNCH_ST
-        } else if (g_map_kernel_variant >= 3) {
-            if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true, true); else LTM_LAUNCH_BM(false, false, true); }
-            else { if (el3) LTM_LAUNCH_BM(true, true, true); else LTM_LAUNCH_BM(true, false, true); }
-        } else {
-            if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true, false); else LTM_LAUNCH_BM(false, false, false); }
-            else { if (el3) LTM_LAUNCH_BM(true, true, false); else LTM_LAUNCH_BM(true, false, false); }
-        }
+        if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true); else LTM_LAUNCH_BM(false, false); }
+        else { if (el3) LTM_LAUNCH_BM(true, true); else LTM_LAUNCH_BM(true, false); }
 #undef LTM_LAUNCH_BM
         return hipGetLastError();
     }
@@ -1491,20 +1150,10 @@ hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv
 {
     if (!n_pairs) return hipSuccess;
     dim3 grid((unsigned)(((n_pairs + 7) / 8) * 8));
-#define LTM_LAUNCH_BMP(ID, E, W) k_map_rimg_blockmin<ID, E, W><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, g_bm_combine_iters)
+#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, g_bm_stop)
     const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
-    if (g_map_kernel_variant >= 4) {
-#define LTM_LAUNCH_STP(ID, E) k_map_rimg_stream<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, g_bm_combine_iters >> 8)
-        if (!b2l_identity) { if (el3) LTM_LAUNCH_STP(false, true); else LTM_LAUNCH_STP(false, false); }
-        else { if (el3) LTM_LAUNCH_STP(true, true); else LTM_LAUNCH_STP(true, false); }
-#undef LTM_LAUNCH_STP
-    } else if (g_map_kernel_variant >= 3) {
-        if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true, true); else LTM_LAUNCH_BMP(false, false, true); }
-        else { if (el3) LTM_LAUNCH_BMP(true, true, true); else LTM_LAUNCH_BMP(true, false, true); }
-    } else {
-        if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true, false); else LTM_LAUNCH_BMP(false, false, false); }
-        else { if (el3) LTM_LAUNCH_BMP(true, true, false); else LTM_LAUNCH_BMP(true, false, false); }
-    }
+    if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true); else LTM_LAUNCH_BMP(false, false); }
+    else { if (el3) LTM_LAUNCH_BMP(true, true); else LTM_LAUNCH_BMP(true, false); }
 #undef LTM_LAUNCH_BMP
     return hipGetLastError();
 }

@@ -44,10 +44,11 @@ def main():
             cmap = ctx.voxel_centroid(ctx.merge_to_global(scans, poses), 0.05)
             labels = torch.zeros(len(cmap), dtype=torch.uint8, device="cuda:0")
             torch.cuda.synchronize()
-            for alpha in (2.5, 2.0, 1.5):       # warm-up: scan images cached, pool filled
+            for alpha in (2.5, 2.0, 1.5):       # warm-up: pool filled
                 ctx.visibility_vote(cmap, scans, poses, 0, poses.n, alpha, 0.1, 0, labels.data_ptr())
             ctx.reproject(cmap, poses, 3.0)
             ctx.synchronize()
+            ctx.clear_caches()                  # the timed votes build their scan images again (class vote_scan)
             ctx.profile_reset(); ctx.profile_enable(True)
             for alpha in (2.5, 2.0, 1.5):
                 ctx.visibility_vote(cmap, scans, poses, 0, poses.n, alpha, 0.1, 0, labels.data_ptr())
@@ -67,7 +68,7 @@ def main():
     print(f"map {n_map} points, {args.kf} keyframes; ms per launch, per round")
     for v in variants:
         print(f"[{v or 'default'}]")
-        for cls in ("vote_map_cull", "vote_map_exact", "reproject_map", "voxel", "vote_compare", "reproject_gather"):
+        for cls in ("vote_map_cull", "vote_map_exact", "reproject_map", "vote_scan", "voxel", "vote_compare", "reproject_gather"):
             if cls in results[v]:
                 xs = results[v][cls]
                 print(f"  {cls:18s} " + " ".join(f"{x:8.3f}" for x in xs) + f"   min {min(xs):8.3f}")
