@@ -172,6 +172,7 @@ struct ltm_ctx {
     HostMat34 L2B, B2L;
     int l2b_identity = 1, b2l_identity = 1;
     size_t kf_batch = 512;
+    KernelOpts kopts;               // kernel variants / diagnostics of this context (environment, read at ltm_create)
     int fast_math = 0;   // set by the create-time self-check of the fast arithmetic forms for this FOV
     unsigned long long selfcheck[3] = {0, 0, 0};
     Pool pool;
@@ -689,9 +690,9 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     if (!map.n || !nb) return;
     const size_t n_tiles = (map.n + 4095) / 4096, n_pairs = n_tiles * nb;
     // (the list-driven launch exists for the block-local arg-min kernel only: LTM_MAP_KERNEL=0/1, the A/B baselines, take the plain launch)
-    const bool occl = c->occlusion_cull && map_kernel_variant() >= 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
+    const bool occl = c->occlusion_cull && c->kopts.map_kernel_variant >= 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
     if (!occl) {
-        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream));
+        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream, c->kopts));
         return;
     }
     const size_t rbs = (size_t)g.rows, cbs = ((size_t)g.cols + 7) / 8;
@@ -730,7 +731,7 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
         LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream, dirty));
         uint32_t n_live = 0;
         d2h(c, &n_live, count, 4);
-        LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, c->stream));
+        LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, c->stream, c->kopts));
         n_proj += n_live;
         if (shell == 0) c->occl_near += n_live;
         if (last) break;
@@ -760,7 +761,7 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
         const size_t nb = std::min(KB, kf_end - kb);
         const uint32_t* smax = nullptr;
         const float* qbound = nullptr;
-        const bool cull = mode == 0 && vote_cull_enabled() && ps.approx_dev;
+        const bool cull = mode == 0 && (c->kopts.vote_cull != 0) && ps.approx_dev;
         const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g, &smax, cull ? thr : -1.0f, &qbound);
         {
             ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 8));
@@ -772,7 +773,7 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
             // (measurement only, when profiling is on) they are counted by the same predicate and left out.
             // compulsory bytes of the launch as designed: the map once, per keyframe the range|index image written (8 B) and, culled form, the bound image read (4 B)
             double pts = (double)map.n * nb, bytes = 16.0 * pts + (double)nb * 8.0 * npx, bytes_c = 16.0 * map.n + (double)nb * (cull ? 12.0 : 8.0) * npx;
-            const bool count_live = cull && c->prof_on && tile_cull_enabled() && smax && c->pending_live.size() < (size_t)kLiveSlots;
+            const bool count_live = cull && c->prof_on && (c->kopts.tile_cull != 0) && smax && c->pending_live.size() < (size_t)kLiveSlots;
             if (count_live) {      // no host round trip here: the count is read when the profile is collected
                 if (!c->live_counts) LTM_HIP(hipMalloc(reinterpret_cast<void**>(&c->live_counts), sizeof(unsigned long long) * kLiveSlots));
                 const int slot = (int)c->pending_live.size();
@@ -784,7 +785,7 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
             ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, bytes, bytes_c);
             if (cull) {
                 LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, qbound, tb.as<float>(), smax, thr, mode,
-                                              map_img.as<uint64_t>(), c->stream));
+                                              map_img.as<uint64_t>(), c->stream, c->kopts));
             } else exact_map_images(c, map, ps, kb, nb, g, map_img.as<uint64_t>());
         }
         {
@@ -1330,16 +1331,16 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         delete c;
         return LTM_E_DEVICE;
     }
-    // A/B switches for profiling.  They are process-wide (kernel-side globals): every context creation sets ALL of them, to the
-    // environment's value or to the default, so that a variant chosen for one context does not leak into the next one of the process
+    // A/B switches and diagnostics of the projection kernels: part of THIS context (KernelOpts, ltm_kernels.h) -- round 4 kept them in process-wide
+    // statics that every ltm_create rewrote, a data race by the letter for `ltm_run --gpus K` (K threads, K contexts)
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
-    set_map_kernel_variant(env_int("LTM_MAP_KERNEL", 2));
-    set_vote_cull(env_int("LTM_VOTE_CULL", 1));
-    set_cull_variant(env_int("LTM_CULL_VARIANT", 0));
-    set_kf_per_block(env_int("LTM_KF_PER_BLOCK", 8));
-    set_bm_stop(env_int("LTM_BM_STOP", 0));
-    set_tile_cull(env_int("LTM_TILE_CULL", 1));
-    set_stats_select(env_int("LTM_STATS_BLOCKMIN", 0));
+    c->kopts.map_kernel_variant = env_int("LTM_MAP_KERNEL", 2);
+    c->kopts.vote_cull = env_int("LTM_VOTE_CULL", 1);
+    c->kopts.cull_variant = env_int("LTM_CULL_VARIANT", 0);
+    c->kopts.kf_per_block = env_int("LTM_KF_PER_BLOCK", 8);
+    c->kopts.bm_stop = env_int("LTM_BM_STOP", 0);
+    c->kopts.tile_cull = env_int("LTM_TILE_CULL", 1);
+    c->kopts.stats_blockmin = env_int("LTM_STATS_BLOCKMIN", 0);
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's
     // constants; they are enabled only if they reproduce the exact IEEE results for every input.
     {
@@ -2102,14 +2103,37 @@ static void box_check(const float* mn, const float* mx)
 }
 // packed keys of `in` under the frame of the box (mn, mx): the compressed Morton code starts at bit `ib` of every key, `shift` brings its top
 // <= 12 bits down to the histogram bin
+// The compressed code without its `drop` lowest bits (a PREFIX of the code: points of one voxel still share it, order is kept up to ties)
+static KeyCompress key_compress_drop_low(const KeyCompress& kc, unsigned drop)
+{
+    if (!drop) return kc;
+    KeyCompress o{};
+    for (int r = 0; r < kc.n_runs; ++r) {
+        unsigned len = 0;
+        while (len < 64 && ((kc.mask[r] >> len) & 1ull)) ++len;
+        const unsigned lo = kc.dst[r], hi = lo + len;            // the run fills output bits [lo, hi)
+        if (hi <= drop) continue;
+        const unsigned cut = lo < drop ? drop - lo : 0;           // bits of the run that fall below the cut
+        o.src[o.n_runs] = (unsigned char)(kc.src[r] + cut);
+        o.dst[o.n_runs] = (unsigned char)(lo + cut - drop);
+        o.mask[o.n_runs] = kc.mask[r] >> cut;
+        ++o.n_runs;
+    }
+    o.bits = kc.bits > drop ? kc.bits - drop : 1;
+    if (o.n_runs == 0) { o.n_runs = 1; o.src[0] = 0; o.dst[0] = 0; o.mask[0] = 0; }
+    return o;
+}
 static void box_keys(ltm_ctx* c, const Cloud& in, const float* mn, const float* mx, float leaf, DevBuf& keys, unsigned* ib_out, unsigned* shift_out)
 {
     OctreeFrame f;
     if (!octree_frame_from_bbox(mn, mx, leaf, &f)) throw Err{LTM_E_UNSUPPORTED, "octree depth > 21 (extent / leaf too large)"};
     unsigned ib = 1;
     while (ib < 32 && ((size_t)1 << ib) < in.n) ++ib;
-    const KeyCompress kc = key_compress_for(mn, mx, f, true);
-    if (kc.bits + ib > 64) throw Err{LTM_E_UNSUPPORTED, "voxel key + index bits exceed 64"};
+    // These keys only ROUTE points (4096-bin histogram of the top 12 code bits, then a range split): whole voxels must stay together, which any prefix of
+    // the code guarantees.  So the code is cut to what fits beside a 32-bit index -- a function of the SHARED box alone: every rank of the exchange takes the
+    // same decision whatever its local point count (a rank-local `ib` could let one rank throw while the others entered the collective)
+    KeyCompress kc = key_compress_for(mn, mx, f, true);
+    if (kc.bits + 32 > 64) kc = key_compress_drop_low(kc, kc.bits + 32 - 64);
     LTM_HIP(morton_keys_packed(in.d, in.n, f, kc, ib, keys.as<uint64_t>(), c->stream));
     *ib_out = ib;
     *shift_out = ib + (kc.bits > 12 ? kc.bits - 12 : 0);
@@ -2644,7 +2668,7 @@ int ltm_debug_viz_images(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hscans, ltm_pos
         DevBuf img(c, npx * 8), mr(c, npx * 4), mi(c, npx * 4), df(c, npx * 4), out(c, npx * 3), lutd(c, 768);
         LTM_HIP(fill_u64(img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, npx, c->stream));
         if (map.n)                                                                         // transformGlobalMapToLocal + map2RangeImg (exact image)
-            LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kf, 1, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream));
+            LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kf, 1, c->B2L, c->b2l_identity, g, img.as<uint64_t>(), c->stream, c->kopts));
         LTM_HIP(decode_image(img.as<uint64_t>(), npx, mr.as<float>(), mi.as<int32_t>(), c->stream));
         uint8_t lut[768];
         jet_lut_bgr(lut);
@@ -2721,7 +2745,7 @@ int ltm_debug_cull_stats(ltm_ctx* c, uint64_t* survivors, uint64_t* points, int 
 {
     return guarded(c, [&] {
         unsigned long long v[2] = {0, 0};
-        LTM_HIP(cull_stats(v, reset, c->stream));
+        LTM_HIP(cull_stats(v, reset, c->stream, c->kopts.stats_blockmin));
         if (survivors) *survivors = v[0];
         if (points) *points = v[1];
     });

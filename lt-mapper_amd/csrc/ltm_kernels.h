@@ -40,19 +40,28 @@ hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, s
 hipError_t scan_qbound(const uint32_t* scan_img, size_t n, float thr, float* qbound, hipStream_t s);
 // bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);
-void set_stats_select(int v);
-void set_tile_cull(int v);
+// Kernel variants and diagnostics, held by the context (ltm_ctx::kopts, read from the environment at ltm_create) and handed to the launchers: K contexts
+// on K host threads (ltm_run --gpus K) share no mutable state.  The non-default values are A/B baselines and timing diagnostics, not product paths.
+struct KernelOpts {
+    int map_kernel_variant = 2;   // LTM_MAP_KERNEL   exact arg-min image: 0 one global atomic per point, 1 LDS pre-reduction, 2 + workgroup-local arg-min pre-filter
+    int vote_cull = 1;            // LTM_VOTE_CULL    1: mode-0 votes use k_vote_map_cull, 0: the exact-image kernel
+    int tile_cull = 1;            // LTM_TILE_CULL    whole-tile range cull inside k_vote_map_cull
+    int cull_variant = 0;         // LTM_CULL_VARIANT 1: generic elevation polynomial even where the fitted one applies
+    int kf_per_block = 8;         // LTM_KF_PER_BLOCK keyframes that reuse one map tile on an XCD (tile_kf_of_block)
+    int bm_stop = 0;              // LTM_BM_STOP      DIAGNOSTIC: k_map_rimg_blockmin leaves after phase 1 (1) / the certain survivors (2) / before the flush (3)
+    int stats_blockmin = 0;       // LTM_STATS_BLOCKMIN  ltm_debug_cull_stats reports the exact-image kernel's survivor counts instead of the vote kernel's
+};
 // transformGlobalMapToLocal + map2RangeImg: map_img[(kf-kb)*npx+px] = min (range_bits<<32 | idx)
 // inv_poses_dev: 12 doubles per keyframe (3x4 row-major).  b2l: 12 doubles, b2l_identity skips the arithmetic.
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
+                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s, const KernelOpts& ko);
 // occlusion cull of the exact-image kernel on large maps (see ltm_kernels.hip): pair t = tile * nb + keyframe.  flags: n_tiles * nb bytes,
 // done: n_tiles * nb zeroed bytes, pos / list: n_tiles * nb uint32, count: one uint32, cmax: nb * rows * ceil(cols/8) uint32, temp: scan_temp_bytes(n_tiles * nb)
 hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
                                  const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
                                  void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty_rows = nullptr);
 hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s);
+                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s, const KernelOpts& ko);
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
 hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
                             uint8_t* labels, hipStream_t s);
@@ -60,20 +69,12 @@ hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, s
 // approx_poses_dev: 16 floats per keyframe {A[9], c_hi[3], c_lo[3], ok} with p_local ~= A (p - c) (see xform_approx)
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                  HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
-                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s);
-void set_vote_cull(int v);
-void set_cull_variant(int v);
-int vote_cull_enabled();
-int tile_cull_enabled();
+                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s, const KernelOpts& ko);
 hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,
                             const uint32_t* smax_bits_dev, float thr, unsigned long long* live_dev, hipStream_t s);
-void set_bm_stop(int v);            // DIAGNOSTIC: k_map_rimg_blockmin stops after a phase (timing only; tools/ab_kernels.py)
-void set_kf_per_block(int v);    // keyframes that share one map-tile read inside a workgroup (1, 2, 4, 8)
-hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s);   // {survivors, points} since the last reset
+hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s, int which_kernel);   // {survivors, points} since the last reset; 0 vote kernel, 1 exact-image kernel
 hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,
                       Geom g, unsigned long long* bad_dev, hipStream_t s);
-int map_kernel_variant();
-void set_map_kernel_variant(int v);   // 0 = per-point global atomics, 1 = LDS pre-reduction (default)
 // generic single image with up to two explicit transforms (debug / parity)
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,
                               uint64_t* img, hipStream_t s);

@@ -325,7 +325,7 @@ k_map_rimg_lds(const float4* __restrict__ map, uint32_t M, const double* __restr
 }
 
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s);
+                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s, const KernelOpts& ko);
 
 // ---------------------------------------------------------------------------------------------------------------
 // Range-culled vote kernel (mode 0: diff = scan - map).  A map point P can influence the labels only if it could be
@@ -447,8 +447,6 @@ __device__ __forceinline__ float cull_min_range(const HostMat34& b2l)
 }
 
 __device__ unsigned long long g_cull_stats[4];   // {survivors, points} of k_vote_map_cull, then of k_map_rimg_blockmin: diagnostic, read by cull_stats()
-static int g_stats_select = 0;             // which pair cull_stats() reports (env LTM_STATS_BLOCKMIN=1: the reprojection kernel)
-void set_stats_select(int v) { g_stats_select = v ? 1 : 0; }
 
 static constexpr int kCullQueue = 2048;   // survivor queue capacity (~370 of 4096 expected); overflow sends the whole tile down the exact path
 
@@ -693,9 +691,9 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         }
 }
 
-hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s)
+hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s, int which_kernel)
 {
-    hipError_t e = hipMemcpyFromSymbolAsync(out2, HIP_SYMBOL(g_cull_stats), 16, 16 * (size_t)g_stats_select, hipMemcpyDeviceToHost, s);
+    hipError_t e = hipMemcpyFromSymbolAsync(out2, HIP_SYMBOL(g_cull_stats), 16, 16 * (size_t)(which_kernel ? 1 : 0), hipMemcpyDeviceToHost, s);
     if (e != hipSuccess) return e;
     e = hipStreamSynchronize(s);
     if (e != hipSuccess || !reset) return e;
@@ -704,28 +702,18 @@ hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s)
     return e == hipSuccess ? hipStreamSynchronize(s) : e;
 }
 
-static int g_kf_per_block = 8;         // keyframes that reuse one map tile on an XCD (tile_kf_of_block); env LTM_KF_PER_BLOCK
-void set_kf_per_block(int v) { g_kf_per_block = v < 1 ? 1 : (v > 64 ? 64 : v); }
-static int g_tile_cull = 1;   // whole-tile range cull inside k_vote_map_cull (env LTM_TILE_CULL)
-void set_tile_cull(int v) { g_tile_cull = v; }
-static int g_cull_variant = 0;   // env LTM_CULL_VARIANT=1: the vote / exact-image kernels use the generic elevation polynomial even where the fitted one applies (A/B)
-void set_cull_variant(int v) { g_cull_variant = v; }
-static int g_vote_cull = 1;   // 1: mode-0 votes use k_vote_map_cull; 0: always k_map_rimg_lds (A/B, env LTM_VOTE_CULL)
-void set_vote_cull(int v) { g_vote_cull = v; }
-int vote_cull_enabled() { return g_vote_cull != 0; }
-int tile_cull_enabled() { return g_tile_cull != 0; }
 
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                  HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
-                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s)
+                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s, const KernelOpts& ko)
 {
     if (!M || !nb) return hipSuccess;
-    if (mode != 0 || !g_vote_cull || !approx_poses_dev || !qbound_img) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s);
+    if (mode != 0 || !ko.vote_cull || !approx_poses_dev || !qbound_img) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s, ko);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
-    const unsigned kfg = (unsigned)g_kf_per_block;
+    const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-    const float* tb = (g_tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
-    const bool el3 = g.el_fit != 0 && g_cull_variant != 1;       // LTM_CULL_VARIANT=1: generic elevation polynomial (A/B)
+    const float* tb = (ko.tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
+    const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;       // LTM_CULL_VARIANT=1: generic elevation polynomial (A/B)
 #define LTM_LAUNCH_CULL(ID, E) k_vote_map_cull<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
     if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL(false, true); else LTM_LAUNCH_CULL(false, false); }
     else { if (el3) LTM_LAUNCH_CULL(true, true); else LTM_LAUNCH_CULL(true, false); }
@@ -793,8 +781,6 @@ static constexpr int kBmQueue = 2048;     // survivor queue capacity (~11 % of 4
 static constexpr uint32_t kBmRowUncertain = 511u;
 static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain survivors (~1 % of the tile); beyond it they are handled in place
 
-static int g_bm_stop = 0;      // DIAGNOSTIC, env LTM_BM_STOP (tools/ab_kernels.py): k_map_rimg_blockmin leaves after phase 1 (1) / the certain survivors (2) / before the flush (3)
-void set_bm_stop(int v) { g_bm_stop = v; }
 
 // pairs != null: workgroup b processes the (tile, keyframe) pair pairs[b] = tile * nb + keyframe (occlusion-culled launch, see exact_images_occlusion_*)
 // (Round 5 tried three restructurings of phase 1 -- a wave-level combine of the lanes of one pixel, a single 64-bit {owner, minimum} table word, and
@@ -964,28 +950,25 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
 }
 
 
-static int g_map_kernel_variant = 2;   // 0: one global atomic per point (baseline), 1: LDS pre-reduction, 2: + workgroup-local arg-min pre-filter
-void set_map_kernel_variant(int v) { g_map_kernel_variant = v; }
-int map_kernel_variant() { return g_map_kernel_variant; }
 
 hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s)
+                            HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, hipStream_t s, const KernelOpts& ko)
 {
     if (!M || !nb) return hipSuccess;
-    if (g_map_kernel_variant >= 2 && approx_poses_dev) {
+    if (ko.map_kernel_variant >= 2 && approx_poses_dev) {
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
-        const unsigned kfg = (unsigned)g_kf_per_block;
+        const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, g_bm_stop)
-        const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
+#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, ko.bm_stop)
+        const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;
         if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true); else LTM_LAUNCH_BM(false, false); }
         else { if (el3) LTM_LAUNCH_BM(true, true); else LTM_LAUNCH_BM(true, false); }
 #undef LTM_LAUNCH_BM
         return hipGetLastError();
     }
-    if (g_map_kernel_variant >= 1) {
+    if (ko.map_kernel_variant >= 1) {
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
-        const unsigned kfg = (unsigned)g_kf_per_block;
+        const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
         if (b2l_identity) k_map_rimg_lds<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
         else k_map_rimg_lds<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
@@ -1146,12 +1129,12 @@ hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_
 }
 // k_map_rimg_blockmin over an explicit list of n_pairs (tile * nb + keyframe) pairs
 hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s)
+                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s, const KernelOpts& ko)
 {
     if (!n_pairs) return hipSuccess;
     dim3 grid((unsigned)(((n_pairs + 7) / 8) * 8));
-#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, g_bm_stop)
-    const bool el3 = g.el_fit != 0 && g_cull_variant != 1;
+#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, ko.bm_stop)
+    const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;
     if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true); else LTM_LAUNCH_BMP(false, false); }
     else { if (el3) LTM_LAUNCH_BMP(true, true); else LTM_LAUNCH_BMP(true, false); }
 #undef LTM_LAUNCH_BMP
@@ -1899,7 +1882,7 @@ k_key_range_flags(const uint64_t* __restrict__ keys, size_t n, uint64_t lo, uint
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const uint64_t k = keys[i];
-    flags[i] = (k >= lo && k < hi) ? 1 : 0;
+    flags[i] = (k >= lo && (k < hi || hi == ~0ull)) ? 1 : 0;      // hi = ~0: the last part, its bound inclusive (an all-ones key belongs to it)
 }
 hipError_t key_range_flags(const uint64_t* keys, size_t n, uint64_t lo, uint64_t hi, uint8_t* flags, hipStream_t s)
 {
