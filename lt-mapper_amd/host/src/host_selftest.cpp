@@ -7,6 +7,7 @@
 #include <cstring>
 #include <fstream>
 #include <string>
+#include <vector>
 
 #include "removert/RosParamServer.h"
 #include "removert/utility.h"
@@ -28,6 +29,45 @@ static std::string lzf_literals(const std::string& in)
         out.push_back((char)(n - 1));
         out.append(in, i, n);
     }
+    return out;
+}
+
+// greedy LZF compressor WITH back references (liblzf's stream format, the one pcl::io::savePCDFileBinaryCompressed writes): 3-byte hash chains of depth 1,
+// matches of 3..264 bytes at distances 1..8192 -- short and extended length codes, overlapping copies (distance < length) and literal runs all occur
+static std::string lzf_greedy(const std::string& in, size_t* n_refs = nullptr, size_t* n_long = nullptr, size_t* n_overlap = nullptr)
+{
+    const unsigned char* d = reinterpret_cast<const unsigned char*>(in.data());
+    const size_t n = in.size();
+    std::string out, lit;
+    std::vector<long> last(1 << 16, -1);
+    auto flush = [&] {
+        for (size_t i = 0; i < lit.size(); i += 32) { const size_t m = std::min<size_t>(32, lit.size() - i); out.push_back((char)(m - 1)); out.append(lit, i, m); }
+        lit.clear();
+    };
+    size_t i = 0;
+    while (i < n) {
+        size_t best = 0, dist = 0;
+        if (i + 3 <= n) {
+            const unsigned h = ((d[i] * 2654435761u) ^ (d[i + 1] * 40503u) ^ (d[i + 2] * 2246822519u)) & 0xffffu;
+            const long c = last[h];
+            last[h] = (long)i;
+            if (c >= 0 && i - (size_t)c <= 8192) {
+                size_t l = 0;
+                while (i + l < n && l < 264 && d[(size_t)c + l] == d[i + l]) ++l;      // (reads past i when the match overlaps itself: that is the point)
+                if (l >= 3) { best = l; dist = i - (size_t)c; }
+            }
+        }
+        if (!best) { lit.push_back((char)d[i++]); continue; }
+        flush();
+        const unsigned off = (unsigned)(dist - 1), L = (unsigned)(best - 2);
+        if (L < 7) out.push_back((char)((L << 5) | (off >> 8)));
+        else { out.push_back((char)((7u << 5) | (off >> 8))); out.push_back((char)(L - 7)); if (n_long) ++*n_long; }
+        out.push_back((char)(off & 0xffu));
+        if (n_refs) ++*n_refs;
+        if (n_overlap && dist < best) ++*n_overlap;
+        i += best;
+    }
+    flush();
     return out;
 }
 
@@ -107,6 +147,31 @@ int main(int argc, char** argv)
         f.write(reinterpret_cast<const char*>(&cs), 4); f.write(reinterpret_cast<const char*>(&us), 4); f.write(comp.data(), cs);
     }
     CHECK(loadPCDFile(dir + "/d.pcd", r, &err) && r.size() == c.size() && std::memcmp(r.data(), c.data(), c.size() * 16) == 0);
+    // binary_compressed with BACK REFERENCES (the literal-only stream above never ran the decoder's match branch): a cloud with
+    // constant and periodic columns compresses into short, extended-length and self-overlapping matches
+    {
+        Cloud rep;
+        for (int i = 0; i < 5000; ++i) rep.push_back(PointType{0.1f * (float)(i % 37), i < 2500 ? 1.25f : -0.0f, 7.0f, (float)(i % 4)});
+        std::string soa;
+        for (int fld = 0; fld < 4; ++fld)
+            for (const PointType& p : rep) { const float v = fld == 0 ? p.x : fld == 1 ? p.y : fld == 2 ? p.z : p.intensity; soa.append(reinterpret_cast<const char*>(&v), 4); }
+        size_t refs = 0, longs = 0, overlaps = 0;
+        const std::string comp = lzf_greedy(soa, &refs, &longs, &overlaps);
+        CHECK(refs > 100 && longs > 10 && overlaps > 0 && comp.size() < soa.size() / 4);
+        std::string back(soa.size(), '\0');
+        CHECK(lzf_decompress(reinterpret_cast<const unsigned char*>(comp.data()), comp.size(), reinterpret_cast<unsigned char*>(&back[0]), back.size()) && back == soa);
+        // a truncated stream, a match that reaches before the start of the output and an output that is too small are refused, not read out of bounds
+        CHECK(!lzf_decompress(reinterpret_cast<const unsigned char*>(comp.data()), comp.size() - 1, reinterpret_cast<unsigned char*>(&back[0]), back.size()));
+        CHECK(!lzf_decompress(reinterpret_cast<const unsigned char*>(comp.data()), comp.size(), reinterpret_cast<unsigned char*>(&back[0]), back.size() - 8));
+        const unsigned char bad_ref[3] = {0x20, 0x05, 0x00};      // match of 3 bytes at distance 6 into an empty output
+        CHECK(!lzf_decompress(bad_ref, 2, reinterpret_cast<unsigned char*>(&back[0]), 3));
+        std::ofstream f(dir + "/e.pcd", std::ios::binary);
+        f << "VERSION 0.7\nFIELDS x y z intensity\nSIZE 4 4 4 4\nTYPE F F F F\nCOUNT 1 1 1 1\nWIDTH 5000\nHEIGHT 1\nPOINTS 5000\nDATA binary_compressed\n";
+        const uint32_t cs = (uint32_t)comp.size(), us = (uint32_t)soa.size();
+        f.write(reinterpret_cast<const char*>(&cs), 4); f.write(reinterpret_cast<const char*>(&us), 4); f.write(comp.data(), cs);
+        f.close();
+        CHECK(loadPCDFile(dir + "/e.pcd", r, &err) && r.size() == rep.size() && std::memcmp(r.data(), rep.data(), rep.size() * 16) == 0);
+    }
     CHECK(!loadPCDFile(dir + "/does_not_exist.pcd", r, &err) && !err.empty());
 
     // pose lines (Session.cpp:102-114)

@@ -15,6 +15,8 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_ref", "libltm_ref.so")
 EXE_PATH = os.path.join(_HERE, "_ref", "removert_removert")
+# the same process with the multi-resolution remove / revert loop switched on (oracle/refshim/removert_selfremovert_main.cpp)
+EXE_SELFREMOVERT_PATH = os.path.join(_HERE, "_ref", "removert_selfremovert")
 REFERENCE = "/root/reference/ltremovert"
 _lib = None
 
@@ -305,7 +307,8 @@ class Removerter:
         return buf[:n.value].copy()
 
 
-def run_process(yaml_path, timeout=3600):
-    """the reference's process (removert_main.cpp + everything) on a params_ltmapper.yaml-style file: files in, files out"""
+def run_process(yaml_path, timeout=3600, self_removert=False):
+    """the reference's process (removert_main.cpp + everything) on a params_ltmapper.yaml-style file: files in, files out.
+    self_removert: the second main, whose removeHighDynamicPoints runs the reference's own selfRemovert (Removerter.cpp:1582,1586 un-commented)"""
     env = dict(os.environ, REFSHIM_PARAMS=str(yaml_path))
-    return subprocess.run([EXE_PATH], env=env, capture_output=True, text=True, timeout=timeout)
+    return subprocess.run([EXE_SELFREMOVERT_PATH if self_removert else EXE_PATH], env=env, capture_output=True, text=True, timeout=timeout)

@@ -14,10 +14,58 @@ MAP_FILES = ["OriginalNoisyCentralMapGlobal", "OriginalNoisyQueryMapGlobal", "ce
 SCAN_DIRS = [("scans_updated", True), ("scans_updated_strong", False), ("scans_pd", False), ("scans_pd_strong", False), ("scans_nd_strong", False)]
 
 
-def write_pcd(path, pts, ascii_=False):
+def lzf_compress(data):
+    """greedy LZF compressor (liblzf's stream format, what pcl::io::savePCDFileBinaryCompressed writes): literal runs and back references of 3..264
+    bytes at distances 1..8192.  Slow, for small test clouds only."""
+    d = bytes(data)
+    n = len(d)
+    out, lit, last, i = bytearray(), bytearray(), {}, 0
+
+    def flush():
+        for a in range(0, len(lit), 32):
+            piece = lit[a:a + 32]
+            out.append(len(piece) - 1)
+            out.extend(piece)
+        lit.clear()
+    while i < n:
+        best = dist = 0
+        if i + 3 <= n:
+            key = d[i:i + 3]
+            c = last.get(key, -1)
+            last[key] = i
+            if c >= 0 and i - c <= 8192:
+                ln = 0
+                while i + ln < n and ln < 264 and d[c + ln] == d[i + ln]:
+                    ln += 1
+                if ln >= 3:
+                    best, dist = ln, i - c
+        if not best:
+            lit.append(d[i])
+            i += 1
+            continue
+        flush()
+        off, L = dist - 1, best - 2
+        if L < 7:
+            out.append((L << 5) | (off >> 8))
+        else:
+            out.append((7 << 5) | (off >> 8))
+            out.append(L - 7)
+        out.append(off & 0xff)
+        i += best
+    flush()
+    return bytes(out)
+
+
+def write_pcd(path, pts, ascii_=False, compressed=False):
     n = len(pts)
     with open(path, "wb") as f:
-        if ascii_:
+        if compressed:      # DATA binary_compressed: u32 compressed size, u32 raw size, LZF stream of the structure-of-arrays payload (all x, all y, ...)
+            soa = np.ascontiguousarray(np.asarray(pts, dtype=np.float32).T).tobytes()
+            comp = lzf_compress(soa)
+            f.write(HDR.format(w=n, h=1, n=n).replace("DATA binary", "DATA binary_compressed").encode())
+            f.write(np.array([len(comp), len(soa)], dtype=np.uint32).tobytes())
+            f.write(comp)
+        elif ascii_:
             f.write(HDR.format(w=n, h=1, n=n).replace("DATA binary", "DATA ascii").encode())
             for p in pts:
                 f.write((" ".join(repr(float(v)) for v in p) + "\n").encode())
@@ -45,7 +93,7 @@ def parse_keyframes(n, start, end):       # Session.cpp:138-173 incl. the double
     return out
 
 
-def write_session_dirs(root, sessions, tags=("01", "02"), ascii_scans=()):
+def write_session_dirs(root, sessions, tags=("01", "02"), ascii_scans=(), compressed=False):
     """sessions: tools.synth.to_numpy dicts.  Returns the scan directories."""
     dirs = []
     for tag, S in zip(tags, sessions):
@@ -54,7 +102,7 @@ def write_session_dirs(root, sessions, tags=("01", "02"), ascii_scans=()):
         n_kf = len(S["offsets"]) - 1
         for k in range(n_kf):
             a, b = int(S["offsets"][k]), int(S["offsets"][k + 1])
-            write_pcd(os.path.join(d, S["names"][k]), S["scans"][a:b], ascii_=(k in ascii_scans))
+            write_pcd(os.path.join(d, S["names"][k]), S["scans"][a:b], ascii_=(k in ascii_scans), compressed=compressed)
         with open(os.path.join(str(root), tag, "poses.txt"), "w") as f:
             for k in range(n_kf):
                 f.write(" ".join(repr(float(v)) for v in S["poses"][k][:12]) + "\n")

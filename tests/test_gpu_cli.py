@@ -236,3 +236,35 @@ def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
             diff.append((nme, (la, ua), (lb, ub)))
     assert not diff, f"the two hosts do not issue the same work: (class, C++ host, Python host) = {diff}"
     assert len(names) >= 12
+
+
+def test_binary_compressed_scan_directories_give_the_same_output_tree(tmp_path):
+    """Session.cpp:275 loads whatever PCD encoding the scan files have (pcl::io::loadPCDFile).  The same two sessions written as `DATA binary` and as
+    `DATA binary_compressed` (LZF streams with back references, structure-of-arrays payload: tests/fileproto.py) must give byte-identical output trees."""
+    import filecmp
+    import fileproto as fp
+    from tools import synth
+    exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
+    n_kf = 16
+    sess = [synth.to_numpy(synth.make_session(s, n_kf, "tiny")) for s in (1, 2)]
+    for S in sess:      # noisy float coordinates do not compress; a constant intensity column does: long, self-overlapping back references
+        S["scans"] = S["scans"].copy()
+        S["scans"][:, 3] = 7.0
+    outs = {}
+    for kind in ("binary", "compressed"):
+        root = tmp_path / kind
+        root.mkdir()
+        dirs = fp.write_session_dirs(root, sess, compressed=(kind == "compressed"))
+        if kind == "compressed":
+            one = open(os.path.join(dirs[0], sess[0]["names"][0]), "rb").read()
+            assert b"DATA binary_compressed\n" in one and len(one) < 0.8 * 16 * int(sess[0]["offsets"][1]), "the scans really are compressed (back references)"
+        out = root / "out"
+        y = root / "params.yaml"
+        y.write_text(fp.yaml_text(root, dirs, out, 0, n_kf - 1))
+        r = subprocess.run([exe, str(y)], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, kind + ": " + r.stdout[-1500:] + r.stderr[-1500:]
+        outs[kind] = str(out)
+    files = sorted(os.path.relpath(os.path.join(d, f), outs["binary"]) for d, _, fs in os.walk(outs["binary"]) for f in fs)
+    assert len(files) >= 14 + 5 * n_kf
+    for f in files:
+        assert filecmp.cmp(os.path.join(outs["binary"], f), os.path.join(outs["compressed"], f), shallow=False), f

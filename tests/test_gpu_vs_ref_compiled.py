@@ -64,20 +64,24 @@ def test_pipeline_equals_reference_compiled(ltm, case):
     ctx.close(); R.close()
 
 
-@pytest.mark.parametrize("sensor,n_kf", [("tiny", 40), ("os1-64", 40)])
-def test_product_process_and_reference_process_write_identical_trees(tmp_path, sensor, n_kf):
+# three_res: BASELINE configs[1]'s form.  The shipped reference has its selfRemovert calls commented out (Removerter.cpp:1582,1586), so its own main can only
+# write the single-resolution tree; oracle/_ref/removert_selfremovert is the same process with those two calls restored
+@pytest.mark.parametrize("sensor,n_kf,three_res", [("tiny", 40, False), ("os1-64", 40, False), ("tiny", 40, True), ("os1-64", 40, True)])
+def test_product_process_and_reference_process_write_identical_trees(tmp_path, sensor, n_kf, three_res):
     import fileproto as fp
     from tools import synth
     exe = os.path.join(ROOT, "lt-mapper_amd", "host", "ltm_run")
-    assert os.path.exists(exe) and os.path.exists(ref_py.EXE_PATH)
+    assert os.path.exists(exe) and os.path.exists(ref_py.EXE_PATH) and os.path.exists(ref_py.EXE_SELFREMOVERT_PATH)
     sess = [synth.to_numpy(synth.make_session(s, n_kf, sensor)) for s in (1, 2)]
     dirs = fp.write_session_dirs(tmp_path, sess, ascii_scans=(14,))
     outs = {}
+    kw = dict(res_list=(2.5, 2.0, 1.5), extra="  gpu_use_self_removert: true\n") if three_res else {}
     for who in ("product", "reference"):
         out = tmp_path / f"out_{who}"
         y = tmp_path / f"{who}.yaml"
-        y.write_text(fp.yaml_text(tmp_path, dirs, out, 11, n_kf - 1))
-        r = subprocess.run([exe, str(y)], capture_output=True, text=True, timeout=900) if who == "product" else ref_py.run_process(y, timeout=1800)
+        y.write_text(fp.yaml_text(tmp_path, dirs, out, 11, n_kf - 1, **kw))
+        r = (subprocess.run([exe, str(y)], capture_output=True, text=True, timeout=900) if who == "product"
+             else ref_py.run_process(y, timeout=1800, self_removert=three_res))
         assert r.returncode == 0, who + ": " + r.stdout[-1500:] + r.stderr[-1500:]
         outs[who] = out
     n_files = 0
