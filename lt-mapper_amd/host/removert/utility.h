@@ -53,28 +53,7 @@ bool readPCDPointCount(const std::string& path, size_t* n_points, std::string* e
 // (output = input) that PCL takes for large extents.  Points inside a voxel are summed in input order.
 void voxelGridFilter(const Cloud& in, float leaf, Cloud& out);
 void voxelGridFilter(Cloud&& in, float leaf, Cloud& out);      // the early-out hands the input over instead of copying it
-// pcl::VoxelGrid's "leaf size is too small" early-out (voxel_grid.hpp: dx * dy * dz > INT_MAX => output = input) decided on records that need not be
-// aligned (a mapped file's payload): true iff voxelGridFilter(in, leaf, out) would return its input.  Same arithmetic, same order as voxelGridFilter.
-bool voxelGridPassesThrough(const void* records16, size_t n, float leaf);
 
-// A `DATA binary` PCD whose records are exactly x y z intensity as four float32 -- what pcl::io::savePCDFileBinary writes for PointXYZI with the padding
-// stripped, the on-disk form of the reference's scans and ALSO the device layout (16 B per point) -- mapped read-only: the payload can go
-// to ltm_scanset_upload_chunk in place, no host copy of the scan is ever made (Step 0, Session.cpp:266-302).  open() returns false for every other
-// PCD (other fields / types / encodings, truncated payload): the general reader loadPCDFile takes those.
-class MappedPCD
-{
-public:
-    MappedPCD() = default;
-    ~MappedPCD();
-    MappedPCD(const MappedPCD&) = delete;
-    MappedPCD& operator=(const MappedPCD&) = delete;
-    bool open(const std::string& path);
-    const void* records() const { return payload_; }     // n() records of 16 bytes, possibly unaligned
-    size_t n() const { return n_; }
-private:
-    void* map_ = nullptr; size_t map_len_ = 0;
-    const void* payload_ = nullptr; size_t n_ = 0;
-};
 
 // runs f(i) for i in [0, n) on up to `threads` host threads (0 = hardware concurrency); exceptions are re-thrown on the caller
 void parallelFor(size_t n, const std::function<void(size_t)>& f, unsigned threads = 0);

@@ -310,22 +310,7 @@ void Session::loadKeyframes(void)
     const unsigned n_threads = (unsigned)std::max(1, kNumOmpCores);
     std::vector<Cloud> per_kf(n_kf);
     std::vector<size_t> raw_sizes(n_kf, 0), out_sizes(n_kf, 0);
-    // Round 5: a scan file in the usual form -- DATA binary, records of exactly x y z intensity float32, which is also the
-    // device layout -- is MAPPED, and when pcl::VoxelGrid's int32-overflow early-out applies (output = input: every raw scan with more than ~65 m of
-    // extent at the 0.05 m leaf) its payload goes to the upload in place: one pass to find the extent, one copy into the pinned staging
-    // buffer, no host copy of the scan in between (round 4: read into a byte vector, decoded into a cloud, scanned, moved, staged -- Step 0 was 0.19 of
-    // the 0.42 s files -> files).  Everything else (ascii, binary_compressed, other fields, small scans the filter really thins) takes loadPCDFile.
-    std::vector<std::unique_ptr<MappedPCD>> mapped(n_kf);
-    const bool use_map = gpu_async_io_ && !(std::getenv("LTM_LOADER_MMAP") && std::string(std::getenv("LTM_LOADER_MMAP")) == "0");
     auto decode = [&](size_t k) {          // Session.cpp:272-292: loadPCDFile + per-scan pcl::VoxelGrid
-        if (use_map) {
-            std::unique_ptr<MappedPCD> mp(new MappedPCD);
-            if (mp->open(keyframe_paths_[k]) && voxelGridPassesThrough(mp->records(), mp->n(), kDownsampleVoxelSize)) {
-                raw_sizes[k] = out_sizes[k] = mp->n();
-                mapped[k] = std::move(mp);
-                return;
-            }
-        }
         Cloud points;
         std::string err;
         if (!loadPCDFile(keyframe_paths_[k], points, &err)) throw std::runtime_error(err);
@@ -382,11 +367,9 @@ void Session::loadKeyframes(void)
                     if (err) break;
                 }
                 const uint64_t n = out_sizes[k];
-                const void* src = mapped[k] ? mapped[k]->records() : static_cast<const void*>(per_kf[k].data());
-                ltmCheck(dev_->ctx, ltm_scanset_upload_chunk(dev_->ctx, up, src, sizeof(PointType), &n, 1), "ltm_scanset_upload_chunk");
+                ltmCheck(dev_->ctx, ltm_scanset_upload_chunk(dev_->ctx, up, per_kf[k].data(), sizeof(PointType), &n, 1), "ltm_scanset_upload_chunk");
                 report(k);
                 Cloud().swap(per_kf[k]);
-                mapped[k].reset();      // (the library has copied the records into its pinned staging buffer when upload_chunk returns)
             }
         } catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); next = n_kf; }
         for (auto& th : pool) th.join();

@@ -3,11 +3,6 @@
 #include "ltm_pclsort.h"
 #include "removert/utility.h"
 
-#include <fcntl.h>
-#include <sys/mman.h>
-#include <sys/stat.h>
-#include <unistd.h>
-
 #include <algorithm>
 #include <atomic>
 #include <condition_variable>
@@ -379,69 +374,6 @@ void voxelGridFilter(const Cloud& in, float leaf, Cloud& out)
         a = b;
     }
     out.swap(res);
-}
-
-bool voxelGridPassesThrough(const void* records16, size_t n, float leaf)
-{
-    if (!n) return false;
-    const float inv = 1.0f / leaf;
-    float mn[3] = {std::numeric_limits<float>::max(), std::numeric_limits<float>::max(), std::numeric_limits<float>::max()};
-    float mx[3] = {-mn[0], -mn[1], -mn[2]};
-    const unsigned char* b = static_cast<const unsigned char*>(records16);
-    for (size_t i = 0; i < n; ++i) {
-        float c[3];
-        memcpy(c, b + 16 * i, 12);
-        for (int d = 0; d < 3; ++d) { mn[d] = std::min(mn[d], c[d]); mx[d] = std::max(mx[d], c[d]); }
-    }
-    const int64_t dx = (int64_t)((mx[0] - mn[0]) * inv) + 1, dy = (int64_t)((mx[1] - mn[1]) * inv) + 1, dz = (int64_t)((mx[2] - mn[2]) * inv) + 1;
-    return dx * dy * dz > (int64_t)std::numeric_limits<int32_t>::max();
-}
-
-MappedPCD::~MappedPCD() { if (map_) munmap(map_, map_len_); }
-bool MappedPCD::open(const std::string& path)
-{
-    const int fd = ::open(path.c_str(), O_RDONLY);
-    if (fd < 0) return false;
-    struct stat st;
-    if (fstat(fd, &st) != 0 || st.st_size < 64) { ::close(fd); return false; }
-    void* m = mmap(nullptr, (size_t)st.st_size, PROT_READ, MAP_PRIVATE, fd, 0);
-    ::close(fd);
-    if (m == MAP_FAILED) return false;
-    map_ = m; map_len_ = (size_t)st.st_size;
-    // the header: text lines up to and including "DATA binary\n" (at most a few hundred bytes)
-    const char* t = static_cast<const char*>(m);
-    const size_t lim = std::min<size_t>(map_len_, 4096);
-    size_t pos = 0, n_points = 0, width = 0, height = 1;
-    bool fields_ok = false, size_ok = false, type_ok = false, count_ok = true, data_ok = false;
-    while (pos < lim) {
-        size_t e = pos;
-        while (e < lim && t[e] != '\n') ++e;
-        if (e == lim) break;
-        std::string line(t + pos, e - pos);
-        if (!line.empty() && line.back() == '\r') line.pop_back();
-        pos = e + 1;
-        if (line.empty() || line[0] == '#') continue;
-        std::stringstream ss(line);
-        std::string key, rest;
-        ss >> key;
-        std::getline(ss, rest);
-        const size_t a = rest.find_first_not_of(' ');
-        rest = a == std::string::npos ? "" : rest.substr(a);
-        while (!rest.empty() && rest.back() == ' ') rest.pop_back();
-        if (key == "FIELDS") fields_ok = rest == "x y z intensity";
-        else if (key == "SIZE") size_ok = rest == "4 4 4 4";
-        else if (key == "TYPE") type_ok = rest == "F F F F";
-        else if (key == "COUNT") count_ok = rest == "1 1 1 1";
-        else if (key == "WIDTH") width = (size_t)std::strtoull(rest.c_str(), nullptr, 10);
-        else if (key == "HEIGHT") height = (size_t)std::strtoull(rest.c_str(), nullptr, 10);
-        else if (key == "POINTS") n_points = (size_t)std::strtoull(rest.c_str(), nullptr, 10);
-        else if (key == "DATA") { data_ok = rest == "binary"; break; }
-    }
-    if (!(fields_ok && size_ok && type_ok && count_ok && data_ok)) return false;
-    if (n_points == 0) n_points = width * height;
-    if (pos + 16 * n_points > map_len_) return false;      // truncated: let the general reader report it
-    payload_ = t + pos; n_ = n_points;
-    return true;
 }
 
 // same filter; when PCL's overflow early-out applies (the usual case for a raw scan at 0.05 m) the input buffer
