@@ -135,6 +135,16 @@ int main(int argc, char** argv)
           << "7 1.5 2.5 3.5 11\n9 -1 -2 -3 12\n";
     }
     CHECK(loadPCDFile(dir + "/c.pcd", r, &err) && r.size() == 2 && r[0].x == 1.5f && r[0].intensity == 7.0f && r[1].z == -3.0f && r[1].intensity == 9.0f);
+    // binary with an extra field and another field order: the general record decoder (the in-place read is for plain x y z intensity float32 only)
+    {
+        std::ofstream f(dir + "/c2.pcd", std::ios::binary);
+        f << "VERSION 0.7\nFIELDS intensity x y z ring\nSIZE 4 4 4 4 2\nTYPE F F F F U\nCOUNT 1 1 1 1 1\nWIDTH 2\nHEIGHT 1\nPOINTS 2\nDATA binary\n";
+        const float a[4] = {7.0f, 1.5f, 2.5f, 3.5f}, b[4] = {9.0f, -1.0f, -2.0f, -3.0f};
+        const uint16_t ra = 11, rb = 12;
+        f.write(reinterpret_cast<const char*>(a), 16); f.write(reinterpret_cast<const char*>(&ra), 2);
+        f.write(reinterpret_cast<const char*>(b), 16); f.write(reinterpret_cast<const char*>(&rb), 2);
+    }
+    CHECK(loadPCDFile(dir + "/c2.pcd", r, &err) && r.size() == 2 && r[0].x == 1.5f && r[0].intensity == 7.0f && r[1].z == -3.0f && r[1].intensity == 9.0f);
     // binary_compressed: structure-of-arrays payload, LZF literal stream
     {
         std::string soa;

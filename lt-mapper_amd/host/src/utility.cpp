@@ -187,6 +187,14 @@ bool loadPCDFile(const std::string& path, Cloud& out, std::string* err)
         }
         return true;
     }
+    if (data_kind == "binary" && stride == 16 && fields.size() == 4 && ix == 0 && iy == 1 && iz == 2 && ii == 3 &&
+        std::all_of(fields.begin(), fields.end(), [](const Field& fd) { return fd.type == 'F' && fd.size == 4 && fd.count == 1; })) {
+        // the usual scan file (what pcl::io::savePCDFileBinary writes for PointXYZI, padding stripped): the records ARE PointType -- read in place
+        // (round 4 read into a byte vector and decoded field by field: two more passes over every scan on the four loader threads, Step 0 of files -> files)
+        f.read(reinterpret_cast<char*>(out.data()), (std::streamsize)(n_points * sizeof(PointType)));
+        if ((size_t)f.gcount() != n_points * sizeof(PointType)) return fail("truncated binary data");
+        return true;
+    }
     std::vector<unsigned char> raw((size_t)stride * n_points);
     if (data_kind == "binary") {
         f.read(reinterpret_cast<char*>(raw.data()), (std::streamsize)raw.size());
