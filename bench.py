@@ -93,6 +93,8 @@ def parse_args():
     ap.add_argument("--no-t-total", action="store_true", help="skip the files -> files measurement through ltm_run (default workload, one GPU)")
     ap.add_argument("--cpu-allcore", action="store_true", help="cpu_baseline: also time the oracle on all host cores now (every keyframe when the box has "
                                                                "many cores: ~3 min on 256); without it the committed measurement is quoted")
+    ap.add_argument("--no-cascade-overlap", action="store_true", help="cascade workloads: finish every hand-over (scans_updated re-gridded in PCL's order: keys to host threads and back) "
+                                                                      "before the next pair run starts, as in round 4, instead of beside the next run's query session (A/B)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--extra-out", default=None, help="sidecar file for everything the printed line does not carry (default profiles/bench_extra_latest.json)")
     ap.add_argument("--overlap-sessions", action="store_true", help="EXPERIMENT (one GPU, pair workloads): merge + grid and Step 1 of the query session on a second "
@@ -176,7 +178,7 @@ def main():
     def one_step():
         ctx.clear_caches()   # no derived data (scan range images) survives from a previous step: every step is a fresh run
         if n_sessions > 2:
-            runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:])
+            runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:], overlap=not args.no_cascade_overlap)
             return runs[-1]
         (cs, cp), (qs, qp) = loaded
         side = None

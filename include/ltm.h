@@ -220,6 +220,14 @@ int ltm_voxel_centroid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset
  * order entirely on the device: faster, but the last bit of a centroid of three or more points may differ.  This is what makes a device-resident cascade hand over the scans the reference would
  * re-load from scans_updated/ (README.md:115-118; Removerter.cpp:1658-1660). */
 int ltm_voxel_grid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset* out);
+/* The same in two halves, for a caller that has other work for the device meanwhile (the lifelong cascade: the next run's query session does not depend on
+ * the re-loaded central scans -- Session.cpp:284-289 of the NEXT process, Removerter.cpp:1653-1660).  _begin enqueues the key kernels, sends the keys to the
+ * host on the copy stream and starts the host threads that reproduce std::sort's order; it returns without waiting for either, and whatever is submitted to
+ * the context afterwards runs beside them.  _end waits for the order and finishes the grid.  `in` must stay alive and unchanged until _end, which consumes
+ * the ticket whatever it returns.  ltm_voxel_grid_scanset is _begin + _end back to back. */
+typedef struct ltm_vgs ltm_vgs;
+int ltm_voxel_grid_scanset_begin(ltm_ctx*, ltm_scanset in, float leaf, ltm_vgs** ticket);
+int ltm_voxel_grid_scanset_end(ltm_ctx*, ltm_vgs* ticket, ltm_scanset* out);
 
 /* Visibility vote, keyframes [kf_begin,kf_end) of `scans`/`poses` against `map`:
  *   scan2RangeImg (Removerter.cpp:109-156) + transformGlobalMapToLocal (utility.cpp:64-72) +

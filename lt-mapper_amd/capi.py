@@ -93,6 +93,8 @@ SIGNATURES = {
     "ltm_voxel_centroid_box": (_i, [_vp, _u64, C.POINTER(_f), C.POINTER(_f), _f, _pu64]),
     "ltm_voxel_centroid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_voxel_grid_scanset": (_i, [_vp, _u64, _f, _pu64]),
+    "ltm_voxel_grid_scanset_begin": (_i, [_vp, _u64, _f, C.POINTER(_vp)]),
+    "ltm_voxel_grid_scanset_end": (_i, [_vp, _vp, _pu64]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
     "ltm_visibility_partition": (_i, [_vp, _u64, _u64, _u64, _f, _f, _i, _pu64, _pu64, _vp]),
@@ -356,6 +358,19 @@ class Context:
     def voxel_grid_scanset(self, scans, leaf):
         out = _u64()
         self._ck(self.lib.ltm_voxel_grid_scanset(self.h, scans.h, leaf, C.byref(out)))
+        return ScanSet(self, out.value)
+
+    def voxel_grid_scanset_begin(self, scans, leaf):
+        """first half of voxel_grid_scanset: returns a ticket at once (keys on their way to the host threads); `scans` must stay alive until
+        voxel_grid_scanset_end(ticket).  Work submitted in between runs beside the transfer and the host sort."""
+        t = C.c_void_p()
+        self._ck(self.lib.ltm_voxel_grid_scanset_begin(self.h, scans.h, leaf, C.byref(t)))
+        return (t, scans)
+
+    def voxel_grid_scanset_end(self, ticket):
+        t, _scans = ticket
+        out = _u64()
+        self._ck(self.lib.ltm_voxel_grid_scanset_end(self.h, t, C.byref(out)))
         return ScanSet(self, out.value)
 
     def visibility_vote(self, cmap, scans, poses, kf_begin, kf_end, alpha, thr, mode, labels_dev_ptr):

@@ -2276,163 +2276,214 @@ int ltm_voxel_centroid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scan
     });
 }
 
+// The loader's per-scan pcl::VoxelGrid on a device-resident scan set, in two halves so that the caller can keep the GPU busy while the host threads
+// reproduce std::sort's order (round 5, VERDICT r4 item 6: on the lifelong cascade the hand-over was 199 of 1054 ms per step with the GPU idle for most of it):
+//   begin: bounding boxes, frames, keys on the device; the keys travel to a pinned buffer on the COPY stream and a coordinator thread sorts them keyframe
+//          by keyframe as soon as they are there.  Returns at once: what the caller enqueues next on the context runs beside the transfer and the sort.
+//   end:   waits for the order, sends it up, gathers, segments and averages.
+// ltm_voxel_grid_scanset = begin + end back to back.
+struct ltm_vgs {
+    ltm_scanset in = 0;
+    float leaf = 0.0f;
+    size_t nk = 0, n = 0;
+    unsigned kf_bits = 1;
+    bool pcl_order = true, trivial = false;
+    std::vector<VoxelGridFrame> frames;
+    std::unique_ptr<DevBuf> fdev, keys, idx;
+    ltm_pclsort::Entry* he = nullptr;      // pinned: the keys as they arrive, then the sorted (leaf index, point index) pairs
+    uint32_t* hi = nullptr;               // pinned: the point order
+    hipEvent_t ev_keys = nullptr;
+    std::thread coordinator;
+    std::atomic<bool> failed{false};
+    std::chrono::steady_clock::time_point t_begin, t_sorted;
+};
+namespace {
+void vgs_release(ltm_ctx* c, ltm_vgs* v)
+{
+    if (v->coordinator.joinable()) v->coordinator.join();
+    if (v->ev_keys) { (void)hipEventDestroy(v->ev_keys); v->ev_keys = nullptr; }
+    if (v->he) { pinned_free(c, v->he); v->he = nullptr; }
+    if (v->hi) { pinned_free(c, v->hi); v->hi = nullptr; }
+    delete v;
+}
+void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
+{
+    LTM_REQUIRE(ticket, "null argument");
+    LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
+    const ScanSet& s = get_ss(c, hin);
+    std::unique_ptr<ltm_vgs> v(new ltm_vgs);
+    v->in = hin; v->leaf = leaf; v->nk = s.nkf(); v->n = s.n_pts;
+    v->t_begin = v->t_sorted = std::chrono::steady_clock::now();
+    const size_t nk = v->nk, n = v->n;
+    LTM_REQUIRE(n < 0xffffffffull, "scan set too large for 32-bit point indices");
+    if (n == 0 || nk == 0) { v->trivial = true; *ticket = v.release(); return; }
+    ProfScope ps(c, "voxel_grid_scanset", (double)n, 64.0 * n);
+    DevBuf bb(c, nk * 6 * sizeof(uint32_t));
+    LTM_HIP(bbox_reduce_seg(s.d, s.off_dev, nk, n, bb.as<uint32_t>(), c->stream));
+    std::vector<uint32_t> enc(nk * 6);
+    d2h(c, enc.data(), bb.p, enc.size() * 4);
+    // pcl::VoxelGrid::applyFilter (PCL 1.10 voxel_grid.hpp): inverse leaf size in float, the "leaf size is too small"
+    // test on int64 cell counts, min_b / div_b from floor(min * inv), floor(max * inv)
+    const float inv = 1.0f / leaf;
+    v->frames.resize(nk);
+    for (size_t k = 0; k < nk; ++k) {
+        VoxelGridFrame& f = v->frames[k];
+        f.inv = inv; f.passthrough = 1;
+        for (int d = 0; d < 3; ++d) { f.min_b[d] = 0; f.div_b[d] = 1; }
+        if (s.off[k + 1] == s.off[k]) continue;
+        float mn[3], mx[3];
+        int64_t cells = 1;
+        for (int d = 0; d < 3; ++d) {
+            mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]);
+            const float ext = (mx[d] - mn[d]) * inv;
+            cells *= (int64_t)ext + 1;
+        }
+        if (cells > (int64_t)INT32_MAX) continue;           // output = input (the common case for a raw 0.05 m scan)
+        f.passthrough = 0;
+        for (int d = 0; d < 3; ++d) {
+            f.min_b[d] = (int)std::floor(mn[d] * inv);
+            f.div_b[d] = (int)std::floor(mx[d] * inv) - f.min_b[d] + 1;
+        }
+    }
+    while ((1ull << v->kf_bits) < nk) ++v->kf_bits;
+    v->fdev.reset(new DevBuf(c, nk * sizeof(VoxelGridFrame)));
+    h2d(c, v->fdev->p, v->frames.data(), nk * sizeof(VoxelGridFrame));
+    v->keys.reset(new DevBuf(c, n * 8));
+    v->idx.reset(new DevBuf(c, n * 4));
+    LTM_HIP(voxelgrid_keys_seg(s.d, s.off_dev, nk, n, v->fdev->as<VoxelGridFrame>(), v->keys->as<uint64_t>(), v->idx->as<uint32_t>(), c->stream));
+    // PCL groups the points of a leaf with std::sort on the LEAF INDEX ONLY (cloud_point_index_idx::operator<): the order of the float
+    // sums inside a voxel is whatever that (unstable) sort leaves, and a voxel with three or more points rounds differently in a
+    // different order.  Round 4 measured it against the reference's own sources compiled with stand-in headers (oracle/_ref): an
+    // input-order sum changes the last bit of ~0.05 % of the loaded points.  To hand over what the reference would re-load, the
+    // default makes the SAME std::sort call on the host, one keyframe per task (the permutation is a function of the key sequence
+    // alone): keys down (8 B / point), point order up (4 B / point), everything else stays on the device.  LTM_VOXELGRID_ORDER=input
+    // keeps the whole grid on the device with a stable radix sort (input order inside a voxel; faster, not bit-identical to PCL).
+    const char* order_env = std::getenv("LTM_VOXELGRID_ORDER");
+    v->pcl_order = !(order_env && std::strcmp(order_env, "input") == 0);
+    if (v->pcl_order) {
+        // The pinned buffer receives the 64-bit keys (keyframe id << 32 | leaf index) and is read as the (leaf index, point index) pairs PCL
+        // sorts: on this little-endian host a key's low word IS the pair's first member, and the high word -- the keyframe id, which the
+        // keyframe-by-keyframe sort does not need -- is overwritten with the point index.  ltm_pclsort::sort performs std::sort's element moves
+        // without its branch mispredictions (ltm_pclsort.h: checked against std::sort itself); LTM_VOXELGRID_STDSORT=1 calls std::sort.
+        using Entry = ltm_pclsort::Entry;
+        static_assert(sizeof(Entry) == sizeof(uint64_t) && offsetof(Entry, idx) == 0 && offsetof(Entry, cloud_point_index) == 4, "a pair overlays a key");
+        v->he = static_cast<Entry*>(pinned_alloc(c, n * 8));
+        v->hi = static_cast<uint32_t*>(pinned_alloc(c, n * 4));
+        // keys down on the copy stream, behind the kernel that makes them: the compute stream is free for whatever the caller enqueues next
+        hipEvent_t made = nullptr;
+        LTM_HIP(hipEventCreateWithFlags(&made, hipEventDisableTiming));
+        hipError_t e = hipEventRecord(made, c->stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(copy_stream(c), made, 0);
+        if (e == hipSuccess) e = hipMemcpyAsync(v->he, v->keys->p, n * 8, hipMemcpyDeviceToHost, copy_stream(c));
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&v->ev_keys, hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventRecord(v->ev_keys, copy_stream(c));
+        (void)hipEventDestroy(made);
+        if (e != hipSuccess) { ltm_vgs* raw = v.release(); (void)hipStreamSynchronize(copy_stream(c)); vgs_release(c, raw); LTM_HIP(e); }
+        const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
+        const bool use_std_sort = std_env && atoi(std_env) != 0;
+        // one keyframe per task.  A scans_updated set of 500 keyframes x 107-134 k points is ~1 s of host CPU time with ltm_pclsort (2.5 s
+        // with std::sort): 20 ms on 64 threads of the GPU box (profiles/r4_hostsort_pclsort_vs_stdsort.txt); LTM_VOXELGRID_THREADS
+        // overrides the cap of 64
+        const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+        const char* tenv = getenv("LTM_VOXELGRID_THREADS");
+        const size_t cap = tenv && atoi(tenv) > 0 ? (size_t)atoi(tenv) : 64;
+        const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw, cap), nk));
+        ltm_vgs* vp = v.get();
+        const ScanSet* sp = &s;          // (the input scan set stays alive until the ticket is ended: the caller's contract)
+        const int device = c->device;
+        vp->coordinator = std::thread([vp, sp, nt, use_std_sort, device] {
+            // the only wait of the whole order: for the keys.  One thread waits; the workers never touch the runtime
+            if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(vp->ev_keys) != hipSuccess) { vp->failed = true; return; }
+            std::atomic<size_t> next{0};
+            auto work = [&] {
+                for (;;) {
+                    const size_t k = next.fetch_add(1);
+                    if (k >= vp->nk) return;
+                    const size_t a = sp->off[k], b = sp->off[k + 1];
+                    Entry* he = vp->he; uint32_t* hi = vp->hi;
+                    if (vp->frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
+                    for (size_t i = a; i < b; ++i) he[i].cloud_point_index = (uint32_t)i;
+                    if (use_std_sort) std::sort(he + a, he + b, ltm_pclsort::Less());
+                    else ltm_pclsort::sort(he + a, he + b);
+                    for (size_t i = a; i < b; ++i) hi[i] = he[i].cloud_point_index;
+                }
+            };
+            std::vector<std::thread> pool;
+            try { for (size_t t = 1; t < nt; ++t) pool.emplace_back(work); }
+            catch (...) {}      // fewer threads than asked for: the ones that started (and this one) still finish every keyframe
+            try { work(); } catch (...) { vp->failed = true; }
+            for (std::thread& t : pool) t.join();
+            vp->t_sorted = std::chrono::steady_clock::now();
+        });
+    }
+    *ticket = v.release();
+}
+void vgs_end(ltm_ctx* c, ltm_vgs* v, ltm_scanset* out)
+{
+    LTM_REQUIRE(out, "null argument");
+    const size_t nk = v->nk, n = v->n;
+    std::vector<uint64_t> off(nk + 1, 0);
+    if (v->trivial) { *out = new_scanset(c, reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4))), std::move(off)); return; }
+    const ScanSet& s = get_ss(c, v->in);
+    LTM_REQUIRE(s.nkf() == nk && s.n_pts == n, "the scan set changed between begin and end");
+    auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    DevBuf keys2(c, n * 8), idx2(c, n * 4);
+    if (v->pcl_order) {
+        const auto t_wait = std::chrono::steady_clock::now();
+        v->coordinator.join();
+        if (v->failed) throw Err{LTM_E_DEVICE, "voxel_grid_scanset: the host order of the keys failed (keys transfer or worker threads)"};
+        const auto t_joined = std::chrono::steady_clock::now();
+        LTM_HIP(hipMemcpyAsync(idx2.p, v->hi, n * 4, hipMemcpyHostToDevice, c->stream));
+        LTM_HIP(gather_u64_by_u32(v->keys->as<uint64_t>(), idx2.as<uint32_t>(), n, keys2.as<uint64_t>(), c->stream));
+        sync(c);
+        if (getenv("LTM_VOXELGRID_TIMING"))
+            fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: begin -> order ready %.1f ms (keys down on the copy stream + the sort on host threads), "
+                            "the caller waited %.1f ms of it in end, order up + gather %.1f ms\n",
+                    n, nk, ms(v->t_begin, v->t_sorted), ms(t_wait, t_joined), ms(t_joined, std::chrono::steady_clock::now()));
+    } else {
+        const size_t stb = sort_temp_bytes(n);
+        DevBuf stemp(c, stb);
+        LTM_HIP(sort_pairs_u64(v->keys->as<uint64_t>(), keys2.as<uint64_t>(), v->idx->as<uint32_t>(), idx2.as<uint32_t>(), n, 32 + v->kf_bits, stemp.p, stb, c->stream));
+    }
+    ProfScope ps(c, "voxel_grid_scanset", 0.0, 0.0);
+    DevBuf heads(c, n), pos(c, n * 4);
+    LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
+    const size_t tb = scan_temp_bytes(n);
+    DevBuf temp(c, tb);
+    LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
+    const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
+    // the keys lead with the keyframe id (and the host order works keyframe by keyframe), so keyframe k still occupies positions [off[k], off[k+1])
+    DevBuf bout(c, (nk + 1) * 4);
+    LTM_HIP(gather_u32(pos.as<uint32_t>(), s.off_dev, nk + 1, n, (uint32_t)nvox, bout.as<uint32_t>(), c->stream));
+    std::vector<uint32_t> b(nk + 1);
+    d2h(c, b.data(), bout.p, (nk + 1) * 4);
+    for (size_t k = 0; k <= nk; ++k) off[k] = b[k];
+    DevBuf starts(c, nvox * 4);
+    LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
+    float4* o = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nvox, 1) * sizeof(float4)));
+    LTM_HIP(voxelgrid_centroids(s.d, keys2.as<uint64_t>(), idx2.as<uint32_t>(), starts.as<uint32_t>(), v->fdev->as<VoxelGridFrame>(), nvox, n, o, c->stream));
+    *out = new_scanset(c, o, std::move(off));
+}
+} // namespace
+
+int ltm_voxel_grid_scanset_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
+{
+    if (ticket) *ticket = nullptr;
+    return guarded(c, [&] { vgs_begin(c, hin, leaf, ticket); });
+}
+int ltm_voxel_grid_scanset_end(ltm_ctx* c, ltm_vgs* ticket, ltm_scanset* out)
+{
+    if (!ticket) return LTM_E_INVALID;
+    const int rc = guarded(c, [&] { vgs_end(c, ticket, out); });
+    if (c) { (void)hipStreamSynchronize(c->stream); vgs_release(c, ticket); }      // the ticket is consumed either way (its buffers may still be read by queued work)
+    return rc;
+}
 int ltm_voxel_grid_scanset(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_scanset* out)
 {
-    return guarded(c, [&] {
-        LTM_REQUIRE(out, "null argument");
-        LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
-        const ScanSet& s = get_ss(c, hin);
-        const size_t nk = s.nkf();
-        const size_t n = s.n_pts;
-        LTM_REQUIRE(n < 0xffffffffull, "scan set too large for 32-bit point indices");
-        std::vector<uint64_t> off(nk + 1, 0);
-        if (n == 0 || nk == 0) {
-            *out = new_scanset(c, reinterpret_cast<float4*>(c->pool.alloc(sizeof(float4))), std::move(off));
-            return;
-        }
-        ProfScope ps(c, "voxel_grid_scanset", (double)n, 64.0 * n);
-        DevBuf bb(c, nk * 6 * sizeof(uint32_t));
-        LTM_HIP(bbox_reduce_seg(s.d, s.off_dev, nk, n, bb.as<uint32_t>(), c->stream));
-        std::vector<uint32_t> enc(nk * 6);
-        d2h(c, enc.data(), bb.p, enc.size() * 4);
-        // pcl::VoxelGrid::applyFilter (PCL 1.10 voxel_grid.hpp): inverse leaf size in float, the "leaf size is too small"
-        // test on int64 cell counts, min_b / div_b from floor(min * inv), floor(max * inv)
-        const float inv = 1.0f / leaf;
-        std::vector<VoxelGridFrame> frames(nk);
-        for (size_t k = 0; k < nk; ++k) {
-            VoxelGridFrame& f = frames[k];
-            f.inv = inv; f.passthrough = 1;
-            for (int d = 0; d < 3; ++d) { f.min_b[d] = 0; f.div_b[d] = 1; }
-            if (s.off[k + 1] == s.off[k]) continue;
-            float mn[3], mx[3];
-            int64_t cells = 1;
-            for (int d = 0; d < 3; ++d) {
-                mn[d] = bbox_decode(enc[6 * k + d]); mx[d] = bbox_decode(enc[6 * k + 3 + d]);
-                const float ext = (mx[d] - mn[d]) * inv;
-                cells *= (int64_t)ext + 1;
-            }
-            if (cells > (int64_t)INT32_MAX) continue;           // output = input (the common case for a raw 0.05 m scan)
-            f.passthrough = 0;
-            for (int d = 0; d < 3; ++d) {
-                f.min_b[d] = (int)std::floor(mn[d] * inv);
-                f.div_b[d] = (int)std::floor(mx[d] * inv) - f.min_b[d] + 1;
-            }
-        }
-        unsigned kf_bits = 1;
-        while ((1ull << kf_bits) < nk) ++kf_bits;
-        DevBuf fdev(c, nk * sizeof(VoxelGridFrame));
-        h2d(c, fdev.p, frames.data(), nk * sizeof(VoxelGridFrame));
-        DevBuf keys(c, n * 8), keys2(c, n * 8), idx(c, n * 4), idx2(c, n * 4);
-        LTM_HIP(voxelgrid_keys_seg(s.d, s.off_dev, nk, n, fdev.as<VoxelGridFrame>(), keys.as<uint64_t>(), idx.as<uint32_t>(), c->stream));
-        // PCL groups the points of a leaf with std::sort on the LEAF INDEX ONLY (cloud_point_index_idx::operator<): the order of the float
-        // sums inside a voxel is whatever that (unstable) sort leaves, and a voxel with three or more points rounds differently in a
-        // different order.  Round 4 measured it against the reference's own sources compiled with stand-in headers (oracle/_ref): an
-        // input-order sum changes the last bit of ~0.05 % of the loaded points.  To hand over what the reference would re-load, the
-        // default makes the SAME std::sort call on the host, one keyframe per task (the permutation is a function of the key sequence
-        // alone): keys down (8 B / point), point order up (4 B / point), everything else stays on the device.  LTM_VOXELGRID_ORDER=input
-        // keeps the whole grid on the device with a stable radix sort (input order inside a voxel; faster, not bit-identical to PCL).
-        const char* order_env = std::getenv("LTM_VOXELGRID_ORDER");
-        const bool pcl_order = !(order_env && std::strcmp(order_env, "input") == 0);
-        if (pcl_order) {
-            const bool timing = getenv("LTM_VOXELGRID_TIMING") != nullptr;
-            auto now = [] { return std::chrono::steady_clock::now(); };
-            auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-            const auto t0 = now();
-            // The pinned buffer receives the 64-bit keys (keyframe id << 32 | leaf index) and is read as the (leaf index, point index) pairs PCL
-            // sorts: on this little-endian host a key's low word IS the pair's first member, and the high word -- the keyframe id, which the
-            // keyframe-by-keyframe sort does not need -- is overwritten with the point index.  ltm_pclsort::sort performs std::sort's element moves
-            // without its branch mispredictions (ltm_pclsort.h: checked against std::sort itself); LTM_VOXELGRID_STDSORT=1 calls std::sort.
-            using Entry = ltm_pclsort::Entry;
-            static_assert(sizeof(Entry) == sizeof(uint64_t) && offsetof(Entry, idx) == 0 && offsetof(Entry, cloud_point_index) == 4, "a pair overlays a key");
-            Entry* he = static_cast<Entry*>(pinned_alloc(c, n * 8));
-            uint32_t* hi = static_cast<uint32_t*>(pinned_alloc(c, n * 4));
-            const auto t1 = now();
-            auto t2 = t1, t3 = t1;
-            // The keys come down in ONE piece and the sort starts when they are there (67 M keys = 0.54 GB: 10 ms; the sort of 500 keyframes:
-            // 20 ms on 64 threads).  LTM_VOXELGRID_CHUNKS=G > 1 sends them in G chunks of whole keyframes with an event behind each, so that the
-            // first keyframes are sorted while the rest is still on the link -- measured SLOWER on the GPU box (33-35 ms against 10 + 20.5 ms,
-            // profiles/r4_voxel_grid_scanset_chunked_keys.txt): 64 threads waiting on events spin, and spinning threads eat the 16 CPUs' worth of
-            // time the container has.  Kept as a switch for hosts without such a quota.
-            const char* genv = getenv("LTM_VOXELGRID_CHUNKS");
-            const size_t G = std::min<size_t>(genv && atoi(genv) > 0 ? (size_t)atoi(genv) : 1, std::max<size_t>(nk, 1));
-            std::vector<size_t> chunk_kf(G + 1);
-            for (size_t g = 0; g <= G; ++g) chunk_kf[g] = nk * g / G;
-            std::vector<hipEvent_t> ev(G, nullptr);
-            auto drop_events = [&] { for (hipEvent_t& e : ev) if (e) { (void)hipEventDestroy(e); e = nullptr; } };
-            try {
-                for (size_t g = 0; g < G; ++g) {
-                    LTM_HIP(hipEventCreateWithFlags(&ev[g], hipEventDisableTiming));
-                    const size_t a = s.off[chunk_kf[g]], b = s.off[chunk_kf[g + 1]];
-                    if (b > a) LTM_HIP(hipMemcpyAsync(he + a, keys.as<uint64_t>() + a, (b - a) * 8, hipMemcpyDeviceToHost, c->stream));
-                    LTM_HIP(hipEventRecord(ev[g], c->stream));
-                }
-                if (G == 1) { sync(c); t2 = now(); }       // the calling thread waits once; no worker ever waits
-                const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
-                const bool use_std_sort = std_env && atoi(std_env) != 0;
-                std::atomic<size_t> next{0};
-                std::atomic<bool> failed{false};
-                auto work = [&] {
-                    if (G > 1 && hipSetDevice(c->device) != hipSuccess) { failed = true; return; }      // only a thread that waits for an event talks to the runtime
-                    size_t g = 0;
-                    for (;;) {
-                        const size_t k = next.fetch_add(1);      // keyframes are handed out in ascending order: so are the chunks waited for
-                        if (k >= nk || failed) return;
-                        while (k >= chunk_kf[g + 1]) ++g;
-                        if (G > 1 && hipEventSynchronize(ev[g]) != hipSuccess) { failed = true; return; }
-                        const size_t a = s.off[k], b = s.off[k + 1];
-                        if (frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
-                        for (size_t i = a; i < b; ++i) he[i].cloud_point_index = (uint32_t)i;
-                        if (use_std_sort) std::sort(he + a, he + b, ltm_pclsort::Less());
-                        else ltm_pclsort::sort(he + a, he + b);
-                        for (size_t i = a; i < b; ++i) hi[i] = he[i].cloud_point_index;
-                    }
-                };
-                // one keyframe per task.  A scans_updated set of 500 keyframes x 107-134 k points is ~1 s of host CPU time with ltm_pclsort (2.5 s
-                // with std::sort): 20 ms on 64 threads of the GPU box (profiles/r4_hostsort_pclsort_vs_stdsort.txt); LTM_VOXELGRID_THREADS
-                // overrides the cap of 64
-                const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
-                const char* tenv = getenv("LTM_VOXELGRID_THREADS");
-                const size_t cap = tenv && atoi(tenv) > 0 ? (size_t)atoi(tenv) : 64;
-                const size_t nt = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(hw, cap), nk));
-                std::vector<std::thread> pool;
-                for (size_t t = 1; t < nt; ++t) pool.emplace_back(work);
-                work();
-                for (std::thread& t : pool) t.join();
-                if (failed) throw Err{LTM_E_DEVICE, "voxel_grid_scanset: waiting for the keys of a keyframe chunk failed"};
-                t3 = now();
-                if (G > 1) t2 = t1;
-                LTM_HIP(hipMemcpyAsync(idx2.p, hi, n * 4, hipMemcpyHostToDevice, c->stream));
-                LTM_HIP(gather_u64_by_u32(keys.as<uint64_t>(), idx2.as<uint32_t>(), n, keys2.as<uint64_t>(), c->stream));
-                sync(c);
-            } catch (...) { (void)hipStreamSynchronize(c->stream); drop_events(); pinned_free(c, he); pinned_free(c, hi); throw; }
-            drop_events();
-            pinned_free(c, he); pinned_free(c, hi);
-            if (timing)
-                fprintf(stderr, "[ltm] voxel_grid_scanset (PCL order): %zu points, %zu keyframes: pinned buffers %.1f ms, keys down (%zu chunk%s) %.1f ms, the sort on host threads %s%.1f ms, order up + gather %.1f ms\n",
-                        n, nk, ms(t0, t1), G, G > 1 ? "s" : "", ms(t1, t2), G > 1 ? "(keys arriving meanwhile) " : "", ms(t2, t3), ms(t3, now()));
-        } else {
-            const size_t stb = sort_temp_bytes(n);
-            DevBuf stemp(c, stb);
-            LTM_HIP(sort_pairs_u64(keys.as<uint64_t>(), keys2.as<uint64_t>(), idx.as<uint32_t>(), idx2.as<uint32_t>(), n, 32 + kf_bits, stemp.p, stb, c->stream));
-        }
-        DevBuf heads(c, n), pos(c, n * 4);
-        LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
-        const size_t tb = scan_temp_bytes(n);
-        DevBuf temp(c, tb);
-        LTM_HIP(exclusive_scan_u8(heads.as<uint8_t>(), pos.as<uint32_t>(), n, temp.p, tb, c->stream));
-        const size_t nvox = scan_total_u8(c, heads.as<uint8_t>(), pos.as<uint32_t>(), n);
-        // the keys lead with the keyframe id (and the host order works keyframe by keyframe), so keyframe k still occupies positions [off[k], off[k+1])
-        DevBuf bout(c, (nk + 1) * 4);
-        LTM_HIP(gather_u32(pos.as<uint32_t>(), s.off_dev, nk + 1, n, (uint32_t)nvox, bout.as<uint32_t>(), c->stream));
-        std::vector<uint32_t> b(nk + 1);
-        d2h(c, b.data(), bout.p, (nk + 1) * 4);
-        for (size_t k = 0; k <= nk; ++k) off[k] = b[k];
-        DevBuf starts(c, nvox * 4);
-        LTM_HIP(segment_starts(heads.as<uint8_t>(), pos.as<uint32_t>(), n, starts.as<uint32_t>(), c->stream));
-        float4* o = reinterpret_cast<float4*>(c->pool.alloc(std::max<size_t>(nvox, 1) * sizeof(float4)));
-        LTM_HIP(voxelgrid_centroids(s.d, keys2.as<uint64_t>(), idx2.as<uint32_t>(), starts.as<uint32_t>(), fdev.as<VoxelGridFrame>(), nvox, n, o, c->stream));
-        *out = new_scanset(c, o, std::move(off));
-    });
+    ltm_vgs* t = nullptr;
+    const int rc = ltm_voxel_grid_scanset_begin(c, hin, leaf, &t);
+    if (rc != LTM_OK) return rc;
+    return ltm_voxel_grid_scanset_end(c, t, out);
 }
 
 int ltm_visibility_vote(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_poses hp, size_t kf_begin, size_t kf_end, float alpha,

@@ -235,6 +235,8 @@ class ShardedOps:
             return LazyScans(self, self.ops.voxel_scanset(s.local, leaf), s.kb, s.ke, s.n)
         return self.ops.voxel_scanset(s, leaf)
 
+    supports_deferred_grid = False      # (cascade.run_cascade: the two-halves hand-over is a one-context path)
+
     def voxel_grid_scanset(self, s, leaf):      # per-keyframe, like voxel_scanset
         if isinstance(s, LazyScans):
             return LazyScans(self, self.ops.voxel_grid_scanset(s.local, leaf), s.kb, s.ke, s.n)
@@ -354,6 +356,12 @@ class CommMeter:
     def zip_concat(self, a, b, c): return self._mark(self.ops.zip_concat(a, b, c))
     def voxel_scanset(self, s, leaf): return self._mark(self.ops.voxel_scanset(s, leaf))
     def voxel_grid_scanset(self, s, leaf): return self._mark(self.ops.voxel_grid_scanset(s, leaf)) if self._is_local(s) else self.ops.voxel_grid_scanset(s, leaf)
+
+    def voxel_grid_scanset_begin(self, s, leaf): return (self.ops.voxel_grid_scanset_begin(s, leaf), self._is_local(s))
+
+    def voxel_grid_scanset_end(self, ticket):
+        out = self.ops.voxel_grid_scanset_end(ticket[0])
+        return self._mark(out) if ticket[1] else out
     def preclean(self, s, radius): return self._mark(self.ops.preclean(s, radius)) if self._is_local(s) else self.ops.preclean(s, radius)
 
     def merge_to_global(self, scans, poses):

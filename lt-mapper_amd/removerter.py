@@ -59,6 +59,10 @@ class HipOps:
         return self.voxel_batch([self.merge_to_global(s, p) for s, p in merges] + list(clouds), leaf)
     def voxel_scanset(self, s, leaf): return self.ctx.voxel_centroid_scanset(s, leaf)
     def voxel_grid_scanset(self, s, leaf): return self.ctx.voxel_grid_scanset(s, leaf)      # the loader's pcl::VoxelGrid, Session.cpp:284-289
+    supports_deferred_grid = True
+
+    def voxel_grid_scanset_begin(self, s, leaf): return self.ctx.voxel_grid_scanset_begin(s, leaf)      # ... in two halves (cascade hand-over)
+    def voxel_grid_scanset_end(self, ticket): return self.ctx.voxel_grid_scanset_end(ticket)
     def preclean(self, s, radius): return self.ctx.preclean(s, radius)                      # Session.cpp:506-533
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
     def reproject(self, cmap, poses, alpha): return self.ctx.reproject(cmap, poses, alpha)
@@ -164,6 +168,10 @@ class Removerter:
         self.ops, self.P = ops, params
         self.central_sess_, self.query_sess_ = central, query
         self.query_side = query_side
+        # cascade.run_cascade: a callable that delivers the central session's scans (the previous run's scans_updated, re-gridded: its host half is still
+        # running when this run starts).  While it is set, run() takes the query session's makeGlobalMap + Step-1 chain first -- it does not depend on the
+        # central scans (Removerter.cpp:1584-1591 runs the two sessions one after the other, either order gives the same clouds) -- and asks for the scans then
+        self.central_scans_future = None
         self.on_stage = None
         self.outputs = {}        # name -> cloud handle, the *.pcd maps of the output protocol
         self.timings = {}
@@ -297,13 +305,26 @@ class Removerter:
             self.outputs["central_sess_high_dyn"], self.outputs["query_sess_high_dyn"] = hd[id(C)], hd[id(Q)]
         self._tick("remove_high_dynamic", t0)
 
+    def _queryThenCentral(self):
+        """makeGlobalMap + the Step-1 chains with the query session first; the central scans are asked for when the query session's chain has been issued"""
+        C, Q = self.central_sess_, self.query_sess_
+        for s in (Q, C):
+            if s is C:
+                s.keyframe_scans_ = self.central_scans_future()
+                self.central_scans_future = None
+            s.map_global_curr_ = self.octreeDownsampling(self.ops.merge_to_global(s.keyframe_scans_, s.keyframe_poses), self.P.downsample_voxel_size)
+            self.outputs["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_curr_
+            self._removeHighDynamicOf(s)
+
     def removeHighDynamicPoints(self):                  # Removerter.cpp:1580-1604
         groups = self._rankGroups()
         if groups is not None:
             return self._sessionsOnRankGroups(*groups)
         t0 = time.perf_counter()
         C, Q = self.central_sess_, self.query_sess_
-        if self.query_side is not None:
+        if self.central_scans_future is not None:
+            self._queryThenCentral()
+        elif self.query_side is not None:
             self._sessionsSideBySide()
         else:
             self._removeHighDynamicOf(C)
@@ -445,6 +466,9 @@ class Removerter:
                             query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
 
     def run(self):
-        if self.query_side is None and self._rankGroups() is None:
+        if self.central_scans_future is not None and (self.query_side is not None or self._rankGroups() is not None):
+            self.central_sess_.keyframe_scans_ = self.central_scans_future()      # (the deferred hand-over is a single-context path)
+            self.central_scans_future = None
+        if self.query_side is None and self._rankGroups() is None and self.central_scans_future is None:
             self.makeGlobalMap()         # otherwise part of the two sessions' separate chains (removeHighDynamicPoints)
         self.run_steps_1_to_3()
