@@ -1,6 +1,8 @@
 // ltm_api.cpp -- C ABI of libltm_hip.so (include/ltm.h): context, device memory pool, handles and the
 // per-stage orchestration of the gfx950 kernels in ltm_kernels.hip.  No CPU fallback: every stage runs
-// on the device or fails with an error code.
+// on the device or fails with an error code.  One stage has a host HALF by design: ltm_voxel_grid_scanset's default order -- the permutation
+// pcl::VoxelGrid's std::sort leaves the points of a voxel in is a property of libstdc++'s introsort, reproduced on host threads (ltm_pclsort.h, which
+// assumes that library's algorithm: checked against std::sort itself in tests/test_abi.py); keys down, point order up, everything else on the device.
 #include "ltm.h"
 #include "ltm_pclsort.h"
 #include "ltm_kernels.h"

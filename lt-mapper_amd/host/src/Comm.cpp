@@ -30,7 +30,7 @@ struct LocalGroup
     // a failure anywhere must release every rank, whichever group's barrier it is parked in: the world group knows its session groups and they
     // know it
     std::vector<std::shared_ptr<LocalGroup>> subs;
-    LocalGroup* parent = nullptr;
+    std::weak_ptr<LocalGroup> parent;      // (weak: the world group owns its session groups; a session-group endpoint may outlive the world endpoints)
     explicit LocalGroup(int w) : world(w), stage((size_t)w), scalars((size_t)w, 0), a2a_sizes((size_t)w) {}
 
     void barrier()
@@ -50,9 +50,11 @@ struct LocalGroup
     }
     void fail()
     {
-        LocalGroup* top = parent ? parent : this;
+        const std::shared_ptr<LocalGroup> up = parent.lock();
+        LocalGroup* top = up ? up.get() : this;
         top->failHere();
         for (auto& s : top->subs) s->failHere();
+        failHere();      // (a session group whose world group is gone still releases its own ranks)
     }
 };
 
@@ -196,7 +198,7 @@ std::vector<std::shared_ptr<Comm>> makeLocalComms(int world)
     if (sessionGroupsEnabled(world)) {
         for (int color = 0; color < 2; ++color) {      // even ranks: central session's group, odd ranks: query session's
             auto sg = std::make_shared<LocalGroup>(world / 2);
-            sg->parent = g.get();
+            sg->parent = g;
             g->subs.push_back(sg);
             for (int r = color; r < world; r += 2) ends[(size_t)r]->setSessionGroup(std::make_shared<LocalComm>(sg, r / 2));
         }

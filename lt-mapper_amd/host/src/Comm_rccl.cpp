@@ -32,12 +32,18 @@ struct RcclGroup
     std::vector<ncclComm_t> comms;
     std::vector<int> devs;
     std::mutex mx;                 // abort() may come from any rank's thread
+    // the session groups of a world group (its even / odd ranks): a rank that fails may have peers parked in a collective of EITHER of its groups, so an
+    // abort of the world releases them too (only the world's communicators used to be aborted; LocalGroup::fail already did this)
+    std::vector<std::shared_ptr<RcclGroup>> subs;
     // an aborted communicator is already released by ncclCommAbort: its slot is nulled there so that it is not destroyed twice
     ~RcclGroup() { for (ncclComm_t c : comms) if (c) ncclCommDestroy(c); }
     void abortAll()
     {
-        std::lock_guard<std::mutex> lk(mx);
-        for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+        {
+            std::lock_guard<std::mutex> lk(mx);
+            for (ncclComm_t& c : comms) if (c) { (void)ncclCommAbort(c); c = nullptr; }
+        }
+        for (const std::shared_ptr<RcclGroup>& s : subs) s->abortAll();
     }
 };
 
@@ -190,6 +196,7 @@ std::vector<std::shared_ptr<Comm>> makeRcclComms(const std::vector<int>& devs)
             for (size_t r = color; r < devs.size(); r += 2) sg->devs.push_back(devs[r]);
             sg->comms.assign(sg->devs.size(), nullptr);
             LTM_NCCL(ncclCommInitAll(sg->comms.data(), (int)sg->devs.size(), sg->devs.data()));
+            g->subs.push_back(sg);
             for (size_t r = color; r < devs.size(); r += 2) ends[r]->setSessionGroup(std::make_shared<RcclComm>(sg, (int)(r / 2)));
         }
     }
