@@ -434,7 +434,8 @@ def slim_line(full, extra_path):
                            "share_of_step", "valu_frac", "hbm_algorithmic_frac", "hbm_compulsory_frac", "hbm_measured_frac", "traffic_over_compulsory", "pmc")
     cb = full.get("cpu_baseline")
     if isinstance(cb, dict):
-        o = _num(cb, "value", "unit", "cores", "kind", "measured_s", "keyframe_stride", "extrapolated_step_s", "host_cores", "cgroup_cpu_quota_cpus")
+        o = _num(cb, "value", "unit", "cores", "kind", "measured_s", "keyframe_stride", "extrapolated_step_s", "host_cores", "cgroup_cpu_quota_cpus",
+                 "host", "cpu_model", "quoted_from", "same_oracle_sources")
         o["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:200]
         ac = cb.get("all_cores")
         if isinstance(ac, dict):
