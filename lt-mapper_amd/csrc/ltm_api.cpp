@@ -134,7 +134,9 @@ struct Pending { int cls; hipEvent_t a, b; };
 struct PendingLive { int cls; int slot; double max_pts; double image_bytes; double map_pts; double image_bytes_c; };
 struct PinnedBlock { void* p; size_t bytes; bool in_use; };
 // pipelined scan-set upload: device array of `cap` points filled front to back, two pinned staging buffers in flight
-struct UploadState { float4* d = nullptr; size_t cap = 0, n = 0; std::vector<uint64_t> off{0}; void* stage[2] = {nullptr, nullptr}; size_t stage_sz[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int next = 0; };
+// (fill: bytes gathered in stage[next] and not yet on their way; flushed: points whose DMA has been issued -- round 5: chunks are gathered into 16 MB
+// staging buffers before a DMA is issued; one hipMemcpyAsync + event per 54 k-point scan cost ~0.1 ms of fixed overhead each, 55 ms per 500-keyframe session)
+struct UploadState { float4* d = nullptr; size_t cap = 0, n = 0; std::vector<uint64_t> off{0}; void* stage[2] = {nullptr, nullptr}; size_t stage_sz[2] = {0, 0}; hipEvent_t ev[2] = {nullptr, nullptr}; bool busy[2] = {false, false}; int next = 0; size_t fill = 0, flushed = 0; };
 
 } // namespace
 
@@ -165,6 +167,52 @@ struct FetchRing {
     std::deque<ltm_fetch*> jobs;
     bool stop = false;
     std::thread worker;
+};
+
+// staging copies of the pipelined upload (host memory -> pinned buffer) split over a few helper threads: the feeder thread's single memcpy of every scan was
+// what bounded Step 0 of files -> files once the loader decoded on more than four threads (round 5)
+struct CopyPool {
+    static constexpr unsigned kHelpers = 3;
+    std::vector<std::thread> th;
+    std::mutex m;
+    std::condition_variable cv_go, cv_done;
+    const char* src = nullptr; char* dst = nullptr; size_t bytes = 0;
+    uint64_t gen = 0; unsigned pending = 0; bool stop = false;
+    void part(unsigned i) const
+    {
+        const size_t n = kHelpers + 1, lo = bytes * i / n & ~(size_t)63, hi = i + 1 == n ? bytes : (bytes * (i + 1) / n & ~(size_t)63);
+        if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
+    }
+    void worker(unsigned i)
+    {
+        uint64_t seen = 0;
+        for (;;) {
+            { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
+            part(i + 1);
+            { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_one(); }
+        }
+    }
+    void copy(void* d, const void* s, size_t n)
+    {
+        if (n < ((size_t)256 << 10)) { memcpy(d, s, n); return; }
+        if (th.empty()) {
+            try { for (unsigned i = 0; i < kHelpers; ++i) th.emplace_back(&CopyPool::worker, this, i); }
+            catch (...) { if (th.size() < kHelpers) { shutdown(); memcpy(d, s, n); return; } }
+        }
+        { std::lock_guard<std::mutex> lk(m); src = static_cast<const char*>(s); dst = static_cast<char*>(d); bytes = n; pending = kHelpers; ++gen; }
+        cv_go.notify_all();
+        part(0);
+        std::unique_lock<std::mutex> lk(m);
+        cv_done.wait(lk, [&] { return pending == 0; });
+    }
+    void shutdown()
+    {
+        { std::lock_guard<std::mutex> lk(m); stop = true; }
+        cv_go.notify_all();
+        for (std::thread& t : th) if (t.joinable()) t.join();
+        th.clear();
+        stop = false;
+    }
 };
 
 struct ltm_ctx {
@@ -223,6 +271,7 @@ struct ltm_ctx {
     hipStream_t copy_stream = nullptr;
     std::vector<PinnedBlock> pinned;
     std::unordered_map<uint64_t, UploadState> uploads;
+    CopyPool copy_pool;                         // helper threads of the staging copies (created by the first large ltm_scanset_upload_chunk)
 };
 
 namespace {
@@ -1389,6 +1438,7 @@ void ltm_destroy(ltm_ctx* c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
     destroy_ring(c);
+    c->copy_pool.shutdown();
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     if (c->live_counts) (void)hipFree(c->live_counts);
@@ -1692,6 +1742,22 @@ int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
 }
 
 // ------------------------------------------------------------------ pipelined upload / async fetch
+namespace {
+// what has been gathered in the current staging buffer goes to the device array behind the points already sent; the other buffer becomes current
+void upload_flush(ltm_ctx* c, UploadState& u)
+{
+    if (!u.fill) return;
+    const int b = u.next;
+    if (!u.ev[b]) LTM_HIP(hipEventCreateWithFlags(&u.ev[b], hipEventDisableTiming));
+    LTM_HIP(hipMemcpyAsync(u.d + u.flushed, u.stage[b], u.fill, hipMemcpyHostToDevice, copy_stream(c)));
+    LTM_HIP(hipEventRecord(u.ev[b], copy_stream(c)));
+    u.busy[b] = true;
+    u.flushed += u.fill / 16;
+    u.fill = 0;
+    u.next ^= 1;
+}
+} // namespace
+
 int ltm_scanset_upload_begin(ltm_ctx* c, size_t capacity_points, ltm_upload* up)
 {
     return guarded(c, [&] {
@@ -1720,24 +1786,26 @@ int ltm_scanset_upload_chunk(ltm_ctx* c, ltm_upload up, const void* pts, size_t 
         LTM_REQUIRE(stride == 16 || stride >= 32 || n == 0, "stride must be 16 or >= 32");
         LTM_REQUIRE(u.n + n <= u.cap, "upload exceeds the announced capacity");
         if (n) {
+            static constexpr size_t kStage = (size_t)16 << 20;
+            if (u.fill && u.fill + n * 16 > u.stage_sz[u.next]) upload_flush(c, u);      // does not fit behind what is gathered: send that first
             const int b = u.next;
-            u.next ^= 1;
             if (u.busy[b]) { LTM_HIP(hipEventSynchronize(u.ev[b])); u.busy[b] = false; }      // its previous DMA must have drained
-            if (u.stage_sz[b] < n * 16) {
+            const size_t want = std::max(kStage, n * 16);
+            if (u.stage_sz[b] < want) {
                 if (u.stage[b]) pinned_free(c, u.stage[b]);
-                u.stage[b] = pinned_alloc(c, n * 16);
-                u.stage_sz[b] = n * 16;
+                u.stage[b] = nullptr; u.stage_sz[b] = 0;
+                u.stage[b] = pinned_alloc(c, want);
+                u.stage_sz[b] = want;
             }
-            if (stride == 16) memcpy(u.stage[b], pts, n * 16);
+            unsigned char* dst = static_cast<unsigned char*>(u.stage[b]) + u.fill;
+            if (stride == 16) c->copy_pool.copy(dst, pts, n * 16);
             else {
                 const unsigned char* s = static_cast<const unsigned char*>(pts);
-                float* o = static_cast<float*>(u.stage[b]);
+                float* o = reinterpret_cast<float*>(dst);
                 for (size_t i = 0; i < n; ++i) { memcpy(o + 4 * i, s + i * stride, 12); memcpy(o + 4 * i + 3, s + i * stride + 16, 4); }
             }
-            if (!u.ev[b]) LTM_HIP(hipEventCreateWithFlags(&u.ev[b], hipEventDisableTiming));
-            LTM_HIP(hipMemcpyAsync(u.d + u.n, u.stage[b], n * 16, hipMemcpyHostToDevice, copy_stream(c)));
-            LTM_HIP(hipEventRecord(u.ev[b], copy_stream(c)));
-            u.busy[b] = true;
+            u.fill += n * 16;
+            if (u.fill >= u.stage_sz[b]) upload_flush(c, u);
         }
         for (size_t k = 0; k < n_kf; ++k) { u.n += kf_sizes[k]; u.off.push_back(u.n); }
     });
@@ -1749,6 +1817,7 @@ int ltm_scanset_upload_end(ltm_ctx* c, ltm_upload up, ltm_scanset* out)
         LTM_REQUIRE(out, "null argument");
         auto it = c->uploads.find(up);
         LTM_REQUIRE(it != c->uploads.end(), "invalid upload handle");
+        upload_flush(c, it->second);
         UploadState u = std::move(it->second);
         c->uploads.erase(it);
         LTM_HIP(hipStreamSynchronize(copy_stream(c)));
@@ -1809,7 +1878,7 @@ static FetchRing* ensure_ring(ltm_ctx* c)
     if (c->ring) return c->ring;
     std::unique_ptr<FetchRing> r(new FetchRing());
     r->device = c->device;
-    size_t mb = 32, n_slots = 8;
+    size_t mb = 8, n_slots = 8;      // 64 MB pinned once (~15 ms; round 4's 8 x 32 MB cost 45 ms of page-locking inside the first fetch, i.e. inside makeGlobalMap's map write)
     if (const char* v = getenv("LTM_FETCH_CHUNK_MB")) mb = (size_t)std::max(1, atoi(v));
     if (const char* v = getenv("LTM_FETCH_SLOTS")) n_slots = (size_t)std::max(2, atoi(v));
     r->slot_bytes = mb << 20;

@@ -1,6 +1,7 @@
 // Removerter.cpp -- mirror of ltremovert/src/Removerter.cpp over the C ABI (include/ltm.h).
 #include "removert/Removerter.h"
 
+#include <cstdlib>
 #include <sstream>
 
 #include <chrono>
@@ -839,11 +840,20 @@ void Removerter::run(void)                                                      
     using clk = std::chrono::steady_clock;
     const auto t0 = clk::now();
     // # Step 0: Preparations
-    loadSessionInfo();
-    parseKeyframes();
-    loadKeyframes();
-    precleaningKeyframes(2.5);
-    makeGlobalMap();
+    const bool t0_detail = std::getenv("LTM_STEP0_TIMING") != nullptr;      // where Step 0 goes, on stderr
+    auto lap = [&, last = t0](const char* what) mutable {
+        if (!t0_detail) return;
+        ltm_synchronize(dev_->ctx);
+        const auto now = clk::now();
+        std::fprintf(stderr, "[ltm_run] step 0: %-22s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
+    loadSessionInfo(); lap("loadSessionInfo");
+    parseKeyframes(); lap("parseKeyframes");
+    central_sess_.loadKeyframes(); lap("loadKeyframes central");
+    query_sess_.loadKeyframes(); lap("loadKeyframes query");
+    precleaningKeyframes(2.5); lap("precleaningKeyframes");
+    makeGlobalMap(); lap("makeGlobalMap");
     const auto t1 = clk::now();
     // # Step 1: HD noise removal
     removeHighDynamicPoints();

@@ -2,6 +2,8 @@
 // keyframe selection, PCD loading) is restated here; every loop over points is a call into libltm_hip.so.
 #include "removert/Session.h"
 
+#include <cstdio>
+#include <chrono>
 #include <memory>
 #include <algorithm>
 #include <cmath>
@@ -307,16 +309,30 @@ void Session::loadKeyframes(void)
     const int cout_interval{10};
     if (!logQuiet()) std::cout << std::endl << " ... (display every " << cout_interval << " readings) ..." << std::endl;
     const size_t n_kf = keyframe_paths_.size();
-    const unsigned n_threads = (unsigned)std::max(1, kNumOmpCores);
+    // The reference reads its scans on one thread (Session.cpp:266-302; num_omp_cores is for its OpenMP regions).  Here one task per file -- and the task
+    // is not the read (0.1 ms) but pcl::VoxelGrid's std::sort order on the scan's 54 k points (1.7-2.3 ms of thread time per os1-64 scan on the lot, where
+    // the grid really thins the scan; LTM_STEP0_TIMING prints it): ~0.9 s of CPU per 500-keyframe session.  As many threads as the hand-over of the cascade
+    // uses for the same sort, up to a cap (hardware threads, at most 32; LTM_LOADER_THREADS overrides): a container's CPU quota is averaged over 100 ms periods, so a
+    // burst this short runs wider than its 16 CPUs -- up to a point: measured on the GPU box (profiles/r5_step0_loader_threads.txt) 16 threads leave the feeder
+    // waiting for the decode (query session 56 ms), 32 do not (29 ms), 64 and 128 starve the feeder thread's staging copies instead (57-67 ms).
+    const char* lt_env = std::getenv("LTM_LOADER_THREADS");
+    const unsigned hw_threads = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned n_threads = lt_env && std::atoi(lt_env) > 0 ? (unsigned)std::atoi(lt_env)
+                                                              : std::max<unsigned>((unsigned)std::max(1, kNumOmpCores), std::min(32u, hw_threads));
     std::vector<Cloud> per_kf(n_kf);
     std::vector<size_t> raw_sizes(n_kf, 0), out_sizes(n_kf, 0);
+    std::atomic<uint64_t> decode_us[2] = {{0}, {0}};      // LTM_STEP0_TIMING: thread time inside loadPCDFile / voxelGridFilter, summed over the files
     auto decode = [&](size_t k) {          // Session.cpp:272-292: loadPCDFile + per-scan pcl::VoxelGrid
         Cloud points;
         std::string err;
+        const auto td0 = std::chrono::steady_clock::now();
         if (!loadPCDFile(keyframe_paths_[k], points, &err)) throw std::runtime_error(err);
+        const auto td1 = std::chrono::steady_clock::now();
         raw_sizes[k] = points.size();
         voxelGridFilter(std::move(points), kDownsampleVoxelSize, per_kf[k]);
         out_sizes[k] = per_kf[k].size();
+        decode_us[0] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(td1 - td0).count();
+        decode_us[1] += (uint64_t)std::chrono::duration_cast<std::chrono::microseconds>(std::chrono::steady_clock::now() - td1).count();
     };
     auto report = [&](size_t k) {
         if ((k + 1) % cout_interval == 0 && !logQuiet())
@@ -339,8 +355,13 @@ void Session::loadKeyframes(void)
         // Pipelined feeder: decode threads fill per_kf[] in any order; this thread hands every keyframe to the device as
         // soon as it AND all earlier ones are ready -- pinned double buffering on the copy stream, so PCD decode, the per-scan
         // VoxelGrid, host packing and the H2D DMA overlap.  The device array is sized from the PCD headers (VoxelGrid never grows a scan).
+        using clk = std::chrono::steady_clock;
+        const bool detail = std::getenv("LTM_STEP0_TIMING") != nullptr;
+        const auto tl0 = clk::now();
+        double wait_ms = 0.0, chunk_ms = 0.0;
         std::vector<size_t> header_pts(n_kf, 0);
         parallelFor(n_kf, [&](size_t k) { std::string err; if (!readPCDPointCount(keyframe_paths_[k], &header_pts[k], &err)) throw std::runtime_error(err); }, n_threads);
+        const auto tl1 = clk::now();
         size_t capacity = 0;
         for (size_t v : header_pts) capacity += v;
         ltm_upload up = 0;
@@ -361,20 +382,32 @@ void Session::loadKeyframes(void)
             });
         try {
             for (size_t k = 0; k < n_kf; ++k) {
+                const auto tw0 = clk::now();
                 {
                     std::unique_lock<std::mutex> lk(m);
                     cv.wait(lk, [&] { return done[k] || err; });
                     if (err) break;
                 }
+                const auto tw1 = clk::now();
+                wait_ms += std::chrono::duration<double, std::milli>(tw1 - tw0).count();
                 const uint64_t n = out_sizes[k];
                 ltmCheck(dev_->ctx, ltm_scanset_upload_chunk(dev_->ctx, up, per_kf[k].data(), sizeof(PointType), &n, 1), "ltm_scanset_upload_chunk");
+                chunk_ms += std::chrono::duration<double, std::milli>(clk::now() - tw1).count();
                 report(k);
                 Cloud().swap(per_kf[k]);
             }
         } catch (...) { std::lock_guard<std::mutex> g(m); if (!err) err = std::current_exception(); next = n_kf; }
+        const auto tl2 = clk::now();
         for (auto& th : pool) th.join();
         if (err) { ltm_scanset tmp = 0; (void)ltm_scanset_upload_end(dev_->ctx, up, &tmp); if (tmp) (void)ltm_scanset_free(dev_->ctx, tmp); std::rethrow_exception(err); }
         ltmCheck(dev_->ctx, ltm_scanset_upload_end(dev_->ctx, up, &h), "ltm_scanset_upload_end");
+        if (detail) {
+            auto msd = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+            std::fprintf(stderr, "[ltm_run] step 0:   %s: headers %.1f ms, feeder loop %.1f ms (waiting for the decode %.1f, in upload_chunk %.1f), join + upload_end %.1f ms, %u threads; "
+                                 "thread time per file: loadPCDFile %.0f us, voxelGridFilter %.0f us\n",
+                         sess_type_.c_str(), msd(tl0, tl1), msd(tl1, tl2), wait_ms, chunk_ms, msd(tl2, clk::now()), n_threads,
+                         (double)decode_us[0].load() / (double)std::max<size_t>(n_kf, 1), (double)decode_us[1].load() / (double)std::max<size_t>(n_kf, 1));
+        }
     }
     keyframe_scans_ = wrap_scans(h);
     uploadPoses();
