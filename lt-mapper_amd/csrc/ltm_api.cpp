@@ -169,52 +169,6 @@ struct FetchRing {
     std::thread worker;
 };
 
-// staging copies of the pipelined upload (host memory -> pinned buffer) split over a few helper threads: the feeder thread's single memcpy of every scan was
-// what bounded Step 0 of files -> files once the loader decoded on more than four threads (round 5)
-struct CopyPool {
-    static constexpr unsigned kHelpers = 3;
-    std::vector<std::thread> th;
-    std::mutex m;
-    std::condition_variable cv_go, cv_done;
-    const char* src = nullptr; char* dst = nullptr; size_t bytes = 0;
-    uint64_t gen = 0; unsigned pending = 0; bool stop = false;
-    void part(unsigned i) const
-    {
-        const size_t n = kHelpers + 1, lo = bytes * i / n & ~(size_t)63, hi = i + 1 == n ? bytes : (bytes * (i + 1) / n & ~(size_t)63);
-        if (hi > lo) memcpy(dst + lo, src + lo, hi - lo);
-    }
-    void worker(unsigned i)
-    {
-        uint64_t seen = 0;
-        for (;;) {
-            { std::unique_lock<std::mutex> lk(m); cv_go.wait(lk, [&] { return stop || gen != seen; }); if (stop) return; seen = gen; }
-            part(i + 1);
-            { std::lock_guard<std::mutex> lk(m); if (--pending == 0) cv_done.notify_one(); }
-        }
-    }
-    void copy(void* d, const void* s, size_t n)
-    {
-        if (n < ((size_t)256 << 10)) { memcpy(d, s, n); return; }
-        if (th.empty()) {
-            try { for (unsigned i = 0; i < kHelpers; ++i) th.emplace_back(&CopyPool::worker, this, i); }
-            catch (...) { if (th.size() < kHelpers) { shutdown(); memcpy(d, s, n); return; } }
-        }
-        { std::lock_guard<std::mutex> lk(m); src = static_cast<const char*>(s); dst = static_cast<char*>(d); bytes = n; pending = kHelpers; ++gen; }
-        cv_go.notify_all();
-        part(0);
-        std::unique_lock<std::mutex> lk(m);
-        cv_done.wait(lk, [&] { return pending == 0; });
-    }
-    void shutdown()
-    {
-        { std::lock_guard<std::mutex> lk(m); stop = true; }
-        cv_go.notify_all();
-        for (std::thread& t : th) if (t.joinable()) t.join();
-        th.clear();
-        stop = false;
-    }
-};
-
 struct ltm_ctx {
     ltm_config cfg;
     int device = 0;
@@ -271,7 +225,6 @@ struct ltm_ctx {
     hipStream_t copy_stream = nullptr;
     std::vector<PinnedBlock> pinned;
     std::unordered_map<uint64_t, UploadState> uploads;
-    CopyPool copy_pool;                         // helper threads of the staging copies (created by the first large ltm_scanset_upload_chunk)
 };
 
 namespace {
@@ -1438,7 +1391,6 @@ void ltm_destroy(ltm_ctx* c)
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
     destroy_ring(c);
-    c->copy_pool.shutdown();
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     if (c->live_counts) (void)hipFree(c->live_counts);
@@ -1798,7 +1750,7 @@ int ltm_scanset_upload_chunk(ltm_ctx* c, ltm_upload up, const void* pts, size_t 
                 u.stage_sz[b] = want;
             }
             unsigned char* dst = static_cast<unsigned char*>(u.stage[b]) + u.fill;
-            if (stride == 16) c->copy_pool.copy(dst, pts, n * 16);
+            if (stride == 16) memcpy(dst, pts, n * 16);
             else {
                 const unsigned char* s = static_cast<const unsigned char*>(pts);
                 float* o = reinterpret_cast<float*>(dst);

@@ -6,7 +6,6 @@
 //                      masks and per-rank map pieces exchanged with RCCL over xGMI (removert/Comm.h)
 //   --logical-ranks K  the same sharding with K ranks that all use GPU `removert/gpu_device` and exchange through host staging
 //                      (LocalComm): the outputs must not depend on K -- this is how the sharding is tested on a 1-GPU box
-#include <malloc.h>
 #include <cstdio>
 #include <cstdlib>
 #include <exception>
@@ -55,14 +54,6 @@ int main(int argc, char** argv)
     if (argc < 2) {
         std::fprintf(stderr, "usage: %s <params_ltmapper.yaml> [--check-wrappers] [--gpus K | --logical-ranks K]\n", argv[0]);
         return 2;
-    }
-    // The loader and the writer allocate and free a ~1 MB cloud per scan file on several threads.  glibc serves such blocks with one mmap / munmap each:
-    // 200+ page faults per scan on fresh zero pages and the address-space lock taken exclusively twice, which the loader threads queue behind (round 5: half
-    // of Step 0's load time, unless LTM_HOST_MALLOC=default).  Keep them in the heap, where a freed scan buffer is the next scan's buffer.
-    if (!(std::getenv("LTM_HOST_MALLOC") && std::string(std::getenv("LTM_HOST_MALLOC")) == "default")) {
-        mallopt(M_MMAP_THRESHOLD, 256 << 20);
-        mallopt(M_TRIM_THRESHOLD, 1 << 30);
-        mallopt(M_ARENA_MAX, 4);
     }
     try {
         RosParamServer::setParamFile(argv[1]);
