@@ -90,6 +90,14 @@ class OracleOps:
     def voxel_grid_scanset(self, s, leaf):      # the loader's pcl::VoxelGrid per keyframe (Session.cpp:284-289)
         return self._pack([orc.voxel_grid(s.pts[int(s.off[k]):int(s.off[k + 1])], leaf) for k in range(len(s.off) - 1)])
 
+    # the two halves of the cascade hand-over (ltm_voxel_grid_scanset_begin / _end): here the grid simply runs in the second half, which is enough to put
+    # cascade.run_cascade's deferred path and Removerter._queryThenCentral -- pure host logic -- under a CPU test
+    supports_deferred_grid = True
+
+    def voxel_grid_scanset_begin(self, s, leaf): return (s, leaf)
+
+    def voxel_grid_scanset_end(self, ticket): return self.voxel_grid_scanset(*ticket)
+
     def preclean(self, s, radius):              # Session.cpp:506-533
         return self._pack([orc.preclean(s.pts[int(s.off[k]):int(s.off[k + 1])], radius) for k in range(len(s.off) - 1)])
 

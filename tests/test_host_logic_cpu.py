@@ -318,3 +318,32 @@ def test_scaling_model_prices_the_session_rank_groups():
     r2 = m["ranks"]["2"]
     rest_comm = r2["comm_ms"] - (1e3 * 3.3e8 / 150e9 + 0.05)
     assert rest_comm > 0 and rest_comm < plain["ranks"]["2"]["comm_ms"]
+
+
+def test_cascade_with_deferred_hand_over_equals_the_serial_cascade(orc):
+    """cascade.run_cascade(overlap=True) starts the re-load of scans_updated when a run ends and finishes it inside the next run, after that run's query
+    session has been issued (Removerter._queryThenCentral: query merge + grid + Step 1 first, then the central session's).  The order of the two
+    sessions' chains must not change a single output: three sessions, both pair runs, every map and scan set against the serial form."""
+    import ltmapper_amd  # noqa: F401
+    from ltmapper_amd.cascade import run_cascade
+    from ltmapper_amd.removerter import Params
+    from oracle_ops import OPoses, OracleOps, OScans
+    S = _tiny_sessions(3)
+    out = {}
+    for overlap in (True, False):
+        up = [(OScans(T["scans"], T["offsets"]), OPoses(T["poses"], T["inv"])) for T in S]
+        ops = OracleOps()
+        runs = run_cascade(ops, Params(gather_scan_outputs=True, gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5]), up[0][0], up[0][1], up[1:], overlap=overlap)
+        assert len(runs) == 2
+        if overlap:
+            assert runs[0].central_scans_future is None and runs[1].central_scans_future is None, "the deferred scans were collected"
+            assert hasattr(runs[-1], "next_central_scans"), "the hand-over after the last run is finished, not dropped"
+        out[overlap] = [({k: np.asarray(v.download()) for k, v in rm.outputs.items()},
+                         {k: tuple(np.asarray(x) for x in v.download()) for k, v in rm.scan_outputs().items()}) for rm in runs]
+    for (ma, sa), (mb, sb) in zip(out[True], out[False]):
+        assert sorted(ma) == sorted(mb) and sorted(sa) == sorted(sb)
+        for k in ma:
+            assert ma[k].shape == mb[k].shape and (ma[k].view(np.uint32) == mb[k].view(np.uint32)).all(), k
+        for k in sa:
+            assert (sa[k][1] == sb[k][1]).all() and (sa[k][0].view(np.uint32) == sb[k][0].view(np.uint32)).all(), k
+    assert len(out[True][1][0]["updated_map"]) > 100
