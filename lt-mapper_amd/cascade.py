@@ -19,14 +19,19 @@ def reload_scans(ops, scans, params: Params):
     return ops.preclean(ops.voxel_grid_scanset(scans, params.downsample_voxel_size), kPrecleanRadius)
 
 
-def run_cascade(ops, params: Params, central_scans, central_poses, queries, overlap=True):
+def run_cascade(ops, params: Params, central_scans, central_poses, queries, overlap=True, prepare_next=False):
     """central_scans / queries: (scans, poses) handles as a loader leaves them (VoxelGrid + pre-clean applied), sessions 1 and
     2..K.  Returns the list of Removerter objects (one per pair run); the live map after the last run is
     runs[-1].outputs['updated_map'], the live scans runs[-1].central_sess_.keyframe_scans_updated_.
 
     overlap (round 5): the re-load of scans_updated is STARTED when a run ends (ltm_voxel_grid_scanset_begin: keys to the host on the copy stream, std::sort's
     order on host threads) and FINISHED inside the next run, after that run's query session -- merge, grid, Step-1 remove / revert passes, none of which needs
-    the central scans -- has been issued: the GPU works through the query session while the host sorts.  Same clouds either way (tests/test_gpu_cascade.py)."""
+    the central scans -- has been issued: the GPU works through the query session while the host sorts.  Same clouds either way (tests/test_gpu_cascade.py).
+
+    prepare_next: also re-load the LAST run's scans_updated (-> runs[-1].next_central_scans) for a caller that will continue the cascade with further
+    sessions; a cascade that ends here has no use for it (the reference re-loads scans_updated only when a next run is started on them), and round 4's
+    bench step paid for that fifth, unused hand-over."""
+    queries = list(queries)
     runs = []
     pending = None
     can_overlap = overlap and getattr(ops, "supports_deferred_grid", False)      # one context, whole scan sets (HipOps; not the keyframe-sharded ops)
@@ -37,11 +42,14 @@ def run_cascade(ops, params: Params, central_scans, central_poses, queries, over
             rm.central_scans_future = lambda t=ticket: ops.preclean(ops.voxel_grid_scanset_end(t), kPrecleanRadius)
         rm.run()
         runs.append(rm)
-        # "scans_updated/" re-loaded as the next central session
+        # "scans_updated/" re-loaded as the next central session -- if there is a next session (or the caller asked for the hand-over)
+        last = q_scans is queries[-1][0]
+        if last and not prepare_next:
+            break
         if can_overlap:
             pending, central_scans = ops.voxel_grid_scanset_begin(rm.central_sess_.keyframe_scans_updated_, params.downsample_voxel_size), None
         else:
             central_scans = reload_scans(ops, rm.central_sess_.keyframe_scans_updated_, params)
-    if pending is not None:      # the hand-over after the last run: finish it (a caller that continues the cascade later starts from this)
-        runs[-1].next_central_scans = ops.preclean(ops.voxel_grid_scanset_end(pending), kPrecleanRadius)
+    if prepare_next and runs:
+        runs[-1].next_central_scans = ops.preclean(ops.voxel_grid_scanset_end(pending), kPrecleanRadius) if pending is not None else central_scans
     return runs

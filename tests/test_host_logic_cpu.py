@@ -333,11 +333,11 @@ def test_cascade_with_deferred_hand_over_equals_the_serial_cascade(orc):
     for overlap in (True, False):
         up = [(OScans(T["scans"], T["offsets"]), OPoses(T["poses"], T["inv"])) for T in S]
         ops = OracleOps()
-        runs = run_cascade(ops, Params(gather_scan_outputs=True, gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5]), up[0][0], up[0][1], up[1:], overlap=overlap)
+        runs = run_cascade(ops, Params(gather_scan_outputs=True, gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0, 1.5]), up[0][0], up[0][1], up[1:], overlap=overlap, prepare_next=True)
         assert len(runs) == 2
         if overlap:
             assert runs[0].central_scans_future is None and runs[1].central_scans_future is None, "the deferred scans were collected"
-            assert hasattr(runs[-1], "next_central_scans"), "the hand-over after the last run is finished, not dropped"
+        assert len(runs[-1].next_central_scans.download()[0]) > 0, "prepare_next: the hand-over after the last run is finished, not dropped"
         out[overlap] = [({k: np.asarray(v.download()) for k, v in rm.outputs.items()},
                          {k: tuple(np.asarray(x) for x in v.download()) for k, v in rm.scan_outputs().items()}) for rm in runs]
     for (ma, sa), (mb, sb) in zip(out[True], out[False]):
