@@ -1,4 +1,7 @@
 #!/bin/bash
+# Last pass of a round on the GPU box (run through gpurun from the repository root), at sources that will not change any more: the GPU suite (which writes the
+# full-size parity record that bench.py checks against the source hashes), the default bench line exactly as the driver runs it, and the lines of configs[2..4]
+# (their counter files come from tools/collect_profiles.sh "w:<workload>").  Results under gpurun_out/profiles_r5_final2/; copy what should be judged to profiles/.
 ROOT=$(pwd); OUT=$ROOT/gpurun_out/profiles_r5_final2; mkdir -p $OUT
 python -m pytest tests -m gpu -q 2>&1 | tee $OUT/r5_pytest_gpu.log | grep -i "passed\|failed\|error" | tail -3
 cp gpurun_out/parity_fullsize_2x500_3res.json profiles/parity_fullsize_2x500_3res.json 2>/dev/null

@@ -1,3 +1,6 @@
+"""Where Step 0 of a files -> files run goes: writes the 2 x 500 os1-64 lot sessions in the reference's on-disk format and runs `ltm_run` on them with
+LTM_STEP0_TIMING=1 (per-stage laps of Step 0, the loader's wait / upload split and the thread time per file inside loadPCDFile and voxelGridFilter) and LTM_POOL_STATS=1,
+once per setting of the swept variable (here: loader threads).  Run through gpurun; profiles/r5_step0_loader_threads.txt is its output, condensed."""
 import os, sys, subprocess, tempfile, shutil
 sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "tests"))
 import fileproto as fp
