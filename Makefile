@@ -23,13 +23,15 @@ oracle:
 host:
 	@if [ -f $(PKG)/host/Makefile ]; then $(MAKE) -C $(PKG)/host; fi
 
-ubench: tools/ubench/valu_rate tools/ubench/mfma_overlap
+ubench: tools/ubench/valu_rate tools/ubench/mfma_overlap tools/ubench/stream_priority
 tools/ubench/valu_rate: tools/ubench/valu_rate.hip
+	$(HIPCC) --offload-arch=$(ARCH) -O3 -w $< -o $@
+tools/ubench/stream_priority: tools/ubench/stream_priority.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -w $< -o $@
 tools/ubench/mfma_overlap: tools/ubench/mfma_overlap.hip
 	$(HIPCC) --offload-arch=$(ARCH) -O3 -w $< -o $@
 
 clean:
-	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so tools/ubench/valu_rate tools/ubench/mfma_overlap
+	rm -f $(PKG)/csrc/*.o $(PKG)/libltm_hip.so tools/ubench/valu_rate tools/ubench/mfma_overlap tools/ubench/stream_priority
 	$(MAKE) -C oracle clean
 .PHONY: all hip oracle host ubench clean

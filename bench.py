@@ -97,6 +97,10 @@ def parse_args():
                                                                       "before the next pair run starts, as in round 4, instead of beside the next run's query session (A/B)")
     ap.add_argument("--verbose", action="store_true")
     ap.add_argument("--extra-out", default=None, help="sidecar file for everything the printed line does not carry (default profiles/bench_extra_latest.json)")
+    ap.add_argument("--lanes", type=int, default=2, choices=(1, 2), help="one GPU: 2 (default) = the independent chains of run() side by side on the context and its lane "
+                    "(two host threads, include/ltm.h 'lanes'; removerter.Removerter.run_two_lanes); 1 = the one-lane order of rounds 1-5.  With 2 lanes the kernel-class "
+                    "times / rooflines come from a separate ONE-lane profiling pass after the timed region (overlapping launches inflate each other's event times)")
+    ap.add_argument("--profile-steps", type=int, default=2, help="steps of the one-lane profiling pass behind a two-lane timed region")
     ap.add_argument("--overlap-sessions", action="store_true", help="EXPERIMENT (one GPU, pair workloads): merge + grid and Step 1 of the query session on a second "
                     "context / stream / host thread beside the central session's (removerter.Removerter query_side).  Kernel times of overlapping launches "
                     "are inflated by each other, so the roofline figures of such a line describe the overlap, not the kernels")
@@ -167,6 +171,9 @@ def main():
         ops = meter = CommMeter(HipOps(ctx))      # single GPU: note what the sharded pipeline would exchange (a few dictionary updates per stage)
 
     loaded = [load(S) for S in sess_t]   # loading + pre-clean are Step 0 plumbing, outside the timed region
+    two_lanes = args.lanes == 2 and world == 1 and not args.overlap_sessions
+    plain_ops = HipOps(ctx)
+    lane_ops = plain_ops.lane() if two_lanes else None
     snap = {"on": False, "prof": {}, "events": {}, "svp": 0, "step1_wall": 0.0, "step1_ms": {}, "step1_voxel_units": 0.0, "step1_events": {}, "step1_svp": 0, "swap_bytes": 0.0}
     ctx2 = q2 = None
     if args.overlap_sessions:
@@ -175,17 +182,19 @@ def main():
         S = sess_t[1]
         q2 = (ctx2.preclean(ctx2.scans_from_device(S["scans"].data_ptr(), S["offsets"].numpy().astype(np.uint64)), 2.5), ctx2.poses(S["poses"], S["inv"]))
 
-    def one_step():
+    def one_step(lanes=False):
         ctx.clear_caches()   # no derived data (scan range images) survives from a previous step: every step is a fresh run
+        if lanes:
+            lane_ops.ctx.clear_caches()
         if n_sessions > 2:
-            runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:], overlap=not args.no_cascade_overlap)
+            runs = run_cascade(plain_ops if lanes else ops, P, loaded[0][0], loaded[0][1], loaded[1:], overlap=not args.no_cascade_overlap, lane_ops=lane_ops if lanes else None)
             return runs[-1]
         (cs, cp), (qs, qp) = loaded
         side = None
         if ctx2 is not None:
             ctx2.clear_caches()
             side = (HipOps(ctx2), Session("Query", q2[0], q2[1]))
-        rm = Removerter(ops, P, Session("Central", cs, cp), Session("Query", qs, qp), query_side=side)
+        rm = Removerter(plain_ops if lanes else ops, P, Session("Central", cs, cp), Session("Query", qs, qp), query_side=side, lane_ops=lane_ops if lanes else None)
         if snap["on"]:
             # makeGlobalMap + Step 1 is the part of the step that an even number of ranks runs on two rank groups (ShardedOps.session_groups): its
             # kernel classes, wall time and would-be collectives are snapshot at its end so that the scaling model can price that split
@@ -224,10 +233,13 @@ def main():
     last = None
     for _ in range(args.warmup):
         last = None
-        last = one_step()
+        last = one_step(two_lanes)
+    if two_lanes and args.warmup:      # the one-lane profiling pass behind the timed region needs its (larger) blocks in the main context's pool too
+        last = None
+        last = one_step(False)
     barrier()
     ctx.profile_reset()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not two_lanes)
     if ctx2 is not None:
         ctx2.synchronize()
         ctx2.profile_reset()
@@ -235,13 +247,33 @@ def main():
     ctx.voxel_stats(reset=True)
     if meter:
         meter.reset()
-    snap["on"] = bool(meter) and n_sessions == 2 and not args.overlap_sessions
+    snap["on"] = bool(meter) and n_sessions == 2 and not args.overlap_sessions and not two_lanes
     t0 = time.perf_counter()
     for _ in range(args.steps):
         last = None
-        last = one_step()
+        last = one_step(two_lanes)
     barrier()
+    if two_lanes:
+        lane_ops.ctx.synchronize()
     elapsed = time.perf_counter() - t0
+    psteps = args.steps          # the steps the kernel-class profile covers
+    one_lane_ms = None
+    timed_stage_ms = {k: round(1e3 * v, 2) for k, v in last.timings.items()}
+    if two_lanes:
+        # kernel classes, rooflines, comm meter: a ONE-lane pass with the HIP-event profile on (events of overlapping launches would count the other lane's work)
+        psteps = max(args.profile_steps, 1)
+        ctx.profile_reset()
+        ctx.profile_enable(True)
+        ctx.voxel_stats(reset=True)
+        ctx.cull_stats()
+        meter.reset()
+        snap["on"] = bool(meter) and n_sessions == 2
+        tp = time.perf_counter()
+        for _ in range(psteps):
+            last = None
+            last = one_step(False)
+        barrier()
+        one_lane_ms = 1e3 * (time.perf_counter() - tp) / psteps
     ctx.profile_enable(False)
     prof = ctx.profile_read()
     if ctx2 is not None:       # the second context's launches belong to the same step
@@ -267,9 +299,9 @@ def main():
     valu_peak = N_CU * SIMD_PER_CU * LANES_PER_SIMD * clock_hz      # VALU lane-instructions per second
     pmc = load_pmc(args.workload)
 
-    groups = traffic_groups(pmc, prof, args.steps)
+    groups = traffic_groups(pmc, prof, psteps)
 
-    steps = max(args.steps, 1)
+    steps = max(psteps, 1)
     step_kernel_ms = sum(v["ms"] for v in prof.values()) / steps
 
     def class_roofline(cls, v):
@@ -368,20 +400,26 @@ def main():
                        "knn": {"k": knn_k, "thr": knn_thr}, "voxel": voxel, "map_points_last_pair": [M_c, M_q],
                        "scan_points": [int(s["offsets"][-1]) for s in sess_t],
                        "parallelism": (f"keyframe-sharded x{world} (label all-reduce, key-range all-to-all for the merges" + (", one rank group per session in Step 1" if dist_session_groups(world) else "") + ")") if world > 1 else
-                                      ("single GPU, the two sessions' merge + Step-1 chains side by side on two contexts (--overlap-sessions experiment)" if args.overlap_sessions else "single GPU"),
+                                      ("single GPU, the two sessions' merge + Step-1 chains side by side on two contexts (--overlap-sessions experiment)" if args.overlap_sessions else
+                                       ("single GPU, two lanes (independent chains of run() side by side on two streams / host threads)" if two_lanes else "single GPU, one lane")),
                        "step": "makeGlobalMap + Removerter::run Steps 1-3 per pair run, inputs resident in HBM"},
             "roofline": roofline, "cpu_baseline": cpu_baseline, "rooflines": rooflines, "traffic_groups": groups or None,
             "t_total": t_total, "parity_fullsize": parity_fullsize_status(),
-            "scaling_model": scaling_model({k: v["ms"] / args.steps for k, v in prof.items()}, ms_per_step,
-                                           {k: (v[0] / args.steps, v[1] / args.steps) for k, v in meter.events.items()},
+            "lanes": 2 if two_lanes else 1,
+            "one_lane_ms_per_step": round(one_lane_ms, 3) if one_lane_ms else None,
+            "class_times_from": (f"a one-lane profiling pass of {psteps} steps after the two-lane timed region (HIP events of overlapping launches would count the other lane's work)"
+                                 if two_lanes else "the timed region"),
+            "scaling_model": scaling_model({k: v["ms"] / psteps for k, v in prof.items()}, one_lane_ms or ms_per_step,
+                                           {k: (v[0] / psteps, v[1] / psteps) for k, v in meter.events.items()},
                                            sharded_voxel_fraction=(meter.sharded_voxel_points / max(prof.get("voxel", {}).get("units", 0.0), 1.0)),
-                                           step1=({"class_ms": {k: v / args.steps for k, v in snap["step1_ms"].items()}, "wall_ms": 1e3 * snap["step1_wall"] / args.steps,
-                                                   "events": {k: (v[0] / args.steps, v[1] / args.steps) for k, v in snap["step1_events"].items()},
+                                           step1=({"class_ms": {k: v / psteps for k, v in snap["step1_ms"].items()}, "wall_ms": 1e3 * snap["step1_wall"] / psteps,
+                                                   "events": {k: (v[0] / psteps, v[1] / psteps) for k, v in snap["step1_events"].items()},
                                                    "sharded_voxel_fraction": snap["step1_svp"] / max(snap["step1_voxel_units"], 1.0),
-                                                   "swap_bytes": snap["swap_bytes"] / args.steps} if snap["on"] and snap["step1_wall"] > 0 else None)) if meter else None,
+                                                   "swap_bytes": snap["swap_bytes"] / psteps} if snap["on"] and snap["step1_wall"] > 0 else None)) if meter else None,
             "stage_ms": {k: round(1e3 * v, 2) for k, v in last.timings.items()},
-            "kernel_classes_ms_per_step": {k: round(v["ms"] / args.steps, 3) for k, v in sorted(prof.items())},
-            "voxel_grids": {"per_step": round(vox_grids / max(args.steps, 1), 2), "recognised_as_identity_per_step": round(vox_identity / max(args.steps, 1), 2),
+            "timed_region_stage_ms": timed_stage_ms,
+            "kernel_classes_ms_per_step": {k: round(v["ms"] / psteps, 3) for k, v in sorted(prof.items())},
+            "voxel_grids": {"per_step": round(vox_grids / max(psteps, 1), 2), "recognised_as_identity_per_step": round(vox_identity / max(psteps, 1), 2),
                             "what": "voxel grids of clouds per step and how many of them the bounding-box pass recognised as the identity (DESIGN.md 4.2)"},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
             "synth_generation_s": round(t_gen, 2),
@@ -423,7 +461,7 @@ def _num(d, *keys):
 def slim_line(full, extra_path):
     """the ONE printed JSON line: contract fields, the dominant kernel's roofline (numbers only), the CPU baseline (numbers + one short sentence),
     a per-class table of numbers, and the path of the sidecar.  Stays well below 6000 bytes (tests/test_bench_line.py)"""
-    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "cxx_host_ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
+    keep = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "cxx_host_ms_per_step", "lanes", "one_lane_ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data")
     out = {k: full.get(k) for k in keep}
     cfg = full.get("config") or {}
     out["config"] = {k: cfg.get(k) for k in ("workload", "keyframes_per_session", "keyframe_pairs_per_step", "sensor", "remove_resolution_list", "knn", "voxel",

@@ -14,7 +14,12 @@
  *    negative LTM_E_* code; the library never throws and never exits.  ltm_last_error()
  *    gives the message for the last failing call on that context.
  *  - A context owns one HIP stream and all device memory reachable through its handles.
- *    It is NOT thread-safe: call it from one host thread (as the reference's run() does).
+ *    Calls on ONE context serialise on a mutex of that context, so a handle may be freed from any
+ *    thread; the pipeline of one context is still driven from one host thread (as the reference's
+ *    run() is).  Independent chains of a run -- the two sessions' remove / revert passes
+ *    (Removerter.cpp:1580-1587), the ND and PD filters (:1395-1411), the reprojections of Step 3
+ *    (:1534-1575) -- may run side by side on LANES: further contexts on the same device, one host
+ *    thread each, that exchange clouds without copies (section "lanes" below).
  *  - Clouds are XYZI float32, 16 B / point on the device.  Host buffers are described by a
  *    byte stride (16 = packed, 32 = pcl::PointXYZI: xyz+pad, intensity+pad).
  *  - Matrices are 4x4 row-major double (the layout of the pose text files, Session.cpp:102-114).
@@ -256,6 +261,38 @@ int ltm_knn_partition(ltm_ctx*, ltm_cloud target, ltm_scanset scans, ltm_poses p
 /* removeWeakNDMapPointsHavingStrongNDInNear (Session.cpp:452-484): split `query` by k-NN distance to `target` */
 int ltm_knn_split_cloud(ltm_ctx*, ltm_cloud target, ltm_cloud query, int k, float thr, ltm_cloud* near, ltm_cloud* far);
 
+/* ------------------------------------------------------------------- lanes ---- */
+/* The reference runs the stages of Removerter::run() one after the other on one thread; several of them do not depend on each other: the
+ * central and the query session's makeGlobalMap + Step-1 chains (Removerter.cpp:213-252, :1580-1587), their HD kNN maps and static reprojections
+ * (:1590-1601, :1527-1538), the two directions of the LD kNN diff (:1418-1421), filterStrongND against filterStrongPD (:1395-1411), the grids of
+ * :1445-1476 and the six reprojections of :1551-1577.  A LANE is a second context on the parent's device (own stream, own pool, the parent's
+ * configuration and create-time self-check) that a second host thread drives; the projection kernels are bound by vector-instruction issue and the
+ * grids / kNN stages by launch latency, so the two kinds of work fill each other's gaps.  The library keeps the lanes out of each other's way by
+ * itself: the large projection launches of a context and its lanes are chained on the device (one at a time, in the order the hosts submit them) and
+ * go to a stream of the lowest priority, so that one lane's partition + grids are dispatched ahead of -- and finish under -- the other lane's
+ * projection instead of both lanes projecting together and then idling together.  Results do not depend on the schedule: every kernel sees the same
+ * inputs as in the one-lane order.
+ *
+ *   ltm_lane_create           a context like `parent` (same device, field of view, extrinsic, kernel switches); destroy with ltm_destroy
+ *   ltm_cloud_lend / _give    make a cloud of context `from` usable in context `to` WITHOUT copying: `lend` leaves ownership with `from` (the new handle
+ *                             is a borrowed view: freeing it releases nothing; `from` must keep its cloud alive and unchanged until the borrower is done
+ *                             with it and must order its own later writes / frees after the borrower's reads -- ltm_lane_fence(to, from) or an event);
+ *                             `give` moves the memory block into `to`'s pool and invalidates the handle in `from`.  Both make `to`'s stream wait for what
+ *                             `from`'s stream has been given so far (the cloud's producer).  Same for scan sets.
+ *   ltm_lane_fence(a, b)      everything submitted to b afterwards runs after everything submitted to a so far (device-side; the host does not wait)
+ *   ltm_event_record / _wait  the same dependency in two halves, for a consumer on another thread: record on one context, hand the event over by
+ *                             whatever means the host language has, wait on the other.  An event may be waited for any number of times.
+ * Two contexts are locked in address order by the two-context calls, so they may be issued from either thread. */
+typedef struct ltm_event ltm_event;
+int  ltm_lane_create(ltm_ctx* parent, ltm_ctx** lane);
+int  ltm_lane_fence(ltm_ctx* done_in, ltm_ctx* before_next_of);
+int  ltm_event_record(ltm_ctx*, ltm_event** ev);
+int  ltm_event_wait(ltm_ctx*, ltm_event* ev);
+void ltm_event_destroy(ltm_event* ev);
+int  ltm_cloud_lend(ltm_ctx* from, ltm_cloud h, ltm_ctx* to, ltm_cloud* out);
+int  ltm_cloud_give(ltm_ctx* from, ltm_cloud h, ltm_ctx* to, ltm_cloud* out);
+int  ltm_scanset_lend(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* out);
+int  ltm_scanset_give(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* out);
 /* ------------------------------------------------------ parity / debug helpers ---- */
 /* one range image of `pts` after optional transforms T1 then T2 (NULL = none); rimg R*C floats,
  * ptidx R*C int32 or NULL.  Host output buffers. */

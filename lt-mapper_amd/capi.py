@@ -98,6 +98,15 @@ SIGNATURES = {
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
     "ltm_visibility_partition": (_i, [_vp, _u64, _u64, _u64, _f, _f, _i, _pu64, _pu64, _vp]),
+    "ltm_lane_create": (_i, [_vp, C.POINTER(_vp)]),
+    "ltm_lane_fence": (_i, [_vp, _vp]),
+    "ltm_event_record": (_i, [_vp, C.POINTER(_vp)]),
+    "ltm_event_wait": (_i, [_vp, _vp]),
+    "ltm_event_destroy": (None, [_vp]),
+    "ltm_cloud_lend": (_i, [_vp, _u64, _vp, _pu64]),
+    "ltm_cloud_give": (_i, [_vp, _u64, _vp, _pu64]),
+    "ltm_scanset_lend": (_i, [_vp, _u64, _vp, _pu64]),
+    "ltm_scanset_give": (_i, [_vp, _u64, _vp, _pu64]),
     "ltm_reproject": (_i, [_vp, _u64, _u64, _sz, _sz, _f, _pu64]),
     "ltm_knn_partition": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _i, _f, _pu64, _pu64]),
     "ltm_knn_split_cloud": (_i, [_vp, _u64, _u64, _i, _f, _pu64, _pu64]),
@@ -196,6 +205,49 @@ class Context:
         if rc != LTM_OK:
             raise LtmError(rc, "ltm_create failed (no usable gfx950 device?)")
         self.h = h
+
+    def lane(self):
+        """ltm_lane_create: a second context on this one's device (own stream, own pool, same configuration) for a second host thread; clouds and
+        scan sets pass between the two without copies (lend / give)"""
+        other = Context.__new__(Context)
+        other.lib, other.vfov, other.hfov, other.device = self.lib, self.vfov, self.hfov, self.device
+        h = _vp()
+        rc = self.lib.ltm_lane_create(self.h, C.byref(h))
+        if rc != LTM_OK:
+            raise LtmError(rc, "ltm_lane_create failed")
+        other.h = h
+        return other
+
+    def _pass(self, obj, to, give):
+        kind = "cloud" if isinstance(obj, Cloud) else "scanset"
+        out = _u64()
+        self._ck(getattr(self.lib, f"ltm_{kind}_{'give' if give else 'lend'}")(self.h, obj.h, to.h, C.byref(out)))
+        new = (Cloud if kind == "cloud" else ScanSet)(to, out.value)
+        if give:
+            obj.h = 0
+        else:
+            new._lender = obj      # keeps the owner's Python handle (and so the memory) alive as long as the view exists
+        return new
+
+    def lend(self, obj, to):
+        """a borrowed view of `obj` (Cloud or ScanSet of this context) in context `to`, no copy; this context keeps ownership"""
+        return self._pass(obj, to, False)
+
+    def give(self, obj, to):
+        """moves `obj` into context `to` (no copy); `obj` is invalid afterwards"""
+        return self._pass(obj, to, True)
+
+    def fence(self, before_next_of):
+        """what is submitted to `before_next_of` from now on runs after everything submitted to this context so far"""
+        self._ck(self.lib.ltm_lane_fence(self.h, before_next_of.h))
+
+    def event_record(self):
+        ev = _vp()
+        self._ck(self.lib.ltm_event_record(self.h, C.byref(ev)))
+        return Event(self.lib, ev)
+
+    def event_wait(self, ev):
+        self._ck(self.lib.ltm_event_wait(self.h, ev.h))
 
     def close(self):
         if getattr(self, "h", None):
@@ -486,6 +538,21 @@ class Context:
         nb_c = (C.c_double * cap)()
         self._ck(min(self.lib.ltm_profile_read_compulsory(self.h, nb_c, cap), 0))
         return {names[i].decode(): dict(ms=ms[i], launches=int(launches[i]), units=units[i], bytes=nbytes[i], bytes_c=nb_c[i]) for i in range(min(n, cap))}
+
+
+class Event:
+    """ltm_event: a point of one context's stream that other contexts can wait for (any number of times)"""
+
+    def __init__(self, lib, h):
+        self.lib, self.h = lib, h
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.lib.ltm_event_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
 
 
 class _Handle:

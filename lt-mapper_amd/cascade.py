@@ -19,7 +19,7 @@ def reload_scans(ops, scans, params: Params):
     return ops.preclean(ops.voxel_grid_scanset(scans, params.downsample_voxel_size), kPrecleanRadius)
 
 
-def run_cascade(ops, params: Params, central_scans, central_poses, queries, overlap=True, prepare_next=False):
+def run_cascade(ops, params: Params, central_scans, central_poses, queries, overlap=True, prepare_next=False, lane_ops=None):
     """central_scans / queries: (scans, poses) handles as a loader leaves them (VoxelGrid + pre-clean applied), sessions 1 and
     2..K.  Returns the list of Removerter objects (one per pair run); the live map after the last run is
     runs[-1].outputs['updated_map'], the live scans runs[-1].central_sess_.keyframe_scans_updated_.
@@ -30,20 +30,23 @@ def run_cascade(ops, params: Params, central_scans, central_poses, queries, over
 
     prepare_next: also re-load the LAST run's scans_updated (-> runs[-1].next_central_scans) for a caller that will continue the cascade with further
     sessions; a cascade that ends here has no use for it (the reference re-loads scans_updated only when a next run is started on them), and round 4's
-    bench step paid for that fifth, unused hand-over."""
+    bench step paid for that fifth, unused hand-over.
+
+    lane_ops (round 6): every pair run takes the two-lane schedule (Removerter.run_two_lanes); the deferred hand-over ends on the main lane while the
+    query session's chain is already running on the other."""
     queries = list(queries)
     runs = []
     pending = None
     can_overlap = overlap and getattr(ops, "supports_deferred_grid", False)      # one context, whole scan sets (HipOps; not the keyframe-sharded ops)
-    for q_scans, q_poses in queries:
-        rm = Removerter(ops, params, Session("Central", central_scans, central_poses), Session("Query", q_scans, q_poses))
+    for i_run, (q_scans, q_poses) in enumerate(queries):
+        rm = Removerter(ops, params, Session("Central", central_scans, central_poses), Session("Query", q_scans, q_poses), lane_ops=lane_ops)
         if pending is not None:
             ticket, pending = pending, None
             rm.central_scans_future = lambda t=ticket: ops.preclean(ops.voxel_grid_scanset_end(t), kPrecleanRadius)
         rm.run()
         runs.append(rm)
         # "scans_updated/" re-loaded as the next central session -- if there is a next session (or the caller asked for the hand-over)
-        last = q_scans is queries[-1][0]
+        last = i_run == len(queries) - 1      # by position: the same query handle may be replayed (ADVICE r5)
         if last and not prepare_next:
             break
         if can_overlap:

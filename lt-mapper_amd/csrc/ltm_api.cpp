@@ -100,6 +100,16 @@ struct Pool {
         free_blocks.emplace(it->second, p);
         live.erase(it);
     }
+    // ltm_*_give: a live block changes pools (both contexts on one device)
+    bool move_to(void* p, Pool& other)
+    {
+        auto it = live.find(p);
+        if (it == live.end()) return false;
+        other.live[p] = it->second;
+        other.bytes_total += it->second; bytes_total -= it->second;
+        live.erase(it);
+        return true;
+    }
     void release_cached()
     {
         for (auto& kv : free_blocks) { (void)hipFree(kv.second); bytes_total -= kv.first; }
@@ -115,11 +125,12 @@ struct Pool {
 
 struct Cloud {
     float4* d = nullptr; size_t n = 0;
+    bool borrowed = false;          // a view of another context's cloud (ltm_cloud_lend): freeing the handle releases nothing
     // the octree frame (and leaf) of the voxel grid this cloud came out of, kept by order-preserving subsets of it (partition outputs, clones):
     // lets the next grid of the cloud test "nothing to do" during its bounding-box pass (k_bbox_reduce_check)
     bool vf_ok = false; OctreeFrame vf{}; float vleaf = 0.0f;
 };
-struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> off; uint64_t* off_dev = nullptr; size_t nkf() const { return off.size() - 1; } };
+struct ScanSet { float4* d = nullptr; size_t n_pts = 0; std::vector<uint64_t> off; uint64_t* off_dev = nullptr; bool borrowed = false; size_t nkf() const { return off.size() - 1; } };
 struct Poses { size_t n = 0; std::vector<double> pose, inv; double* pose_dev = nullptr; double* inv_dev = nullptr; float* approx_dev = nullptr; };
 
 // bytes = SURVEY 8(d)'s algorithmic bytes (one map read per keyframe); bytes_c = the compulsory bytes of the launch as this design issues it (a projection
@@ -169,10 +180,26 @@ struct FetchRing {
     std::thread worker;
 };
 
+// Lanes (include/ltm.h): the projection kernels are bound by vector-instruction issue, everything else by launch latency.  Two projection launches of two
+// lanes running TOGETHER share the vector pipes and end together, after which both lanes' latency-bound stages run together on an idle machine
+// (measured, tools/ubench/stream_priority.hip and profiles/r6_lanes_*: "lockstep").  So the heavy launches of a lane family are CHAINED -- each waits,
+// on the device, for the previous one of any lane -- and go to a stream of the lowest priority: one heavy kernel at a time fills the machine while the
+// other lane's grids / scans / partitions are dispatched ahead of its remaining workgroups.
+struct HeavyChain {
+    std::mutex mx;
+    hipEvent_t last = nullptr;      // end of the most recent heavy launch of the family
+    ~HeavyChain() { if (last) (void)hipEventDestroy(last); }
+};
+
 struct ltm_ctx {
+    std::recursive_mutex mx;        // every entry point holds it (guarded): handles may be freed from any thread, lanes exchange clouds under both locks
     ltm_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t heavy_stream = nullptr;          // lowest priority; created with the first lane of the family (one-lane contexts launch everything on `stream`)
+    std::shared_ptr<HeavyChain> heavy;           // shared by a context and its lanes
+    int heavy_chain_on = 1, heavy_priority_on = 1;      // LTM_HEAVY_CHAIN=0 / LTM_HEAVY_PRIORITY=0: A/B switches
+    size_t heavy_min_blocks = 100000;            // LTM_HEAVY_MIN_BLOCKS: launches below this many workgroups (revert passes on the small dynamic map, ND / PD filters) run unchained
     HostMat34 L2B, B2L;
     int l2b_identity = 1, b2l_identity = 1;
     size_t kf_batch = 512;
@@ -269,6 +296,41 @@ struct ProfScope {   // HIP-event bracket around one kernel class on the context
         c->pending.push_back(Pending{cls, a, b});
     }
 };
+// One heavy (vector-issue bound) launch of a lane family: see HeavyChain.  stream() is where the launch goes.  Without lanes (no heavy stream) this is a no-op
+// on the context's own stream.
+struct HeavyScope {
+    ltm_ctx* c; bool hop = false, chained = false;
+    HeavyScope(ltm_ctx* c_, size_t n_blocks) : c(c_)
+    {
+        if (!c->heavy_stream || n_blocks < c->heavy_min_blocks) return;
+        hop = c->heavy_priority_on != 0;
+        chained = c->heavy_chain_on != 0;
+        if (hop) {
+            hipEvent_t e = get_event(c);
+            LTM_HIP(hipEventRecord(e, c->stream));
+            LTM_HIP(hipStreamWaitEvent(c->heavy_stream, e, 0));
+            c->event_pool.push_back(e);
+        }
+        if (chained) {
+            std::lock_guard<std::mutex> lk(c->heavy->mx);
+            if (c->heavy->last) LTM_HIP(hipStreamWaitEvent(stream(), c->heavy->last, 0));
+        }
+    }
+    hipStream_t stream() const { return hop ? c->heavy_stream : c->stream; }
+    void done()      // after the launch: the family's next heavy launch and this context's own stream continue behind it
+    {
+        if (!hop && !chained) return;
+        hipEvent_t e = nullptr;
+        LTM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        hipError_t rc = hipEventRecord(e, stream());
+        if (rc == hipSuccess && hop) rc = hipStreamWaitEvent(c->stream, e, 0);
+        if (rc != hipSuccess || !chained) { (void)hipEventDestroy(e); LTM_HIP(rc); return; }
+        std::lock_guard<std::mutex> lk(c->heavy->mx);
+        if (c->heavy->last) (void)hipEventDestroy(c->heavy->last);      // waits already enqueued on it keep it alive inside the runtime
+        c->heavy->last = e;
+    }
+};
+
 static constexpr int kLiveSlots = 4096;
 void prof_collect(ltm_ctx* c)
 {
@@ -696,7 +758,9 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     // (the list-driven launch exists for the block-local arg-min kernel only: LTM_MAP_KERNEL=0/1, the A/B baselines, take the plain launch)
     const bool occl = c->occlusion_cull && c->kopts.map_kernel_variant >= 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
     if (!occl) {
-        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, c->stream, c->kopts));
+        HeavyScope hs(c, n_pairs);
+        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, hs.stream(), c->kopts));
+        hs.done();
         return;
     }
     const size_t rbs = (size_t)g.rows, cbs = ((size_t)g.cols + 7) / 8;
@@ -735,7 +799,11 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
         LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream, dirty));
         uint32_t n_live = 0;
         d2h(c, &n_live, count, 4);
-        LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, c->stream, c->kopts));
+        {
+            HeavyScope hs(c, n_live);
+            LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, hs.stream(), c->kopts));
+            hs.done();
+        }
         n_proj += n_live;
         if (shell == 0) c->occl_near += n_live;
         if (last) break;
@@ -788,8 +856,10 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
             }
             ProfScope p(c, cull ? "vote_map_cull" : "vote_map_exact", pts, bytes, bytes_c);
             if (cull) {
+                HeavyScope hs(c, n_tiles * nb);
                 LTM_HIP(vote_map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, qbound, tb.as<float>(), smax, thr, mode,
-                                              map_img.as<uint64_t>(), c->stream, c->kopts));
+                                              map_img.as<uint64_t>(), hs.stream(), c->kopts));
+                hs.done();
             } else exact_map_images(c, map, ps, kb, nb, g, map_img.as<uint64_t>());
         }
         {
@@ -1287,6 +1357,7 @@ template <class F>
 int guarded(ltm_ctx* c, F&& f)
 {
     if (!c) return LTM_E_INVALID;
+    std::lock_guard<std::recursive_mutex> lk(c->mx);
     try {
         use_device(c);
         f();
@@ -1306,6 +1377,39 @@ int guarded(ltm_ctx* c, F&& f)
     }
 }
 
+// two contexts, one call: both locks, taken in address order whichever thread calls
+struct TwoLocks {
+    std::unique_lock<std::recursive_mutex> a, b;
+    TwoLocks(ltm_ctx* x, ltm_ctx* y)
+    {
+        if (x == y) { a = std::unique_lock<std::recursive_mutex>(x->mx); return; }
+        ltm_ctx* lo = x < y ? x : y; ltm_ctx* hi = x < y ? y : x;
+        a = std::unique_lock<std::recursive_mutex>(lo->mx); b = std::unique_lock<std::recursive_mutex>(hi->mx);
+    }
+};
+// everything submitted to `to` from now on runs after everything submitted to `from` so far
+void stream_after(ltm_ctx* from, ltm_ctx* to)
+{
+    if (from == to) return;
+    hipEvent_t e = nullptr;
+    LTM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipError_t rc = hipEventRecord(e, from->stream);
+    if (rc == hipSuccess) rc = hipStreamWaitEvent(to->stream, e, 0);
+    (void)hipEventDestroy(e);      // the wait has captured the recorded state; the runtime keeps the event alive until then
+    LTM_HIP(rc);
+}
+template <class F>
+int guarded2(ltm_ctx* from, ltm_ctx* to, F&& f)
+{
+    if (!from || !to) return LTM_E_INVALID;
+    TwoLocks lk(from, to);
+    const int rc = guarded(from, [&] {
+        LTM_REQUIRE(from->device == to->device, "lanes must share one device");
+        f();
+    });
+    if (rc != LTM_OK) to->err = from->err;
+    return rc;
+}
 } // namespace
 
 // =========================================================================================== C ABI
@@ -1374,7 +1478,11 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
         c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
+        if (const char* v = getenv("LTM_HEAVY_CHAIN")) c->heavy_chain_on = atoi(v);
+        if (const char* v = getenv("LTM_HEAVY_PRIORITY")) c->heavy_priority_on = atoi(v);
+        if (const char* v = getenv("LTM_HEAVY_MIN_BLOCKS")) c->heavy_min_blocks = (size_t)atoll(v);
     }
+    c->heavy = std::make_shared<HeavyChain>();
     *out = c;
     return LTM_OK;
 }
@@ -1405,6 +1513,7 @@ void ltm_destroy(ltm_ctx* c)
         fprintf(stderr, "[ltm] device pool: %zu hipMalloc calls, %.1f MB held, %.1f ms inside hipMalloc; pinned host blocks: %zu, %.1f MB, %.1f ms inside hipHostMalloc\n",
                 c->pool.n_malloc, c->pool.bytes_total / 1048576.0, 1e3 * c->pool.malloc_s, c->pinned.size(), c->pinned_bytes / 1048576.0, 1e3 * c->pinned_s);
     c->pool.release_all();
+    if (c->heavy_stream) { (void)hipStreamSynchronize(c->heavy_stream); (void)hipStreamDestroy(c->heavy_stream); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1565,7 +1674,7 @@ int ltm_buffer_copy(ltm_ctx* c, void* dst, const void* src, size_t bytes, int ki
 }
 int ltm_cloud_free(ltm_ctx* c, ltm_cloud h)
 {
-    return guarded(c, [&] { Cloud& cl = get_cloud(c, h); c->pool.free(cl.d); c->clouds.erase(h); });
+    return guarded(c, [&] { Cloud& cl = get_cloud(c, h); if (!cl.borrowed) c->pool.free(cl.d); c->clouds.erase(h); });
 }
 
 // ---------------------------------------------------------------------------- scan sets
@@ -1690,7 +1799,7 @@ int ltm_scanset_alloc(ltm_ctx* c, const uint64_t* off, size_t n_kf, ltm_scanset*
 }
 int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
 {
-    return guarded(c, [&] { ScanSet& s = get_ss(c, h); scan_cache_drop(c, h); c->pool.free(s.d); c->pool.free(s.off_dev); c->scansets.erase(h); });
+    return guarded(c, [&] { ScanSet& s = get_ss(c, h); scan_cache_drop(c, h); if (!s.borrowed) { c->pool.free(s.d); c->pool.free(s.off_dev); } c->scansets.erase(h); });
 }
 
 // ------------------------------------------------------------------ pipelined upload / async fetch
@@ -2542,6 +2651,126 @@ int ltm_visibility_partition(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_pos
         do_partition(c, map, labels.as<uint8_t>(), kept, flagged);
     });
 }
+
+// ------------------------------------------------------------------------------- lanes
+struct ltm_event { hipEvent_t e = nullptr; int device = 0; };
+
+int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
+{
+    if (!parent || !out) return LTM_E_INVALID;
+    *out = nullptr;
+    ltm_ctx* c = new (std::nothrow) ltm_ctx();
+    if (!c) return LTM_E_NOMEM;
+    {
+        std::lock_guard<std::recursive_mutex> lk(parent->mx);
+        c->cfg = parent->cfg; c->device = parent->device; c->L2B = parent->L2B; c->B2L = parent->B2L;
+        c->l2b_identity = parent->l2b_identity; c->b2l_identity = parent->b2l_identity; c->kf_batch = parent->kf_batch; c->kopts = parent->kopts;
+        c->fast_math = parent->fast_math;      // the exhaustive create-time self-check is a property of (device, vfov, hfov): not repeated
+        for (int i = 0; i < 3; ++i) c->selfcheck[i] = parent->selfcheck[i];
+        c->scan_cache_cap = parent->scan_cache_cap; c->voxel_packed_sort = parent->voxel_packed_sort; c->occlusion_cull = parent->occlusion_cull;
+        c->occlusion_min_pairs = parent->occlusion_min_pairs; c->occlusion_r_near = parent->occlusion_r_near; c->occlusion_incremental = parent->occlusion_incremental;
+        c->voxel_key_compress = parent->voxel_key_compress; c->voxel_fused_tail = parent->voxel_fused_tail; c->voxel_identity = parent->voxel_identity;
+        c->knn_two_phase = parent->knn_two_phase; c->knn_sort_queue = parent->knn_sort_queue; c->knn_stats_on = parent->knn_stats_on;
+        c->cull_eps_scale = parent->cull_eps_scale; c->cull_eps_floor = parent->cull_eps_floor;
+        c->el_fit = parent->el_fit; for (int i = 0; i < 4; ++i) c->el_c[i] = parent->el_c[i]; c->el_fit_err = parent->el_fit_err;
+    }
+    int prio_least = 0, prio_greatest = 0;
+    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
+        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipStreamCreateWithPriority(&c->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
+        if (c->stream) (void)hipStreamDestroy(c->stream);
+        delete c;
+        return LTM_E_DEVICE;
+    }
+    {      // the parent joins the family: from now on its heavy launches are chained with the lane's, on a low-priority stream of its own
+        std::lock_guard<std::recursive_mutex> lk(parent->mx);
+        c->heavy = parent->heavy;
+        c->heavy_chain_on = parent->heavy_chain_on; c->heavy_priority_on = parent->heavy_priority_on; c->heavy_min_blocks = parent->heavy_min_blocks;
+        if (!parent->heavy_stream && hipStreamCreateWithPriority(&parent->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
+            parent->heavy_stream = nullptr;
+            (void)hipStreamDestroy(c->heavy_stream); (void)hipStreamDestroy(c->stream);
+            delete c;
+            return LTM_E_DEVICE;
+        }
+    }
+    *out = c;
+    return LTM_OK;
+}
+
+int ltm_lane_fence(ltm_ctx* from, ltm_ctx* to) { return guarded2(from, to, [&] { stream_after(from, to); }); }
+
+int ltm_event_record(ltm_ctx* c, ltm_event** ev)
+{
+    if (ev) *ev = nullptr;
+    return guarded(c, [&] {
+        LTM_REQUIRE(ev, "null argument");
+        std::unique_ptr<ltm_event> t(new ltm_event());
+        t->device = c->device;
+        LTM_HIP(hipEventCreateWithFlags(&t->e, hipEventDisableTiming));
+        const hipError_t rc = hipEventRecord(t->e, c->stream);
+        if (rc != hipSuccess) { (void)hipEventDestroy(t->e); LTM_HIP(rc); }
+        *ev = t.release();
+    });
+}
+int ltm_event_wait(ltm_ctx* c, ltm_event* ev)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(ev && ev->e, "null event");
+        LTM_REQUIRE(ev->device == c->device, "event of another device");
+        LTM_HIP(hipStreamWaitEvent(c->stream, ev->e, 0));
+    });
+}
+void ltm_event_destroy(ltm_event* ev)
+{
+    if (!ev) return;
+    if (ev->e) { (void)hipSetDevice(ev->device); (void)hipEventDestroy(ev->e); }
+    delete ev;
+}
+
+static int cloud_pass(ltm_ctx* from, ltm_cloud h, ltm_ctx* to, ltm_cloud* out, bool give)
+{
+    return guarded2(from, to, [&] {
+        LTM_REQUIRE(out, "null argument");
+        LTM_REQUIRE(from != to, "lend / give need two contexts");
+        const Cloud src = get_cloud(from, h);
+        LTM_REQUIRE(!give || !src.borrowed, "a borrowed cloud cannot be given away");
+        stream_after(from, to);
+        const ltm_cloud nh = new_cloud(to, src.d, src.n);
+        Cloud& dst = to->clouds[nh];
+        dst.vf_ok = src.vf_ok; dst.vf = src.vf; dst.vleaf = src.vleaf;
+        if (give) {
+            if (!from->pool.move_to(src.d, to->pool)) { to->clouds.erase(nh); throw Err{LTM_E_INVALID, "cloud memory is not owned by this context's pool"}; }
+            from->clouds.erase(h);
+        } else dst.borrowed = true;
+        *out = nh;
+    });
+}
+int ltm_cloud_lend(ltm_ctx* from, ltm_cloud h, ltm_ctx* to, ltm_cloud* out) { return cloud_pass(from, h, to, out, false); }
+int ltm_cloud_give(ltm_ctx* from, ltm_cloud h, ltm_ctx* to, ltm_cloud* out) { return cloud_pass(from, h, to, out, true); }
+
+static int scanset_pass(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* out, bool give)
+{
+    return guarded2(from, to, [&] {
+        LTM_REQUIRE(out, "null argument");
+        LTM_REQUIRE(from != to, "lend / give need two contexts");
+        ScanSet& src = get_ss(from, h);
+        LTM_REQUIRE(!give || !src.borrowed, "a borrowed scan set cannot be given away");
+        stream_after(from, to);
+        ScanSet dst;
+        dst.d = src.d; dst.n_pts = src.n_pts; dst.off = src.off; dst.off_dev = src.off_dev; dst.borrowed = !give;
+        if (give) {
+            LTM_REQUIRE(from->pool.live.count(src.d) && from->pool.live.count(src.off_dev), "scan set memory is not owned by this context's pool");
+            scan_cache_drop(from, h);
+            from->pool.move_to(src.d, to->pool); from->pool.move_to(src.off_dev, to->pool);
+            from->scansets.erase(h);
+        }
+        const uint64_t nh = to->next_handle++;
+        to->scansets[nh] = std::move(dst);
+        *out = nh;
+    });
+}
+int ltm_scanset_lend(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* out) { return scanset_pass(from, h, to, out, false); }
+int ltm_scanset_give(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* out) { return scanset_pass(from, h, to, out, true); }
 
 int ltm_reproject(ltm_ctx* c, ltm_cloud hmap, ltm_poses hp, size_t kf_begin, size_t kf_end, float alpha, ltm_scanset* out)
 {

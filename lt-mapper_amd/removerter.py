@@ -71,6 +71,9 @@ class HipOps:
     def zip_concat(self, a, b, c): return self.ctx.zip_concat(a, b, c)
     def sync(self): self.ctx.synchronize()
     def materialize(self, scans): return scans          # single GPU: scan sets are always whole
+    # lanes (include/ltm.h "lanes"): a second context on the same device, driven by a second host thread
+    def lane(self): return HipOps(self.ctx.lane())
+    def poses_like(self, poses): return self.ctx.poses(poses.host_poses, poses.host_inv)      # the same keyframe poses as a handle of THIS context
 
     # ---- pieces used by dist.ShardedOps (keyframe ranges + tensors for the collectives)
     def n_keyframes(self, poses): return poses.n
@@ -161,13 +164,18 @@ class Session:
 class Removerter:
     kReprojectionAlpha = 3.0     # Session.h:13
 
-    def __init__(self, ops, params: Params, central: Session, query: Session, query_side=None):
-        """`query_side` = (ops2, query session as ops2 sees it): an experiment, off by default -- the merge + grid and the Step-1 chain of the
+    def __init__(self, ops, params: Params, central: Session, query: Session, query_side=None, lane_ops=None):
+        """`lane_ops` = ops of a LANE of `ops`'s context (HipOps.lane()): the independent chains of run() -- the two sessions' makeGlobalMap + Step 1, the two
+        directions of the LD kNN diff, the ND against the PD filter, the reprojections of Step 3 -- run side by side, the query / PD / "strong" halves on the
+        lane from a second host thread (run_two_lanes).  Same clouds as the one-lane order, bit for bit: every kernel sees the same inputs.
+
+        `query_side` = (ops2, query session as ops2 sees it): an experiment, off by default -- the merge + grid and the Step-1 chain of the
         query session run on a second device context (own stream, own pool) from a second host thread while this one does the central
         session's; the two chains share nothing (Removerter.cpp:1584-1591 runs them one after the other), their results are the same clouds."""
         self.ops, self.P = ops, params
         self.central_sess_, self.query_sess_ = central, query
         self.query_side = query_side
+        self.lane_ops = lane_ops
         # cascade.run_cascade: a callable that delivers the central session's scans (the previous run's scans_updated, re-gridded: its host half is still
         # running when this run starts).  While it is set, run() takes the query session's makeGlobalMap + Step-1 chain first -- it does not depend on the
         # central scans (Removerter.cpp:1584-1591 runs the two sessions one after the other, either order gives the same clouds) -- and asks for the scans then
@@ -346,10 +354,11 @@ class Removerter:
         self._tick("reproject_static", t0)
 
     # ------------------------------------------------------------------ Step 2
-    def _removeOnceLD(self, target_maps, source, res_alpha, mode):   # iremoveOnceForND :831-854 / removeOnceForPD :856-880
+    def _removeOnceLD(self, target_maps, source, res_alpha, mode, ops=None):   # iremoveOnceForND :831-854 / removeOnceForPD :856-880
+        ops = ops or self.ops
         cur, strong, weak = target_maps
-        static_tt, dynamic_tt = self.ops.vote_partition(cur, source.keyframe_scans_static_projected_, source.keyframe_poses, res_alpha, 0.1, mode)
-        strong, weak = self.octreeDownsamplingBatch([static_tt, self._append(weak, dynamic_tt)], 0.05)
+        static_tt, dynamic_tt = ops.vote_partition(cur, source.keyframe_scans_static_projected_, source.keyframe_poses, res_alpha, 0.1, mode)
+        strong, weak = ops.voxel_batch([static_tt, self._append(weak, dynamic_tt, ops)], 0.05)
         cur = strong
         return cur, strong, weak
 
@@ -444,6 +453,149 @@ class Removerter:
                 "scans_pd": C.keyframe_scans_pd_, "scans_pd_strong": C.keyframe_scans_strong_pd_,
                 "scans_nd_strong": C.keyframe_scans_strong_nd_}
 
+    # ------------------------------------------------------------------ two lanes (include/ltm.h "lanes")
+    def _fork(self, main_fn, lane_fn):
+        """main_fn on this thread and context, lane_fn on a second thread and the lane context; returns when both are done (host side) and the main context's
+        next work is ordered after everything the lane submitted (device side)"""
+        import threading
+        M, L = self.ops.ctx, self.lane_ops.ctx
+        err = []
+
+        def run():
+            try:
+                lane_fn()
+            except BaseException as e:      # noqa: BLE001 -- re-raised on the calling thread
+                err.append(e)
+        M.fence(L)                           # the lane starts after what the main context has been given so far (its inputs, recycled blocks)
+        th = threading.Thread(target=run)
+        th.start()
+        try:
+            main_fn()
+        finally:
+            th.join()
+        if err:
+            raise err[0]
+        L.fence(M)                           # later frees / overwrites of lent clouds on the main context run after the lane's reads
+
+    def run_two_lanes(self):
+        """run() with the independent chains side by side on the main context and its lane (Removerter.cpp:1653-1678; which stages are independent: include/ltm.h).
+        Stage A: makeGlobalMap + Step-1 chain + HD kNN map + static reprojection of the central session (main) and of the query session (lane); the library
+                 chains the two lanes' large projection launches, which keeps the chains in anti-phase -- one lane's partition + grids under the other's vote;
+        Stage B: C -> Q kNN diff, ND filter and the central-side grids of :1445-1476 (main); Q -> C kNN diff, PD filter and the query-side grids (lane);
+        Stage C: updateCurrentMap, then the reprojections of the updated / weak-ND / PD maps and updateScansScanwise (main) beside those of the
+                 "strong" maps (lane)."""
+        ops, lops, P = self.ops, self.lane_ops, self.P
+        M, L = ops.ctx, lops.ctx
+        C, Q = self.central_sess_, self.query_sess_
+        k, thr = P.num_nn_points_within, P.dist_nn_points_within
+        o = self.outputs
+        # ---- stage A
+        t0 = time.perf_counter()
+        Ql = Session("Query", M.lend(Q.keyframe_scans_, L), lops.poses_like(Q.keyframe_poses))      # the lane's view of the query session
+        Cl_poses = lops.poses_like(C.keyframe_poses)
+
+        def chain(s, op):
+            if s is C and self.central_scans_future is not None:      # cascade: the hand-over's host half ends here, the lane is already at work
+                s.keyframe_scans_ = self.central_scans_future()
+                self.central_scans_future = None
+            s.map_global_curr_ = op.voxel(op.merge_to_global(s.keyframe_scans_, s.keyframe_poses), P.downsample_voxel_size)
+            s.map_global_orig_noisy_ = s.map_global_curr_
+            self._removeHighDynamicOf(s, op)
+            if not P.gpu_skip_hd_knn:
+                _, s.keyframe_scans_dynamic_ = op.knn_partition(s.map_global_curr_static_, s.keyframe_scans_, s.keyframe_poses, k, thr)  # Session.cpp:487-504
+                s.high_dyn_ = op.merge_voxel_batch([(s.keyframe_scans_dynamic_, s.keyframe_poses)], [], 0.05)[0]
+            s.keyframe_scans_static_projected_ = op.reproject(s.map_global_curr_, s.keyframe_poses, self.kReprojectionAlpha)      # Session.cpp:305-309
+        self._fork(lambda: chain(C, ops), lambda: chain(Ql, lops))
+        for name in ("map_global_orig_noisy_", "map_global_curr_static_", "map_global_curr_dynamic_"):
+            setattr(Q, name, L.give(getattr(Ql, name), M))
+        Q.map_global_curr_ = Q.map_global_curr_static_
+        for s in (C, Q):
+            o["OriginalNoisy" + s.sess_type_ + "MapGlobal"] = s.map_global_orig_noisy_
+        if not P.gpu_skip_hd_knn:
+            Q.keyframe_scans_dynamic_ = L.give(Ql.keyframe_scans_dynamic_, M)
+            o["central_sess_high_dyn"], o["query_sess_high_dyn"] = C.high_dyn_, L.give(Ql.high_dyn_, M)
+        self._tick("lanes_step1", t0)
+        # ---- stage B
+        t0 = time.perf_counter()
+        Qproj_view = L.lend(Ql.keyframe_scans_static_projected_, M)
+        Cstat_view, Cproj_view = M.lend(C.map_global_curr_static_, L), M.lend(C.keyframe_scans_static_projected_, L)
+        q_src = Session("Query", None, Q.keyframe_poses); q_src.keyframe_scans_static_projected_ = Qproj_view
+        c_src = Session("Central", None, Cl_poses); c_src.keyframe_scans_static_projected_ = Cproj_view
+
+        def central_side():      # Session.cpp:393-427 C -> Q; constructGlobalNDMap :430-435, filterStrongND :1403-1411, weak -> strong :452-484; grids of :1447-1476
+            C.scans_knn_coexist_, C.scans_knn_diff_ = ops.knn_partition(Q.map_global_curr_static_, C.keyframe_scans_static_projected_, C.keyframe_poses, k, thr)
+            C.map_global_nd_ = ops.merge_voxel_batch([(C.scans_knn_diff_, C.keyframe_poses)], [], 0.05)[0]
+            maps = (C.map_global_nd_, None, None)
+            for _ in range(3):
+                maps = self._removeOnceLD(maps, q_src, 2.5, 1, ops)
+            C.map_global_nd_, C.map_global_nd_strong_, C.map_global_nd_weak_ = maps
+            if ops.size(C.map_global_nd_strong_) != 0:
+                add, new_weak = ops.knn_split(C.map_global_nd_strong_, C.map_global_nd_weak_, 2, 1.0)
+                C.map_global_nd_strong_ = ops.concat([C.map_global_nd_strong_, add])
+                C.map_global_nd_weak_ = new_weak
+            has_strong_nd = ops.size(C.map_global_nd_strong_) != 0
+            res = ops.merge_voxel_batch([(C.scans_knn_coexist_, C.keyframe_poses), (C.scans_knn_diff_, C.keyframe_poses)],
+                                        [C.map_global_nd_weak_] + ([C.map_global_nd_strong_] if has_strong_nd else []), 0.05)
+            self._union_c = o["union_map_centralside"] = res[0]
+            o["nd_map"] = res[1]
+            C.map_global_nd_weak_ = o["weak_nd_map"] = res[2]
+            if has_strong_nd:
+                C.map_global_nd_strong_ = o["strong_nd_map"] = res[3]
+
+        def query_side():        # Session.cpp:393-427 Q -> C; constructGlobalPDMap :437-445, filterStrongPD :1395-1401; grids of :1445-1476
+            Ql.scans_knn_coexist_, Ql.scans_knn_diff_ = lops.knn_partition(Cstat_view, Ql.keyframe_scans_static_projected_, Ql.keyframe_poses, k, thr)
+            Ql.map_global_pd_ = lops.merge_voxel_batch([(Ql.scans_knn_diff_, Ql.keyframe_poses)], [], 0.05)[0]
+            Ql.map_global_pd_orig_ = Ql.map_global_pd_
+            maps = (Ql.map_global_pd_, None, None)
+            for _ in range(3):
+                maps = self._removeOnceLD(maps, c_src, 2.5, 0, lops)
+            Ql.map_global_pd_, Ql.map_global_pd_strong_, Ql.map_global_pd_weak_ = maps
+            res = lops.merge_voxel_batch([(Ql.scans_knn_coexist_, Ql.keyframe_poses), (Ql.scans_knn_diff_, Ql.keyframe_poses)],
+                                         [Ql.map_global_pd_strong_, Ql.map_global_pd_weak_], 0.05)
+            Ql.union_q_, Ql.pd_map_, Ql.map_global_pd_strong_, Ql.map_global_pd_weak_ = res
+        self._fork(central_side, query_side)
+        del Cstat_view, Cproj_view, Qproj_view
+        q_src.keyframe_scans_static_projected_ = c_src.keyframe_scans_static_projected_ = None
+        to_main = lambda x: L.give(x, M)      # noqa: E731
+        Q.keyframe_scans_static_projected_ = to_main(Ql.keyframe_scans_static_projected_)
+        Q.scans_knn_coexist_, Q.scans_knn_diff_ = to_main(Ql.scans_knn_coexist_), to_main(Ql.scans_knn_diff_)
+        same_pd = Ql.map_global_pd_orig_ is Ql.map_global_pd_
+        Q.map_global_pd_orig_ = to_main(Ql.map_global_pd_orig_)
+        Q.map_global_pd_ = Q.map_global_pd_orig_ if same_pd else to_main(Ql.map_global_pd_)
+        self._union_q = o["union_map_queryside"] = to_main(Ql.union_q_)
+        o["pd_map"] = to_main(Ql.pd_map_)
+        Q.map_global_pd_strong_ = o["strong_pd_map"] = to_main(Ql.map_global_pd_strong_)
+        Q.map_global_pd_weak_ = o["weak_pd_map"] = to_main(Ql.map_global_pd_weak_)
+        C.map_global_pd_, C.map_global_pd_orig_, C.map_global_pd_strong_ = Q.map_global_pd_, Q.map_global_pd_orig_, Q.map_global_pd_strong_   # :1435-1437
+        self._tick("lanes_low_dynamic", t0)
+        # ---- stage C
+        t0 = time.perf_counter()
+        self.updateCurrentMap()
+        nd_strong = C.map_global_nd_strong_ if C.map_global_nd_strong_ is not None else ops.empty_cloud()
+        views = [M.lend(x, L) for x in (C.map_global_pd_strong_, nd_strong, C.map_global_updated_strong_)]
+        got = {}
+
+        def main_side():         # Removerter.cpp:1551-1577 (updated, PD, weak ND) + :1540-1549
+            a = self.kReprojectionAlpha
+            C.keyframe_scans_updated_ = ops.reproject(C.map_global_updated_, C.keyframe_poses, a)
+            C.keyframe_scans_pd_ = ops.reproject(C.map_global_pd_orig_, C.keyframe_poses, a)
+            C.keyframe_scans_weak_nd_ = ops.reproject(C.map_global_nd_weak_, C.keyframe_poses, a)
+            merged = ops.zip_concat(C.keyframe_scans_updated_, C.keyframe_scans_weak_nd_, C.keyframe_scans_pd_)
+            C.keyframe_scans_updated_ = ops.voxel_scanset(merged, 0.05)
+
+        def lane_side():         # the "strong" halves of :1551-1577
+            a = self.kReprojectionAlpha
+            got["strong_pd"] = lops.reproject(views[0], Cl_poses, a)
+            got["strong_nd"] = lops.reproject(views[1], Cl_poses, a)
+            got["updated_strong"] = lops.reproject(views[2], Cl_poses, a)
+        self._fork(main_side, lane_side)
+        del views
+        C.keyframe_scans_strong_pd_, C.keyframe_scans_strong_nd_ = to_main(got["strong_pd"]), to_main(got["strong_nd"])
+        C.keyframe_scans_updated_strong_ = to_main(got["updated_strong"])
+        self._tick("lanes_step3", t0)
+        self.outputs.update(central_map_static=C.map_global_curr_static_, central_map_dynamic=C.map_global_curr_dynamic_,
+                            query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
+
     # ------------------------------------------------------------------ run()
     def run_steps_1_to_3(self):                         # Removerter.cpp:1664-1675 (file I/O excluded)
         self.removeHighDynamicPoints()
@@ -466,6 +618,8 @@ class Removerter:
                             query_map_static=Q.map_global_curr_static_, query_map_dynamic=Q.map_global_curr_dynamic_)
 
     def run(self):
+        if self.lane_ops is not None and self.query_side is None and self._rankGroups() is None:
+            return self.run_two_lanes()
         if self.central_scans_future is not None and (self.query_side is not None or self._rankGroups() is not None):
             self.central_sess_.keyframe_scans_ = self.central_scans_future()      # (the deferred hand-over is a single-context path)
             self.central_scans_future = None
