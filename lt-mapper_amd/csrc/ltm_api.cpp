@@ -51,9 +51,23 @@ struct Err { int code; std::string msg; };
 // into a (possibly recycled) block, ltm_scanset_upload_end drains the copy stream; fetches record an event on the compute
 // stream and their sources are kept alive by the caller.  hipMalloc/hipFree (which synchronise the device) happen only on
 // first use of a size class and at ltm_destroy().
+// Lanes: a block that ltm_*_give moved into another context's pool goes HOME when it is freed there (through the home pool's inbox, with an event of
+// the freeing stream that the home stream waits for before the block is handed out again).  Without this every pair run would move ~1.5 GB from the
+// lane's pool into the main one for good: the lane would hipMalloc -- which waits for the whole device, both lanes' queues included -- some twenty
+// times per run and the main pool would grow without bound (measured: profiles/r6_lanes_pool_migration.txt).
+struct PoolInbox {
+    struct Item { void* p; size_t bytes; hipEvent_t ev; };
+    std::mutex mx;
+    std::vector<Item> items;
+    bool closed = false;            // the home pool is gone: returned blocks are released instead
+};
 struct Pool {
     std::multimap<size_t, void*> free_blocks;
     std::unordered_map<void*, size_t> live;
+    struct Foreign { size_t bytes; std::shared_ptr<PoolInbox> home; };
+    std::unordered_map<void*, Foreign> foreign;      // live blocks that belong to another context's pool
+    std::shared_ptr<PoolInbox> inbox = std::make_shared<PoolInbox>();
+    hipStream_t stream = nullptr;   // the owning context's stream (events of returned blocks)
     size_t bytes_total = 0;
     size_t n_malloc = 0;            // diagnostics (LTM_POOL_STATS=1 prints them when the context is destroyed)
     double malloc_s = 0.0;
@@ -64,10 +78,20 @@ struct Pool {
         size_t step = (size_t)1 << (e > 3 ? e - 3 : 0);   // 8 size classes per power of two
         return (b + step - 1) / step * step;
     }
+    void drain_inbox()
+    {
+        std::vector<PoolInbox::Item> got;
+        { std::lock_guard<std::mutex> lk(inbox->mx); got.swap(inbox->items); }
+        for (const PoolInbox::Item& it : got) {
+            if (it.ev) { (void)hipStreamWaitEvent(stream, it.ev, 0); (void)hipEventDestroy(it.ev); }
+            free_blocks.emplace(it.bytes, it.p);
+        }
+    }
     void* alloc(size_t bytes)
     {
         if (bytes == 0) bytes = 1;
         const size_t want = round_up(bytes);
+        drain_inbox();
         auto it = free_blocks.lower_bound(want);
         if (it != free_blocks.end() && it->first <= want + want / 4) {
             void* p = it->second;
@@ -96,27 +120,56 @@ struct Pool {
     {
         if (!p) return;
         auto it = live.find(p);
-        if (it == live.end()) return;
-        free_blocks.emplace(it->second, p);
-        live.erase(it);
+        if (it != live.end()) {
+            free_blocks.emplace(it->second, p);
+            live.erase(it);
+            return;
+        }
+        auto f = foreign.find(p);
+        if (f == foreign.end()) return;
+        send_home(p, f->second, true);
+        foreign.erase(f);
     }
-    // ltm_*_give: a live block changes pools (both contexts on one device)
+    void send_home(void* p, const Foreign& f, bool with_event)
+    {
+        hipEvent_t ev = nullptr;
+        if (with_event && (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess)) {
+            if (ev) (void)hipEventDestroy(ev);
+            ev = nullptr;
+            (void)hipStreamSynchronize(stream);      // no event: the block goes home only when this stream is done with it
+        }
+        std::unique_lock<std::mutex> lk(f.home->mx);
+        if (f.home->closed) { lk.unlock(); if (ev) { (void)hipEventSynchronize(ev); (void)hipEventDestroy(ev); } (void)hipFree(p); return; }
+        f.home->items.push_back(PoolInbox::Item{p, f.bytes, ev});
+    }
+    bool owns(void* p) const { return live.count(p) != 0 || foreign.count(p) != 0; }
+    // ltm_*_give: a live block changes contexts (both on one device); its home stays where it was allocated
     bool move_to(void* p, Pool& other)
     {
         auto it = live.find(p);
-        if (it == live.end()) return false;
-        other.live[p] = it->second;
-        other.bytes_total += it->second; bytes_total -= it->second;
-        live.erase(it);
+        if (it != live.end()) {
+            other.foreign[p] = Foreign{it->second, inbox};
+            live.erase(it);
+            return true;
+        }
+        auto f = foreign.find(p);
+        if (f == foreign.end()) return false;
+        if (f->second.home == other.inbox) other.live[p] = f->second.bytes;      // it comes home while still in use
+        else other.foreign[p] = f->second;
+        foreign.erase(f);
         return true;
     }
     void release_cached()
     {
+        drain_inbox();
         for (auto& kv : free_blocks) { (void)hipFree(kv.second); bytes_total -= kv.first; }
         free_blocks.clear();
     }
-    void release_all()
+    void release_all()      // the owning context's streams have been drained
     {
+        for (auto& kv : foreign) send_home(kv.first, kv.second, false);
+        foreign.clear();
+        { std::lock_guard<std::mutex> lk(inbox->mx); inbox->closed = true; }
         release_cached();
         for (auto& kv : live) (void)hipFree(kv.first);
         live.clear();
@@ -185,10 +238,15 @@ struct FetchRing {
 // (measured, tools/ubench/stream_priority.hip and profiles/r6_lanes_*: "lockstep").  So the heavy launches of a lane family are CHAINED -- each waits,
 // on the device, for the previous one of any lane -- and go to a stream of the lowest priority: one heavy kernel at a time fills the machine while the
 // other lane's grids / scans / partitions are dispatched ahead of its remaining workgroups.
+static void destroy_ring(FetchRing* r);
 struct HeavyChain {
     std::mutex mx;
     hipEvent_t last = nullptr;      // end of the most recent heavy launch of the family
-    ~HeavyChain() { if (last) (void)hipEventDestroy(last); }
+    // the family also shares ONE ring of pinned chunks + copier thread for chunked fetches (page-locking 64 MB costs ~30 ms: a lane of a one-shot
+    // run would pay it a second time for the few outputs it writes itself)
+    std::mutex ring_mx;
+    FetchRing* ring = nullptr;
+    ~HeavyChain() { if (last) (void)hipEventDestroy(last); destroy_ring(ring); }
 };
 
 struct ltm_ctx {
@@ -196,9 +254,14 @@ struct ltm_ctx {
     ltm_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t heavy_stream = nullptr;          // lowest priority; created with the first lane of the family (one-lane contexts launch everything on `stream`)
+    hipStream_t heavy_stream = nullptr;          // LTM_HEAVY_PRIORITY=1 only: lowest priority, created with the first lane of the family
+    bool in_lane_family = false;                 // this context has lanes / is one: its heavy launches are chained with theirs
     std::shared_ptr<HeavyChain> heavy;           // shared by a context and its lanes
-    int heavy_chain_on = 1, heavy_priority_on = 1;      // LTM_HEAVY_CHAIN=0 / LTM_HEAVY_PRIORITY=0: A/B switches
+    // LTM_HEAVY_CHAIN=0: no chaining (A/B).  LTM_HEAVY_PRIORITY=1: the heavy launches go to a stream of the lowest priority of their own -- off by default:
+    // it buys nothing measurable (profiles/r6_lanes_*) and every extra stream is one more hardware queue: with five queues on the four compute pipes one
+    // lane's projection stream shared a pipe with the OTHER lane's stream and held up its small launches for the length of a vote (seen with the C++ host,
+    // whose loader had created a copy stream first: 170 instead of 157 ms per step)
+    int heavy_chain_on = 1, heavy_priority_on = 0;
     size_t heavy_min_blocks = 100000;            // LTM_HEAVY_MIN_BLOCKS: launches below this many workgroups (revert passes on the small dynamic map, ND / PD filters) run unchained
     HostMat34 L2B, B2L;
     int l2b_identity = 1, b2l_identity = 1;
@@ -210,7 +273,6 @@ struct ltm_ctx {
     double pinned_s = 0.0;          // diagnostics (LTM_POOL_STATS): time inside hipHostMalloc, bytes pinned
     size_t pinned_bytes = 0;
     std::mutex pinned_mx;           // the pinned blocks are handed back by writer threads (ltm_fetch_release)
-    FetchRing* ring = nullptr;      // chunked fetches: created by the first one
     uint64_t next_handle = 1;
     std::unordered_map<uint64_t, Cloud> clouds;
     std::unordered_map<uint64_t, ScanSet> scansets;
@@ -300,10 +362,12 @@ struct ProfScope {   // HIP-event bracket around one kernel class on the context
 // on the context's own stream.
 struct HeavyScope {
     ltm_ctx* c; bool hop = false, chained = false;
+    std::unique_lock<std::mutex> turn;      // held from the wait for the predecessor until this launch has become the family's latest: two lanes that get here
+                                            // together must not both queue behind the SAME predecessor (they would run side by side -- seen with the C++ host's two threads)
     HeavyScope(ltm_ctx* c_, size_t n_blocks) : c(c_)
     {
-        if (!c->heavy_stream || n_blocks < c->heavy_min_blocks) return;
-        hop = c->heavy_priority_on != 0;
+        if (!c->in_lane_family || n_blocks < c->heavy_min_blocks) return;
+        hop = c->heavy_priority_on != 0 && c->heavy_stream;
         chained = c->heavy_chain_on != 0;
         if (hop) {
             hipEvent_t e = get_event(c);
@@ -312,7 +376,7 @@ struct HeavyScope {
             c->event_pool.push_back(e);
         }
         if (chained) {
-            std::lock_guard<std::mutex> lk(c->heavy->mx);
+            turn = std::unique_lock<std::mutex>(c->heavy->mx);
             if (c->heavy->last) LTM_HIP(hipStreamWaitEvent(stream(), c->heavy->last, 0));
         }
     }
@@ -325,9 +389,9 @@ struct HeavyScope {
         hipError_t rc = hipEventRecord(e, stream());
         if (rc == hipSuccess && hop) rc = hipStreamWaitEvent(c->stream, e, 0);
         if (rc != hipSuccess || !chained) { (void)hipEventDestroy(e); LTM_HIP(rc); return; }
-        std::lock_guard<std::mutex> lk(c->heavy->mx);
         if (c->heavy->last) (void)hipEventDestroy(c->heavy->last);      // waits already enqueued on it keep it alive inside the runtime
         c->heavy->last = e;
+        turn.unlock();
     }
 };
 
@@ -1439,6 +1503,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         delete c;
         return LTM_E_DEVICE;
     }
+    c->pool.stream = c->stream;
     // A/B switches and diagnostics of the projection kernels: part of THIS context (KernelOpts, ltm_kernels.h) -- round 4 kept them in process-wide
     // statics that every ltm_create rewrote, a data race by the letter for `ltm_run --gpus K` (K threads, K contexts)
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
@@ -1487,7 +1552,6 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     return LTM_OK;
 }
 
-static void destroy_ring(ltm_ctx* c);       // chunked-fetch ring and its copier thread (defined with the fetch entry points)
 
 void ltm_destroy(ltm_ctx* c)
 {
@@ -1498,7 +1562,6 @@ void ltm_destroy(ltm_ctx* c)
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }
     for (auto& kv : c->uploads) { for (int b = 0; b < 2; ++b) if (kv.second.ev[b]) (void)hipEventDestroy(kv.second.ev[b]); c->pool.free(kv.second.d); }
-    destroy_ring(c);
     for (PinnedBlock& b : c->pinned) (void)hipHostFree(b.p);
     if (c->scratch_pinned) (void)hipHostFree(c->scratch_pinned);
     if (c->live_counts) (void)hipFree(c->live_counts);
@@ -1936,7 +1999,8 @@ static void ring_worker(FetchRing* r)
 }
 static FetchRing* ensure_ring(ltm_ctx* c)
 {
-    if (c->ring) return c->ring;
+    std::lock_guard<std::mutex> fam(c->heavy->ring_mx);
+    if (c->heavy->ring) return c->heavy->ring;
     std::unique_ptr<FetchRing> r(new FetchRing());
     r->device = c->device;
     size_t mb = 8, n_slots = 8;      // 64 MB pinned once (~15 ms; round 4's 8 x 32 MB cost 45 ms of page-locking inside the first fetch, i.e. inside makeGlobalMap's map write)
@@ -1956,20 +2020,19 @@ static FetchRing* ensure_ring(ltm_ctx* c)
     c->pinned_bytes += n_slots * r->slot_bytes;
     r->free_slots = r->slots;
     r->worker = std::thread(ring_worker, r.get());
-    c->ring = r.release();
-    return c->ring;
+    c->heavy->ring = r.release();
+    return c->heavy->ring;
 }
-static void destroy_ring(ltm_ctx* c)
+static void destroy_ring(FetchRing* r)      // with the last context of the family
 {
-    FetchRing* r = c->ring;
     if (!r) return;
     { std::lock_guard<std::mutex> lk(r->mx); r->stop = true; }
     r->cv_jobs.notify_all();
     r->cv_free.notify_all();
     if (r->worker.joinable()) r->worker.join();
+    (void)hipSetDevice(r->device);
     for (void* p : r->slots) (void)hipHostFree(p);
     delete r;
-    c->ring = nullptr;
 }
 static void fetch_chunks_begin(ltm_ctx* c, const float4* src, size_t n, std::vector<uint64_t> off, ltm_fetch** out)
 {
@@ -2675,23 +2738,27 @@ int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
         c->el_fit = parent->el_fit; for (int i = 0; i < 4; ++i) c->el_c[i] = parent->el_c[i]; c->el_fit_err = parent->el_fit_err;
     }
     int prio_least = 0, prio_greatest = 0;
+    bool prio = false;
+    { std::lock_guard<std::recursive_mutex> lk(parent->mx); prio = parent->heavy_priority_on != 0; }
     if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
         hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipStreamCreateWithPriority(&c->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
+        (prio && hipStreamCreateWithPriority(&c->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess)) {
         if (c->stream) (void)hipStreamDestroy(c->stream);
         delete c;
         return LTM_E_DEVICE;
     }
-    {      // the parent joins the family: from now on its heavy launches are chained with the lane's, on a low-priority stream of its own
+    c->pool.stream = c->stream;
+    {      // the parent joins the family: from now on its heavy launches are chained with the lane's
         std::lock_guard<std::recursive_mutex> lk(parent->mx);
         c->heavy = parent->heavy;
         c->heavy_chain_on = parent->heavy_chain_on; c->heavy_priority_on = parent->heavy_priority_on; c->heavy_min_blocks = parent->heavy_min_blocks;
-        if (!parent->heavy_stream && hipStreamCreateWithPriority(&parent->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
+        if (prio && !parent->heavy_stream && hipStreamCreateWithPriority(&parent->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
             parent->heavy_stream = nullptr;
             (void)hipStreamDestroy(c->heavy_stream); (void)hipStreamDestroy(c->stream);
             delete c;
             return LTM_E_DEVICE;
         }
+        c->in_lane_family = parent->in_lane_family = true;
     }
     *out = c;
     return LTM_OK;
@@ -2759,7 +2826,7 @@ static int scanset_pass(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* 
         ScanSet dst;
         dst.d = src.d; dst.n_pts = src.n_pts; dst.off = src.off; dst.off_dev = src.off_dev; dst.borrowed = !give;
         if (give) {
-            LTM_REQUIRE(from->pool.live.count(src.d) && from->pool.live.count(src.off_dev), "scan set memory is not owned by this context's pool");
+            LTM_REQUIRE(from->pool.owns(src.d) && from->pool.owns(src.off_dev), "scan set memory is not owned by this context's pool");
             scan_cache_drop(from, h);
             from->pool.move_to(src.d, to->pool); from->pool.move_to(src.off_dev, to->pool);
             from->scansets.erase(h);

@@ -41,6 +41,18 @@ private:
     void finishOutputs();      // waits for every queued file, releases the tickets
     bool bench_mode_ = false;  // runBench(): no output files -- saveMap / saveScans return at once
 
+    // Lanes (include/ltm.h; removert/gpu_lanes, default 2 on one GPU): makeGlobalMap + Steps 1-3 with the independent chains of the reference's run()
+    // side by side -- this object drives the central-side halves on its own context, `lane_` (a second Removerter on a lane of the same GPU, run from a
+    // second host thread, with its own writer) the query-side / PD / "strong" halves; clouds pass between the two without copies.  Same outputs as
+    // runStagesOneLane(), byte for byte.
+    std::shared_ptr<Device> lane_dev_;
+    std::unique_ptr<Removerter> lane_;
+    bool useLanes() const { return gpu_lanes_ >= 2 && dev_->world() == 1 && gpu_viz_every_ <= 0; }      // (the RViz images serialise a pass and number their files per object: one lane)
+    void ensureLane();
+    void runStages(bool write_outputs);
+    void runStagesOneLane(bool write_outputs);
+    void runStagesTwoLanes(bool write_outputs);
+
 public:
     Removerter();
     // one rank of a keyframe-sharded multi-GPU run: its own device context plus its Comm endpoint (removert_main.cpp --gpus K)

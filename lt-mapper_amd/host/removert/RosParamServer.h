@@ -49,6 +49,7 @@ public:
     bool gpu_use_self_removert_;   // removert/gpu_use_self_removert: run selfRemovert() (commented out at Removerter.cpp:1582,1586)
     bool gpu_skip_hd_knn_;         // removert/gpu_skip_hd_knn: skip the visualisation-only HD kNN stage
     int gpu_device_;               // removert/gpu_device
+    int gpu_lanes_;                // removert/gpu_lanes (default 2, one GPU only): the independent chains of run() side by side on the context and a lane (include/ltm.h "lanes"); 1 = one after the other
     bool gpu_async_io_;            // removert/gpu_async_io (default true): pipelined loader (decode || H2D) and background output writer; false = the synchronous path
     bool gpu_fetch_chunked_;       // removert/gpu_fetch_chunked (default true): the background writer takes its data through the library's ring of pinned chunks
                                    // (ltm_*_fetch_chunks_begin) instead of one page-locked buffer per output; false = the whole-buffer fetches

@@ -21,6 +21,8 @@ struct Device
     ltm_ctx* ctx = nullptr;
     std::shared_ptr<Comm> comm;             // null = single GPU; else this rank's endpoint of the keyframe-sharded run (Comm.h)
     explicit Device(const RosParamServer& p, int device_ordinal = -1, std::shared_ptr<Comm> comm_ = nullptr);
+    struct LaneOf { Device& parent; };
+    explicit Device(LaneOf l);                // a lane of `parent` (ltm_lane_create): same GPU, own stream and pool, for a second host thread
     ~Device();
     int rank() const { return comm ? comm->rank() : 0; }
     int world() const { return comm ? comm->world() : 1; }
@@ -29,7 +31,13 @@ struct Device
 };
 
 // RAII handles ("boost::shared_ptr<cloud>" of the reference)
-struct CloudH { ltm_ctx* ctx = nullptr; ltm_cloud h = 0; CloudH() = default; CloudH(ltm_ctx* c, ltm_cloud v) : ctx(c), h(v) {} ~CloudH(); size_t size() const; Cloud download() const; };
+struct CloudH
+{
+    ltm_ctx* ctx = nullptr; ltm_cloud h = 0;
+    std::shared_ptr<void> lender;           // a borrowed view (lendCloud) keeps the owner's handle alive
+    CloudH() = default; CloudH(ltm_ctx* c, ltm_cloud v) : ctx(c), h(v) {}
+    ~CloudH(); size_t size() const; Cloud download() const;
+};
 // A scan set is either whole (keyframes 0..n) or, in a multi-GPU run, this rank's SHARD: keyframes [kb, kb + numKeyframes()) of
 // n_total.  Per-keyframe results stay sharded from stage to stage; Session::gatherScans() assembles the whole set when a stage
 // needs every keyframe (merging scans into a global map).
@@ -37,6 +45,7 @@ struct ScansH
 {
     ltm_ctx* ctx = nullptr; ltm_scanset h = 0;
     bool shard = false; size_t kb = 0, n_total = 0;
+    std::shared_ptr<void> lender;           // a borrowed view (lendScans) keeps the owner's handle alive
     ScansH() = default;
     ScansH(ltm_ctx* c, ltm_scanset v) : ctx(c), h(v) {}
     ~ScansH();
@@ -45,6 +54,12 @@ struct ScansH
 };
 using CloudPtr = std::shared_ptr<CloudH>;
 using ScansPtr = std::shared_ptr<ScansH>;
+// lanes (include/ltm.h): a cloud / scan set of one context made usable in another context of the same GPU without a copy.
+// lend*: a view; the owner keeps the memory (and is kept alive by the view).  give*: the memory moves, `c` is left empty.  Null in, null out.
+CloudPtr lendCloud(const CloudPtr& c, Device& to);
+CloudPtr giveCloud(CloudPtr& c, Device& to);
+ScansPtr lendScans(const ScansPtr& s, Device& to);
+ScansPtr giveScans(ScansPtr& s, Device& to);
 
 // ---- free functions of ltremovert/include/removert/utility.h:128-167 on device clouds (thin wrappers over the C ABI; the batch
 // stages of Session / Removerter do not go through them).  Matrices are row-major 4x4 doubles (Matrix4d).
@@ -167,6 +182,8 @@ public:
     CloudPtr concat(const std::vector<CloudPtr>& parts) const;
     void uploadPoses();
     void setKeyframeBlock();        // kf_begin_ / kf_end_ / poses_local_h_ of rank() in world()
+    // lanes: this session becomes `from` as ITS device sees it -- names and poses copied (poses uploaded to this device), the keyframe scans a borrowed view
+    void adoptKeyframes(const Session& from, bool with_scans);
 };
 
 } // namespace ltremovert

@@ -1,6 +1,7 @@
 // Removerter.cpp -- mirror of ltremovert/src/Removerter.cpp over the C ABI (include/ltm.h).
 #include "removert/Removerter.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <sstream>
 
@@ -11,6 +12,7 @@
 #include <fstream>
 #include <iostream>
 #include <stdexcept>
+#include <thread>
 
 namespace ltremovert
 {
@@ -44,6 +46,7 @@ Removerter::~Removerter()
 
 void Removerter::finishOutputs()
 {
+    if (lane_) lane_->finishOutputs();      // its files may still be read out of clouds that were handed over to this context
     if (!writer_) return;
     std::exception_ptr e;
     try { writer_->drain(); } catch (...) { e = std::current_exception(); }
@@ -803,36 +806,235 @@ int Removerter::runBench(int steps, int warmup)
         s.map_global_pd_.reset(); s.map_global_pd_orig_.reset(); s.map_global_pd_strong_.reset(); s.map_global_pd_weak_.reset();
     };
     double total = 0.0;
+    if (useLanes()) ensureLane();
     for (int it = 0; it < warmup + steps; ++it) {
         reset(central_sess_); reset(query_sess_); union_q_.reset(); union_c_.reset();
         ltmCheck(ctx, ltm_clear_caches(ctx), "ltm_clear_caches");      // a step is a whole pass: no scan image survives from the previous one (as in bench.py)
-        if (it == warmup) { ltmCheck(ctx, ltm_profile_enable(ctx, 1), "ltm_profile_enable"); ltmCheck(ctx, ltm_profile_reset(ctx), "ltm_profile_reset"); }
+        if (it == warmup && !std::getenv("LTM_BENCH_NO_PROFILE")) {
+            ltmCheck(ctx, ltm_profile_enable(ctx, 1), "ltm_profile_enable"); ltmCheck(ctx, ltm_profile_reset(ctx), "ltm_profile_reset");
+            if (lane_dev_) { ltmCheck(lane_dev_->ctx, ltm_profile_enable(lane_dev_->ctx, 1), "ltm_profile_enable"); ltmCheck(lane_dev_->ctx, ltm_profile_reset(lane_dev_->ctx), "ltm_profile_reset"); }
+        }
         ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+        if (lane_) { reset(lane_->central_sess_); reset(lane_->query_sess_); lane_->union_q_.reset(); ltmCheck(lane_dev_->ctx, ltm_clear_caches(lane_dev_->ctx), "ltm_clear_caches"); }
         const auto t0 = clk::now();
-        makeGlobalMap();
-        removeHighDynamicPoints();
-        parseStaticScansViaProjection();
-        detectLowDynamicPoints();
-        updateCurrentMap();
-        parseUpdatedStaticScansViaProjection();
-        parseLDScansViaProjection();
-        updateScansScanwise();
+        runStages(false);
         ltmCheck(ctx, ltm_synchronize(ctx), "ltm_synchronize");
+        if (lane_dev_) ltmCheck(lane_dev_->ctx, ltm_synchronize(lane_dev_->ctx), "ltm_synchronize");
         if (it >= warmup) total += std::chrono::duration<double>(clk::now() - t0).count();
     }
-    const char* names[64]; double ms[64], units[64], bytes[64]; uint64_t launches[64];
-    const int nc = ltm_profile_read(ctx, names, ms, launches, units, bytes, 64);
+    // kernel classes of the step: this context's and, on two lanes, the lane's (launch counts and units add up; the event times of launches that
+    // overlapped count each other's work -- `ltm_run --bench` with removert/gpu_lanes: 1 gives clean class times)
+    struct Cls { double ms = 0, units = 0; uint64_t launches = 0; };
+    std::vector<std::pair<std::string, Cls>> classes;
+    auto collect = [&](ltm_ctx* cx) {
+        const char* names[64]; double ms[64], units[64], bytes[64]; uint64_t launches[64];
+        const int nc = ltm_profile_read(cx, names, ms, launches, units, bytes, 64);
+        for (int i = 0; i < nc && i < 64; ++i) {
+            auto it = std::find_if(classes.begin(), classes.end(), [&](const auto& kv) { return kv.first == names[i]; });
+            if (it == classes.end()) { classes.emplace_back(names[i], Cls()); it = classes.end() - 1; }
+            it->second.ms += ms[i]; it->second.units += units[i]; it->second.launches += launches[i];
+        }
+    };
+    collect(ctx);
+    if (lane_dev_) collect(lane_dev_->ctx);
     std::ostringstream js;
     js.precision(17);
     js << "{\"host\": \"lt-mapper_amd/host (C++ mirror of Removerter/Session over the C ABI)\", \"steps\": " << steps << ", \"warmup\": " << warmup
-       << ", \"ms_per_step\": " << 1e3 * total / std::max(steps, 1) << ", \"keyframes\": [" << central_sess_.keyframe_names_.size() << ", "
+       << ", \"lanes\": " << (useLanes() ? 2 : 1) << ", \"ms_per_step\": " << 1e3 * total / std::max(steps, 1) << ", \"keyframes\": [" << central_sess_.keyframe_names_.size() << ", "
        << query_sess_.keyframe_names_.size() << "], \"classes\": {";
-    for (int i = 0; i < nc && i < 64; ++i)
-        js << (i ? ", " : "") << "\"" << names[i] << "\": {\"ms_per_step\": " << ms[i] / std::max(steps, 1) << ", \"launches_per_step\": "
-           << (double)launches[i] / std::max(steps, 1) << ", \"units_per_step\": " << units[i] / std::max(steps, 1) << "}";
+    for (size_t i = 0; i < classes.size(); ++i)
+        js << (i ? ", " : "") << "\"" << classes[i].first << "\": {\"ms_per_step\": " << classes[i].second.ms / std::max(steps, 1) << ", \"launches_per_step\": "
+           << (double)classes[i].second.launches / std::max(steps, 1) << ", \"units_per_step\": " << classes[i].second.units / std::max(steps, 1) << "}";
     js << "}}";
     std::cout << "[bench] " << js.str() << std::endl;
     return 0;
+}
+
+
+// makeGlobalMap + Steps 1-3 of the reference's run() (Removerter.cpp:1662-1675).  write_outputs: the per-keyframe outputs that are final before
+// updateScansScanwise are queued for writing as soon as they exist (asynchronous I/O only); scans_updated is written by the caller.
+void Removerter::runStages(bool write_outputs)
+{
+    if (useLanes()) runStagesTwoLanes(write_outputs);
+    else runStagesOneLane(write_outputs);
+}
+
+void Removerter::runStagesOneLane(bool write_outputs)
+{
+    makeGlobalMap();
+    // # Step 1: HD noise removal
+    removeHighDynamicPoints();
+    parseStaticScansViaProjection();
+    // # Step 2: LD change detection
+    detectLowDynamicPoints();
+    // # Step 3: LT-map
+    updateCurrentMap();
+    parseUpdatedStaticScansViaProjection();
+    parseLDScansViaProjection();
+    if (write_outputs && gpu_async_io_) {      // four of the five per-keyframe outputs are final here: their fetch + writes overlap the last stage
+        saveScans(central_sess_, central_sess_.keyframe_scans_updated_strong_, updated_strong_scans_save_dir_, false);
+        saveLDScans(central_sess_);
+    }
+    updateScansScanwise();
+}
+
+namespace {
+// main_fn on this thread, lane_fn on a second one; device-side: the lane starts behind what the main context has been given so far, and the main
+// context's next work is ordered behind everything the lane submitted (lent clouds may be freed or overwritten from then on)
+template <class A, class B>
+void forkLanes(ltm_ctx* main_ctx, ltm_ctx* lane_ctx, A&& main_fn, B&& lane_fn)
+{
+    ltmCheck(main_ctx, ltm_lane_fence(main_ctx, lane_ctx), "ltm_lane_fence");
+    std::exception_ptr lane_err;
+    std::thread th([&] { try { lane_fn(); } catch (...) { lane_err = std::current_exception(); } });
+    try { main_fn(); } catch (...) { th.join(); throw; }
+    th.join();
+    if (lane_err) std::rethrow_exception(lane_err);
+    ltmCheck(lane_ctx, ltm_lane_fence(lane_ctx, main_ctx), "ltm_lane_fence");
+}
+} // namespace
+
+void Removerter::ensureLane()
+{
+    if (lane_) return;
+    lane_dev_ = std::make_shared<Device>(Device::LaneOf{*dev_});
+    lane_.reset(new Removerter(lane_dev_));
+}
+
+void Removerter::runStagesTwoLanes(bool write_outputs)
+{
+    ensureLane();
+    Removerter& L = *lane_;
+    L.bench_mode_ = bench_mode_;
+    Device& M = *dev_; Device& LD = *lane_dev_;
+    Session& C = central_sess_; Session& Q = query_sess_;
+    Session& Cl = L.central_sess_; Session& Ql = L.query_sess_;      // the lane's views of the two sessions
+    Ql.adoptKeyframes(Q, true);
+    Cl.adoptKeyframes(C, false);
+    const bool self = gpu_use_self_removert_ && !remove_resolution_list_.empty();
+    const bool timing = std::getenv("LTM_STAGE_TIMING") != nullptr;      // wall time of the three fork / join stages, on stderr
+    auto lap = [&, last = std::chrono::steady_clock::now()](const char* what) mutable {
+        if (!timing) return;
+        ltm_synchronize(M.ctx); ltm_synchronize(LD.ctx);
+        const auto now = std::chrono::steady_clock::now();
+        std::fprintf(stderr, "[ltm_run] two lanes: %-28s %7.2f ms\n", what, std::chrono::duration<double, std::milli>(now - last).count());
+        last = now;
+    };
+    lap("views of the inputs");
+
+    // ---- stage A: makeGlobalMap, the Step-1 chain, the HD kNN map and the static reprojection of one session per lane (Removerter.cpp:213-252, :1580-1604, :1527-1538)
+    auto chainA = [self](Removerter& R, Session& s) {
+        R.makeGlobalMap(s);
+        if (self) R.selfRemovert(s, R.repeat_removert_iter_);
+        else R.removeOnce(s, s, 2.5);
+        if (!R.gpu_skip_hd_knn_) {
+            s.extractHighDynPointsViaKnnDiff(s.map_global_curr_static_);
+            const CloudPtr hd = s.octreeDownsampling(s.mergeScansToGlobal(s.keyframe_scans_dynamic_), 0.05f);
+            R.saveMap(R.save_pcd_directory_ + (s.sess_type_ == "Central" ? "central" : "query") + "_sess_high_dyn.pcd", hd);
+        }
+        R.parseStaticScansViaProjection(s);
+    };
+    forkLanes(M.ctx, LD.ctx, [&] { chainA(*this, C); }, [&] { chainA(L, Ql); });
+    lap("stage A (Step 1 chains)");
+    if (!gpu_skip_hd_knn_) LTM_INFO(" high dynamic maps are saved. ");
+    Ql.map_global_curr_.reset(); Ql.knn_target_map_.reset();
+    Q.map_global_curr_static_ = giveCloud(Ql.map_global_curr_static_, M);
+    Q.map_global_curr_dynamic_ = giveCloud(Ql.map_global_curr_dynamic_, M);
+    Q.map_global_curr_ = Q.map_global_curr_static_;
+    Q.keyframe_scans_dynamic_ = giveScans(Ql.keyframe_scans_dynamic_, M);
+
+    // ---- stage B: the two directions of the LD kNN diff, the ND against the PD filter, the grids of :1445-1476 (Removerter.cpp:1413-1481)
+    Q.keyframe_scans_static_projected_ = lendScans(Ql.keyframe_scans_static_projected_, M);      // source scans of filterStrongND
+    Cl.map_global_curr_static_ = lendCloud(C.map_global_curr_static_, LD);                         // kNN target of the query session
+    Cl.keyframe_scans_static_projected_ = lendScans(C.keyframe_scans_static_projected_, LD);      // source scans of filterStrongPD
+    forkLanes(M.ctx, LD.ctx,
+        [&] {
+            LTM_INFO(" parse low dynamic diff via knn: " << C.sess_type_ << " to " << Q.sess_type_);
+            C.extractLowDynPointsViaKnnDiff(Q.map_global_curr_static_);
+            C.constructGlobalNDMap();
+            filterStrongND(C, Q);
+            C.removeWeakNDMapPointsHavingStrongNDInNear();
+            const bool has_strong_nd = C.map_global_nd_strong_->size() != 0;
+            std::vector<CloudPtr> ins = {C.mergeScansToGlobal(C.scans_knn_coexist_), C.mergeScansToGlobal(C.scans_knn_diff_), C.map_global_nd_weak_};
+            if (has_strong_nd) ins.push_back(C.map_global_nd_strong_);
+            const auto ds = C.octreeDownsamplingBatch(ins, 0.05f);
+            union_c_ = ds[0];
+            saveMap(save_pcd_directory_ + "union_map_centralside.pcd", union_c_);
+            saveMap(save_pcd_directory_ + "nd_map.pcd", ds[1]);
+            if (has_strong_nd) { C.map_global_nd_strong_ = ds[3]; saveMap(save_pcd_directory_ + "strong_nd_map.pcd", C.map_global_nd_strong_); }
+            C.map_global_nd_weak_ = ds[2];
+            saveMap(save_pcd_directory_ + "weak_nd_map.pcd", C.map_global_nd_weak_);
+        },
+        [&] {
+            Ql.extractLowDynPointsViaKnnDiff(Cl.map_global_curr_static_);
+            Ql.constructGlobalPDMap();
+            L.filterStrongPD(Ql, Cl);
+            Ql.revertStrongPDMapPointsHavingWeakPDInNear();
+            const auto ds = Ql.octreeDownsamplingBatch({Ql.mergeScansToGlobal(Ql.scans_knn_coexist_), Ql.mergeScansToGlobal(Ql.scans_knn_diff_),
+                                                        Ql.map_global_pd_strong_, Ql.map_global_pd_weak_}, 0.05f);
+            L.union_q_ = ds[0];
+            L.saveMap(L.save_pcd_directory_ + "union_map_queryside.pcd", L.union_q_);
+            L.saveMap(L.save_pcd_directory_ + "pd_map.pcd", ds[1]);
+            Ql.map_global_pd_strong_ = ds[2];
+            L.saveMap(L.save_pcd_directory_ + "strong_pd_map.pcd", Ql.map_global_pd_strong_);
+            Ql.map_global_pd_weak_ = ds[3];
+            L.saveMap(L.save_pcd_directory_ + "weak_pd_map.pcd", Ql.map_global_pd_weak_);
+        });
+    lap("stage B (low dynamic)");
+    LTM_INFO(" Union, PD, and ND map saved ");
+    LTM_INFO(" Strong/Weak ND map saved ");
+    LTM_INFO(" Strong/Weak PD map saved ");
+    // the views go, the query side's results come over
+    Q.keyframe_scans_static_projected_.reset(); Q.knn_target_map_.reset(); C.knn_target_map_.reset();
+    Cl.map_global_curr_static_.reset(); Cl.keyframe_scans_static_projected_.reset(); Ql.knn_target_map_.reset();
+    Q.keyframe_scans_static_projected_ = giveScans(Ql.keyframe_scans_static_projected_, M);
+    Q.scans_knn_coexist_ = giveScans(Ql.scans_knn_coexist_, M);
+    Q.scans_knn_diff_ = giveScans(Ql.scans_knn_diff_, M);
+    const bool pd_is_orig = Ql.map_global_pd_ == Ql.map_global_pd_orig_;
+    Q.map_global_pd_orig_ = giveCloud(Ql.map_global_pd_orig_, M);
+    if (pd_is_orig) { Ql.map_global_pd_.reset(); Q.map_global_pd_ = Q.map_global_pd_orig_; }
+    else Q.map_global_pd_ = giveCloud(Ql.map_global_pd_, M);
+    Q.map_global_pd_strong_ = giveCloud(Ql.map_global_pd_strong_, M);
+    Q.map_global_pd_weak_ = giveCloud(Ql.map_global_pd_weak_, M);
+    union_q_ = giveCloud(L.union_q_, M);
+    C.map_global_pd_ = Q.map_global_pd_;                 // Removerter.cpp:1435-1437
+    C.map_global_pd_orig_ = Q.map_global_pd_orig_;
+    C.map_global_pd_strong_ = Q.map_global_pd_strong_;
+
+    // ---- stage C: updateCurrentMap, then the reprojections of the updated / PD / weak-ND maps and updateScansScanwise (main) beside those of the
+    // "strong" maps (lane) (Removerter.cpp:1483-1577)
+    updateCurrentMap();
+    lap("hand-over + updateCurrentMap");
+    if (!C.map_global_nd_strong_) { ltm_cloud h = 0; PointType none{}; ltmCheck(M.ctx, ltm_cloud_upload(M.ctx, &none, 0, 16, &h), "ltm_cloud_upload"); C.map_global_nd_strong_ = C.wrap(h); }
+    Cl.map_global_pd_strong_ = lendCloud(C.map_global_pd_strong_, LD);
+    Cl.map_global_nd_strong_ = lendCloud(C.map_global_nd_strong_, LD);
+    Cl.map_global_updated_strong_ = lendCloud(C.map_global_updated_strong_, LD);
+    const bool early = write_outputs && gpu_async_io_;
+    forkLanes(M.ctx, LD.ctx,
+        [&] {
+            C.parseUpdatedStaticScansViaProjection();
+            C.parsePDScansViaProjection();
+            if (early) savePDScans(C);
+            C.parseWeakNDScansViaProjection();
+            updateScansScanwise();
+        },
+        [&] {
+            Cl.parseStrongPDScansViaProjection();
+            if (early) L.saveStrongPDScans(Cl);
+            Cl.parseStrongNDScansViaProjection();
+            if (early) L.saveStrongNDScans(Cl);
+            Cl.parseUpdatedStrongStaticScansViaProjection();
+            if (early) L.saveScans(Cl, Cl.keyframe_scans_updated_strong_, L.updated_strong_scans_save_dir_, false);
+        });
+    lap("stage C (Step 3)");
+    LTM_INFO(" parse updated scans via projection: " << C.sess_type_);
+    LTM_INFO(" parse LD scans via projection: " << C.sess_type_);
+    Cl.map_global_pd_strong_.reset(); Cl.map_global_nd_strong_.reset(); Cl.map_global_updated_strong_.reset();
+    C.keyframe_scans_strong_pd_ = giveScans(Cl.keyframe_scans_strong_pd_, M);
+    C.keyframe_scans_strong_nd_ = giveScans(Cl.keyframe_scans_strong_nd_, M);
+    C.keyframe_scans_updated_strong_ = giveScans(Cl.keyframe_scans_updated_strong_, M);
+    Ql.keyframe_scans_.reset();      // the view of the query session's scans
+    if (write_outputs && !gpu_async_io_) { /* the synchronous path writes everything after the stages (run()) */ }
 }
 
 void Removerter::run(void)                                                         // Removerter.cpp:1653-1678
@@ -853,22 +1055,8 @@ void Removerter::run(void)                                                      
     central_sess_.loadKeyframes(); lap("loadKeyframes central");
     query_sess_.loadKeyframes(); lap("loadKeyframes query");
     precleaningKeyframes(2.5); lap("precleaningKeyframes");
-    makeGlobalMap(); lap("makeGlobalMap");
-    const auto t1 = clk::now();
-    // # Step 1: HD noise removal
-    removeHighDynamicPoints();
-    parseStaticScansViaProjection();
-    // # Step 2: LD change detection
-    detectLowDynamicPoints();
-    // # Step 3: LT-map
-    updateCurrentMap();
-    parseUpdatedStaticScansViaProjection();
-    parseLDScansViaProjection();
-    if (gpu_async_io_) {      // four of the five per-keyframe outputs are final here: their fetch + writes overlap the last stage
-        saveScans(central_sess_, central_sess_.keyframe_scans_updated_strong_, updated_strong_scans_save_dir_, false);
-        saveLDScans(central_sess_);
-    }
-    updateScansScanwise();
+    const auto t1 = clk::now();      // (makeGlobalMap belongs to the stages: on two lanes each session's merge + grid opens its own chain)
+    runStages(true);
     ltmCheck(dev_->ctx, ltm_synchronize(dev_->ctx), "ltm_synchronize");
     const auto t2 = clk::now();
     if (gpu_async_io_) saveScans(central_sess_, central_sess_.keyframe_scans_updated_, updated_scans_save_dir_, true);
@@ -879,7 +1067,7 @@ void Removerter::run(void)                                                      
     if (dev_->comm) dev_->comm->barrier();
     const auto t3 = clk::now();
     auto s = [](auto a, auto b) { return std::chrono::duration<double>(b - a).count(); };
-    LTM_INFO(" [timing] step0 (load+map) " << s(t0, t1) << " s, steps 1-3 " << s(t1, t2) << " s (includes map PCD writes), scan writes " << s(t2, t3) << " s");
+    LTM_INFO(" [timing] step0 (load) " << s(t0, t1) << " s, makeGlobalMap + steps 1-3 " << s(t1, t2) << " s (includes map PCD writes), scan writes " << s(t2, t3) << " s");
     // files -> files wall time (SURVEY 8d "T_total"), machine readable
     if (dev_->rank() == 0)
     std::cout << "[timing] ranks " << dev_->world() << " (" << (dev_->comm ? dev_->comm->backend() : "single") << ") T_total " << s(t0, t3) << " s T_step0 " << s(t0, t1) << " s T_steps123 " << s(t1, t2) << " s T_scan_writes " << s(t2, t3)

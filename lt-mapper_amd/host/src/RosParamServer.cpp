@@ -1,4 +1,5 @@
 #include "removert/RosParamServer.h"
+#include <cstdlib>
 
 #include <algorithm>
 #include <fstream>
@@ -137,6 +138,8 @@ RosParamServer::RosParamServer()
     gpu_use_self_removert_ = getb("gpu_use_self_removert", false);
     gpu_skip_hd_knn_ = getb("gpu_skip_hd_knn", false);
     gpu_device_ = geti("gpu_device", 0);
+    gpu_lanes_ = geti("gpu_lanes", 2);
+    if (const char* v = std::getenv("LTM_LANES")) gpu_lanes_ = std::atoi(v);
     gpu_async_io_ = getb("gpu_async_io", true);
     gpu_fetch_chunked_ = getb("gpu_fetch_chunked", true);
     gpu_viz_every_ = geti("gpu_viz_every", 0);

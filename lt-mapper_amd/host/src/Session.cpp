@@ -30,7 +30,52 @@ Device::Device(const RosParamServer& p, int device_ordinal, std::shared_ptr<Comm
     const int rc = ltm_create(&cfg, &ctx);
     if (rc != LTM_OK) throw std::runtime_error("ltm_create failed (" + std::to_string(rc) + "): no usable MI355X device; there is no CPU fallback");
 }
+Device::Device(LaneOf l)
+{
+    const int rc = ltm_lane_create(l.parent.ctx, &ctx);
+    if (rc != LTM_OK) throw std::runtime_error("ltm_lane_create failed (" + std::to_string(rc) + ")");
+}
 Device::~Device() { ltm_destroy(ctx); }
+
+CloudPtr lendCloud(const CloudPtr& c, Device& to)
+{
+    if (!c) return nullptr;
+    ltm_cloud h = 0;
+    ltmCheck(c->ctx, ltm_cloud_lend(c->ctx, c->h, to.ctx, &h), "ltm_cloud_lend");
+    auto v = std::make_shared<CloudH>(to.ctx, h);
+    v->lender = c;
+    return v;
+}
+CloudPtr giveCloud(CloudPtr& c, Device& to)
+{
+    if (!c) return nullptr;
+    ltm_cloud h = 0;
+    ltmCheck(c->ctx, ltm_cloud_give(c->ctx, c->h, to.ctx, &h), "ltm_cloud_give");
+    c->h = 0;                 // every other holder of this pointer sees an empty handle from now on
+    c.reset();
+    return std::make_shared<CloudH>(to.ctx, h);
+}
+ScansPtr lendScans(const ScansPtr& s, Device& to)
+{
+    if (!s) return nullptr;
+    ltm_scanset h = 0;
+    ltmCheck(s->ctx, ltm_scanset_lend(s->ctx, s->h, to.ctx, &h), "ltm_scanset_lend");
+    auto v = std::make_shared<ScansH>(to.ctx, h);
+    v->shard = s->shard; v->kb = s->kb; v->n_total = s->n_total;
+    v->lender = s;
+    return v;
+}
+ScansPtr giveScans(ScansPtr& s, Device& to)
+{
+    if (!s) return nullptr;
+    ltm_scanset h = 0;
+    ltmCheck(s->ctx, ltm_scanset_give(s->ctx, s->h, to.ctx, &h), "ltm_scanset_give");
+    auto v = std::make_shared<ScansH>(to.ctx, h);
+    v->shard = s->shard; v->kb = s->kb; v->n_total = s->n_total;
+    s->h = 0;
+    s.reset();
+    return v;
+}
 
 CloudH::~CloudH() { if (ctx && h) ltm_cloud_free(ctx, h); }
 size_t CloudH::size() const { size_t n = 0; ltmCheck(ctx, ltm_cloud_size(ctx, h, &n), "ltm_cloud_size"); return n; }
@@ -217,6 +262,14 @@ void Session::uploadPoses()
 }
 
 // this rank's block of keyframes (Comm.h shardRange) among the ranks of comm(): every per-keyframe loop of the reference runs over it
+void Session::adoptKeyframes(const Session& from, bool with_scans)
+{
+    sess_type_ = from.sess_type_; kDownsampleVoxelSize = from.kDownsampleVoxelSize; keyframe_gap_ = from.keyframe_gap_;
+    keyframe_names_ = from.keyframe_names_; keyframe_paths_ = from.keyframe_paths_;
+    keyframe_poses_ = from.keyframe_poses_; keyframe_inverse_poses_ = from.keyframe_inverse_poses_;
+    uploadPoses();
+    keyframe_scans_ = with_scans ? lendScans(from.keyframe_scans_, *dev_) : nullptr;
+}
 void Session::setKeyframeBlock()
 {
     if (poses_local_h_) { ltm_poses_free(dev_->ctx, poses_local_h_); poses_local_h_ = 0; }

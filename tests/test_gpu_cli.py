@@ -201,7 +201,9 @@ def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
     n_kf = 44      # the two sessions start 37 m apart on the same loop: the query's first keyframes fall into the central ROI from ~40 central keyframes on
     sess = [synth.to_numpy(synth.make_session(s, n_kf, "small")) for s in (1, 2)]
     dirs = fp.write_session_dirs(tmp_path, sess)
-    cxx = t_total.bench_cxx_host(str(tmp_path), dirs, n_kf, three_res=True, steps=1, warmup=1)
+    cxx = t_total.bench_cxx_host(str(tmp_path), dirs, n_kf, three_res=True, steps=1, warmup=1, lanes=1)
+    cxx2 = t_total.bench_cxx_host(str(tmp_path), dirs, n_kf, three_res=True, steps=1, warmup=1, lanes=2)      # the same stages on two lanes
+    assert cxx["lanes"] == 1 and cxx2["lanes"] == 2
     # the Python host on what the C++ loader makes of those files: keyframes 0..n_kf-1 of the central session (even start: no Q6 skip), the query
     # keyframes inside the 10 m ROI; per-scan VoxelGrid + pre-clean on the device
     c_kf = fp.parse_keyframes(n_kf, 0, n_kf - 1)
@@ -236,6 +238,15 @@ def test_cxx_host_and_python_host_drive_the_same_pipeline(tmp_path):
             diff.append((nme, (la, ua), (lb, ub)))
     assert not diff, f"the two hosts do not issue the same work: (class, C++ host, Python host) = {diff}"
     assert len(names) >= 12
+    # two lanes: the same work units per class (calls are cut differently -- one grid per lane where one lane batches two -- so launches may differ)
+    diff2 = []
+    for nme in names:
+        if nme == "knn_query_p2":
+            continue
+        a, b = cxx["classes"].get(nme), cxx2["classes"].get(nme)
+        if (a["units_per_step"] if a else 0) != (b["units_per_step"] if b else 0):
+            diff2.append((nme, a, b))
+    assert not diff2, f"the two-lane schedule does not do the one-lane schedule's work: {diff2}"
 
 
 def test_binary_compressed_scan_directories_give_the_same_output_tree(tmp_path):

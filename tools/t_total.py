@@ -64,7 +64,7 @@ def measure(sess, kf, three_res=False, ranks=1, runs=3, root=None, extra_yaml=""
     return res, dirs
 
 
-def bench_cxx_host(root, dirs, kf, three_res=True, steps=3, warmup=1):
+def bench_cxx_host(root, dirs, kf, three_res=True, steps=3, warmup=1, lanes=None):
     """`ltm_run <yaml> --bench steps`: makeGlobalMap + Steps 1-3 timed by the C++ host itself, the loaded sessions resident on the device, no
     output files -- the same timed region as bench.py's, driven by the north-star host.  Returns its JSON line as a dict."""
     import fileproto as fp
@@ -73,7 +73,7 @@ def bench_cxx_host(root, dirs, kf, three_res=True, steps=3, warmup=1):
     yaml = os.path.join(root, "params_bench.yaml")
     with open(yaml, "w") as f:
         f.write(fp.yaml_text(root, dirs, outdir, 0, kf - 1, res_list=(2.5, 2.0, 1.5) if three_res else (2.5,),
-                             extra="  gpu_use_self_removert: true\n" if three_res else ""))
+                             extra=("  gpu_use_self_removert: true\n" if three_res else "") + (f"  gpu_lanes: {int(lanes)}\n" if lanes else "")))
     p = subprocess.run([exe, yaml, "--bench", str(steps), "--warmup", str(warmup)], capture_output=True, text=True)
     shutil.rmtree(outdir, ignore_errors=True)
     if p.returncode != 0:
