@@ -333,6 +333,11 @@ int ltm_debug_voxel_key_bits(const float* mn3, const float* mx3, float leaf, uin
  * arithmetic: counts points (host xyz, n*3 floats; global frame if inv_pose16 is given, else local) whose exact pixel /
  * range fall outside its candidate set / bounds.  Must be 0. */
 int ltm_debug_cull_check(ltm_ctx*, const float* xyz, size_t n, const double* inv_pose16_or_null, float res_alpha, uint64_t* violations);
+/* The culled projection kernels (k_vote_map_cull, the pre-filter of k_map_rimg_blockmin: map2RangeImg, utility.cpp:92-142, evaluated exactly only where it can
+ * matter) rest on error bounds of a bounded-error projection.  Every range-image shape is validated on the device the first time a context uses it -- 2^20
+ * probe points on and beside the pixel-rounding boundaries, in the sensor frame and through one keyframe pose of the call -- and a shape that leaves the
+ * bounds is served by the exact kernels from then on (a line on stderr says so).  Counters since ltm_create: shapes checked / shapes that failed. */
+int ltm_debug_cull_validation(ltm_ctx*, uint64_t* shapes_checked, uint64_t* shapes_failed);
 /* diagnostic counters of the occlusion cull in front of the exact-image kernel on large maps (reprojection, ND votes) since the
  * last reset: (tile, keyframe) pairs seen by culled launches, pairs of the first distance shell, pairs projected in all (the rest was
  * proven hidden and dropped) */

@@ -119,6 +119,7 @@ SIGNATURES = {
     "ltm_debug_selfcheck": (_i, [_vp, _pu64, C.POINTER(_i)]),
     "ltm_debug_cull_check": (_i, [_vp, _vp, _sz, _vp, _f, _pu64]),
     "ltm_debug_cull_stats": (_i, [_vp, _pu64, _pu64, _i]),
+    "ltm_debug_cull_validation": (_i, [_vp, _pu64, _pu64]),
     "ltm_debug_occlusion_stats": (_i, [_vp, _pu64, _pu64, _pu64, _i]),
     "ltm_debug_voxel_stats": (_i, [_vp, _pu64, _pu64, _i]),
     "ltm_rimg_size": (None, [_f, _f, _f, C.POINTER(_i), C.POINTER(_i)]),
@@ -496,6 +497,12 @@ class Context:
     def voxel_stats(self, reset=False):
         a, b = _u64(), _u64()
         self._ck(self.lib.ltm_debug_voxel_stats(self.h, C.byref(a), C.byref(b), 1 if reset else 0))
+        return int(a.value), int(b.value)
+
+    def cull_validation(self):
+        """(image shapes whose bounded-error projection was validated on first use, shapes that failed and fell back to the exact kernels)"""
+        a, b = _u64(), _u64()
+        self._ck(self.lib.ltm_debug_cull_validation(self.h, C.byref(a), C.byref(b)))
         return int(a.value), int(b.value)
 
     def cull_stats(self, reset=True):

@@ -304,6 +304,13 @@ struct ltm_ctx {
     int knn_sort_queue = 1;                     // LTM_KNN_SORT_QUEUE=0: phase 2 walks the undecided queries in scan order instead of sorted by cell (A/B switch)
     int knn_stats_on = 0;                       // LTM_KNN_STATS=1: count the queries phase 1 leaves undecided (one host round trip per call)
     uint64_t knn_undecided = 0, knn_queries = 0;
+    // The culled kernels rest on error bounds of the bounded-error projection that were validated empirically (tools/eps_sweep.py, ltm_debug_cull_check in the
+    // tests) for the fields of view and extrinsics that were fuzzed.  Every image shape is therefore checked ON THE DEVICE the first time a context uses
+    // it (cull_geometry_ok: 2^20 probe points on and beside the pixel boundaries, local frame and through one real keyframe pose); a shape that fails falls
+    // back to the exact kernels for good.  LTM_CULL_SELFCHECK=0 skips it (A/B).
+    std::map<std::pair<int, int>, bool> cull_geom_ok;
+    uint64_t cull_geoms_checked = 0, cull_geoms_failed = 0;
+    int cull_selfcheck = 1;
     float cull_eps_scale = 0.0f;                // LTM_CULL_EPS_SCALE: pixels of distrust per (pixel per degree); 0 = the validated default of geom_for
     float cull_eps_floor = 1.0e-3f;             // LTM_CULL_EPS_FLOOR: the band is never narrower than this [pixels]
     int el_fit = 0;                             // fitted elevation polynomial usable (vfov/2 + 2 deg <= 45 deg and error <= 1e-6 rad)
@@ -812,6 +819,36 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
     return buf;
 }
 
+// first use of an image shape by this context: is the bounded-error projection inside its bounds for it?  (see ltm_ctx::cull_geom_ok)
+bool cull_geometry_ok(ltm_ctx* c, const Geom& g, const Poses& ps, size_t kf)
+{
+    if (!c->cull_selfcheck) return true;
+    const std::pair<int, int> key(g.rows, g.cols);
+    auto it = c->cull_geom_ok.find(key);
+    if (it != c->cull_geom_ok.end()) return it->second;
+    const size_t n = (size_t)1 << 20;
+    DevBuf pts(c, n * 12), bad(c, 8);
+    LTM_HIP(hipMemsetAsync(bad.p, 0, 8, c->stream));
+    LTM_HIP(cull_probe_points(g, n, nullptr, pts.as<float>(), c->stream));
+    LTM_HIP(cull_check(pts.as<float>(), n, nullptr, &c->B2L, c->b2l_identity, nullptr, g, bad.as<unsigned long long>(), c->stream));
+    if (ps.approx_dev && kf < ps.n) {      // the same directions seen through a real keyframe pose: exact transform vs A (p - c)
+        const HostMat34 pose = to34(&ps.pose[16 * kf]), inv = to34(&ps.inv[16 * kf]);
+        LTM_HIP(cull_probe_points(g, n, &pose, pts.as<float>(), c->stream));
+        LTM_HIP(cull_check(pts.as<float>(), n, &inv, &c->B2L, c->b2l_identity, ps.approx_dev + 16 * kf, g, bad.as<unsigned long long>(), c->stream));
+    }
+    unsigned long long v = 0;
+    d2h(c, &v, bad.p, 8);
+    const bool ok = v == 0;
+    ++c->cull_geoms_checked;
+    if (!ok) {
+        ++c->cull_geoms_failed;
+        fprintf(stderr, "[ltm] the bounded-error projection left its validated bounds for the %d x %d range image (%llu of %zu probe points): exact kernels for this shape\n",
+                g.rows, g.cols, v, 2 * n);
+    }
+    c->cull_geom_ok[key] = ok;
+    return ok;
+}
+
 // Exact arg-min images of keyframes [kb, kb + nb) (reprojection, ND votes, RViz images): on a large map behind an occlusion cull
 // (ltm_kernels.hip: near pairs first, a coarse maximum of the partial image, far pairs that nearer returns cover completely are dropped).
 // The image is bit-identical to the plain launch; below `occlusion_min_pairs` (tile, keyframe) pairs the plain launch is used.
@@ -819,11 +856,13 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
 {
     if (!map.n || !nb) return;
     const size_t n_tiles = (map.n + 4095) / 4096, n_pairs = n_tiles * nb;
+    KernelOpts ko = c->kopts;
+    if (ko.map_kernel_variant >= 2 && ps.approx_dev && !cull_geometry_ok(c, g, ps, kb)) ko.map_kernel_variant = 1;      // the pre-filter uses the bounded-error projection
     // (the list-driven launch exists for the block-local arg-min kernel only: LTM_MAP_KERNEL=0/1, the A/B baselines, take the plain launch)
-    const bool occl = c->occlusion_cull && c->kopts.map_kernel_variant >= 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
+    const bool occl = c->occlusion_cull && ko.map_kernel_variant >= 2 && ps.approx_dev && n_pairs >= c->occlusion_min_pairs && n_pairs < 0xffffffffull;
     if (!occl) {
         HeavyScope hs(c, n_pairs);
-        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, hs.stream(), c->kopts));
+        LTM_HIP(map_range_images(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, hs.stream(), ko));
         hs.done();
         return;
     }
@@ -865,7 +904,7 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
         d2h(c, &n_live, count, 4);
         {
             HeavyScope hs(c, n_live);
-            LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, hs.stream(), c->kopts));
+            LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, hs.stream(), ko));
             hs.done();
         }
         n_proj += n_live;
@@ -897,7 +936,7 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
         const size_t nb = std::min(KB, kf_end - kb);
         const uint32_t* smax = nullptr;
         const float* qbound = nullptr;
-        const bool cull = mode == 0 && (c->kopts.vote_cull != 0) && ps.approx_dev;
+        const bool cull = mode == 0 && (c->kopts.vote_cull != 0) && ps.approx_dev && cull_geometry_ok(c, g, ps, kb);
         const uint32_t* scan_img = scan_images(c, ss_handle, ss, kb, nb, g, &smax, cull ? thr : -1.0f, &qbound);
         {
             ProfScope p(c, "vote_fill", (double)(nb * npx), (double)(nb * npx * 8));
@@ -1540,6 +1579,7 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         }
         if (const char* v = getenv("LTM_KNN_STATS")) c->knn_stats_on = atoi(v);
         if (const char* v = getenv("LTM_KNN_SORT_QUEUE")) c->knn_sort_queue = atoi(v);
+        if (const char* v = getenv("LTM_CULL_SELFCHECK")) c->cull_selfcheck = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
         c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
@@ -2735,6 +2775,7 @@ int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
         c->voxel_key_compress = parent->voxel_key_compress; c->voxel_fused_tail = parent->voxel_fused_tail; c->voxel_identity = parent->voxel_identity;
         c->knn_two_phase = parent->knn_two_phase; c->knn_sort_queue = parent->knn_sort_queue; c->knn_stats_on = parent->knn_stats_on;
         c->cull_eps_scale = parent->cull_eps_scale; c->cull_eps_floor = parent->cull_eps_floor;
+        c->cull_selfcheck = parent->cull_selfcheck; c->cull_geom_ok = parent->cull_geom_ok;      // shapes the parent has checked already (same device, field of view, extrinsic)
         c->el_fit = parent->el_fit; for (int i = 0; i < 4; ++i) c->el_c[i] = parent->el_c[i]; c->el_fit_err = parent->el_fit_err;
     }
     int prio_least = 0, prio_greatest = 0;
@@ -3109,6 +3150,11 @@ int ltm_debug_cull_check(ltm_ctx* c, const float* xyz, size_t n, const double* i
         d2h(c, &v, bad.p, 8);
         *violations = v;
     });
+}
+
+int ltm_debug_cull_validation(ltm_ctx* c, uint64_t* shapes_checked, uint64_t* shapes_failed)
+{
+    return guarded(c, [&] { if (shapes_checked) *shapes_checked = c->cull_geoms_checked; if (shapes_failed) *shapes_failed = c->cull_geoms_failed; });
 }
 
 int ltm_debug_cull_stats(ltm_ctx* c, uint64_t* survivors, uint64_t* points, int reset)

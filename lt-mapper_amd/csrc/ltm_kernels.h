@@ -75,6 +75,8 @@ hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb,
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s, int which_kernel);   // {survivors, points} since the last reset; 0 vote kernel, 1 exact-image kernel
 hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const HostMat34* b2l, int b2l_identity, const float* approx_pose_dev,
                       Geom g, unsigned long long* bad_dev, hipStream_t s);
+// n probe points on / beside the pixel-rounding boundaries of the image shape `g` (local frame, or moved into the map frame by `pose`): input of cull_check
+hipError_t cull_probe_points(Geom g, size_t n, const HostMat34* pose, float* xyz_dev, hipStream_t s);
 // generic single image with up to two explicit transforms (debug / parity)
 hipError_t single_range_image(const float4* pts, size_t n, const HostMat34* T1, const HostMat34* T2, Geom g,
                               uint64_t* img, hipStream_t s);

@@ -764,6 +764,43 @@ hipError_t cull_check(const float* xyz_dev, size_t n, const HostMat34* T, const 
     return hipGetLastError();
 }
 
+// Probe points for the create-on-first-use validation of the bounded-error projection (ltm_api.cpp: cull_geometry_ok): local-frame points that sit
+// ON and a hair beside the pixel-rounding boundaries of this image shape -- rows, columns and their crossings -- at ranges from 0.3 m to 200 m, plus
+// points in general position; optionally moved into the map frame by `pose` (3x4) so that the approximate inverse transform is exercised too.
+__global__ void __launch_bounds__(kBlock)
+k_cull_probe_points(Geom g, size_t n, HostMat34 pose, int with_pose, float* __restrict__ xyz)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint32_t h = (uint32_t)i * 0x9e3779b1u + 0x7f4a7c15u;
+    auto next = [&]() { h ^= h >> 16; h *= 0x85ebca6bu; h ^= h >> 13; h *= 0xc2b2ae35u; h ^= h >> 16; return h; };
+    const double jit[8] = {0.0, 1.0e-5, -1.0e-5, 1.0e-4, -1.0e-4, 4.0e-4, -4.0e-4, 2.0e-3};      // pixels off the boundary
+    const double ranges[8] = {0.3, 1.0, 3.0, 10.0, 30.0, 60.0, 119.0, 200.0};
+    const uint32_t kind = next() & 3u;                     // 0: row boundary, 1: column boundary, 2: both, 3: general position
+    double rowf = (double)(next() % (uint32_t)(g.rows * 16 + 1)) / 16.0 - 0.5;
+    double colf = (double)(next() % (uint32_t)(g.cols * 16 + 1)) / 16.0 - 0.5;
+    if (kind == 0 || kind == 2) rowf = (double)(next() % (uint32_t)(g.rows + 1)) - 0.5 + jit[next() & 7u];
+    if (kind == 1 || kind == 2) colf = (double)(next() % (uint32_t)(g.cols + 1)) - 0.5 + jit[next() & 7u];
+    // rowf = R (1 - (el + V/2) / V), colf = C (az + H/2) / H  (utility.cpp:122-123)
+    const double el = ((double)g.vfov * 0.5 - (double)g.vfov * rowf / (double)g.rows) * (3.14159265358979323846 / 180.0);
+    const double az = ((double)g.hfov * colf / (double)g.cols - (double)g.hfov * 0.5) * (3.14159265358979323846 / 180.0);
+    const double r = ranges[next() & 7u] * (1.0 + 1.0e-3 * (double)(next() & 1023u));
+    double x = r * cos(el) * cos(az), y = r * cos(el) * sin(az), z = r * sin(el);
+    if (with_pose) {
+        const double X = pose.m[0] * x + pose.m[1] * y + pose.m[2] * z + pose.m[3], Y = pose.m[4] * x + pose.m[5] * y + pose.m[6] * z + pose.m[7],
+                     Z = pose.m[8] * x + pose.m[9] * y + pose.m[10] * z + pose.m[11];
+        x = X; y = Y; z = Z;
+    }
+    xyz[3 * i] = (float)x; xyz[3 * i + 1] = (float)y; xyz[3 * i + 2] = (float)z;
+}
+hipError_t cull_probe_points(Geom g, size_t n, const HostMat34* pose, float* xyz_dev, hipStream_t s)
+{
+    if (!n) return hipSuccess;
+    HostMat34 z{};
+    k_cull_probe_points<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(g, n, pose ? *pose : z, pose ? 1 : 0, xyz_dev);
+    return hipGetLastError();
+}
+
 // ---------------------------------------------------------------------------------------------------------------
 // Exact arg-min range image with a workgroup-local pre-filter (reprojection, ND votes, and any caller that needs the
 // true image).  Only a point that could be the nearest of its pixel AMONG THE 4096 POINTS OF ITS OWN TILE can be the
