@@ -10,11 +10,14 @@ HIPFLAGS = --offload-arch=$(ARCH) -O3 -std=c++17 -ffp-contract=off -fno-slp-vect
 all: hip oracle host
 
 hip: $(PKG)/libltm_hip.so
-$(PKG)/csrc/ltm_kernels.o: $(PKG)/csrc/ltm_kernels.hip $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_device_math.h
+# kernels by stage (projection + vote, streaming helpers, voxel grid, kNN), one translation unit each, then the C ABI
+KOBJ = $(PKG)/csrc/ltm_k_projection.o $(PKG)/csrc/ltm_k_stream.o $(PKG)/csrc/ltm_k_voxel.o $(PKG)/csrc/ltm_k_knn.o
+$(PKG)/csrc/ltm_k_%.o: $(PKG)/csrc/ltm_k_%.hip $(PKG)/csrc/ltm_kernels_common.h $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_device_math.h
 	$(HIPCC) $(HIPFLAGS) -c $< -o $@
-$(PKG)/csrc/ltm_api.o: $(PKG)/csrc/ltm_api.cpp $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_pclsort.h include/ltm.h
+AOBJ = $(PKG)/csrc/ltm_api_core.o $(PKG)/csrc/ltm_api_vote.o $(PKG)/csrc/ltm_api_voxel.o $(PKG)/csrc/ltm_api_knn.o
+$(PKG)/csrc/ltm_api_%.o: $(PKG)/csrc/ltm_api_%.cpp $(PKG)/csrc/ltm_internal.h $(PKG)/csrc/ltm_kernels.h $(PKG)/csrc/ltm_pclsort.h include/ltm.h
 	$(HIPCC) $(HIPFLAGS) -x hip -c $< -o $@
-$(PKG)/libltm_hip.so: $(PKG)/csrc/ltm_kernels.o $(PKG)/csrc/ltm_api.o
+$(PKG)/libltm_hip.so: $(KOBJ) $(AOBJ)
 	$(HIPCC) --offload-arch=$(ARCH) -shared -fPIC -o $@ $^
 
 oracle:

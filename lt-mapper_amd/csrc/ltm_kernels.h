@@ -15,7 +15,7 @@ struct Geom {            // range-image geometry (utility.cpp:222-236 resetRimgS
                          // does not trust its pixel (proportional to the image resolution: the angular error is fixed, see geom_for)
     // Elevation of the bounded-error projection when the field of view clamps everything steeper than vfov/2 + 2 deg < 45 deg:
     // atan(t) ~ t * (el_c[0] + u (el_c[1] + u (el_c[2] + u el_c[3]))), u = t^2, fitted on [0, tan(vfov/2 + 2 deg)] when the context is
-    // created (fit_elevation_poly in ltm_api.cpp) and evaluated at min(t, el_tclamp); el_tclamp = tan(vfov/2 + one pixel) puts
+    // created (fit_elevation_poly in ltm_api_core.cpp) and evaluated at min(t, el_tclamp); el_tclamp = tan(vfov/2 + one pixel) puts
     // every clamped elevation in the MIDDLE of the out-of-image row -1 / R, where its pixel (row 0 / R-1 after the clamp) is certain.
     int el_fit;          // 0: the fit is not good enough for this field of view, the kernels use the generic polynomial on [0, 1]
     float el_c[4];

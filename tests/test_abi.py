@@ -60,7 +60,7 @@ def test_product_binaries_link_neither_the_oracle_nor_the_reference_build():
 
 def test_elevation_polynomial_fit_of_the_bounded_error_projection(ltm):
     """The degree-3 elevation polynomial the vote / exact-image kernels use is fitted on the host when a context is created
-    (ltm_api.cpp fit_elevation_poly, Lawson minimax).  Host arithmetic only, so it is checked here without a device: the
+    (ltm_api_core.cpp fit_elevation_poly, Lawson minimax).  Host arithmetic only, so it is checked here without a device: the
     reported error is what an independent binary32 evaluation of the returned coefficients gives, it is small enough where
     the fit is declared usable, and the decision flips where the distrust band's error budget (geom_for) says it must."""
     import numpy as np

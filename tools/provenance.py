@@ -5,6 +5,9 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "lt-mapper_amd", "csrc")
+# round 6: the two monolithic sources were split by stage
+KERNEL_SOURCES = ("ltm_kernels_common.h", "ltm_k_projection.hip", "ltm_k_stream.hip", "ltm_k_voxel.hip", "ltm_k_knn.hip", "ltm_device_math.h", "ltm_kernels.h")
+API_SOURCES = ("ltm_internal.h", "ltm_api_core.cpp", "ltm_api_vote.cpp", "ltm_api_voxel.cpp", "ltm_api_knn.cpp", "ltm_pclsort.h")
 
 
 def _sha(files):
@@ -16,12 +19,12 @@ def _sha(files):
 
 def kernels_sha():
     """the device code: what the PMC / rocprof figures of a kernel depend on"""
-    return _sha(("ltm_kernels.hip", "ltm_device_math.h", "ltm_kernels.h"))
+    return _sha(KERNEL_SOURCES)
 
 
 def product_sha():
     """device code + the C ABI orchestration: what the RESULTS of the library depend on"""
-    return _sha(("ltm_kernels.hip", "ltm_device_math.h", "ltm_kernels.h", "ltm_api.cpp", "ltm_pclsort.h"))
+    return _sha(KERNEL_SOURCES + API_SOURCES)
 
 
 def oracle_sha():

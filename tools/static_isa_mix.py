@@ -1,4 +1,4 @@
-"""Static instruction mix of the HIP kernels from their gfx950 assembly (no GPU needed): compiles lt-mapper_amd/csrc/ltm_kernels.hip with the
+"""Static instruction mix of the HIP kernels from their gfx950 assembly (no GPU needed): compiles lt-mapper_amd/csrc/ltm_k_projection.hip with the
 Makefile's flags and --cuda-device-only -S, then counts, per kernel whose mangled name contains a given substring, the VALU / SALU / LDS / global
 instructions, the loop headers, the register and LDS budget, and the most frequent VALU mnemonics.  How profiles/r4_vote_kernel_static_instruction_mix.txt
 was made (the per-point figures there come from reading one unrolled block of the listing by hand).
@@ -21,7 +21,7 @@ def main():
     wanted = sys.argv[1:] or ["k_vote_map_cullILb1ELb1", "k_map_rimg_blockminILb1ELb1"]
     with tempfile.TemporaryDirectory() as d:
         out = os.path.join(d, "k.s")
-        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.join(ROOT, "lt-mapper_amd", "csrc", "ltm_kernels.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
+        subprocess.run(["/opt/rocm/bin/hipcc"] + FLAGS + [os.path.join(ROOT, "lt-mapper_amd", "csrc", "ltm_k_projection.hip"), "-o", out], check=True, stderr=subprocess.DEVNULL)
         lines = open(out).read().splitlines()
     starts = [(i, l.split(":")[0]) for i, l in enumerate(lines) if re.match(r"^_ZN3ltm\w+:", l)]
     for w in wanted:
