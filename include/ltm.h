@@ -243,6 +243,10 @@ int ltm_voxel_grid_scanset_end(ltm_ctx*, ltm_vgs* ticket, ltm_scanset* out);
  * union of :589-590).  The caller zeroes it; ranks combine theirs with a MAX all-reduce. */
 int ltm_visibility_vote(ltm_ctx*, ltm_cloud map, ltm_scanset scans, ltm_poses poses, size_t kf_begin, size_t kf_end,
                         float res_alpha, float diff_thres, int mode, uint8_t* labels_dev);
+/* Optional: scan2RangeImg (Removerter.cpp:109-156) of keyframes [kf_begin,kf_end) of `scans` for ALL the listed resolutions in one pass over the points,
+ * kept for the votes that follow (selfRemovert projects every scan at res and 0.95 res for each entry of remove_resolution_list: six image shapes whose
+ * spherical coordinates are the same).  ltm_visibility_vote computes what it does not find, one shape at a time; the images are identical either way. */
+int ltm_scanset_prepare_range_images(ltm_ctx*, ltm_scanset scans, size_t kf_begin, size_t kf_end, const float* res_alphas, size_t n_alphas);
 /* partitionCurrentMap tail (Removerter.cpp:816-824, :675-687, :933-946): index-ascending split */
 int ltm_partition_by_labels(ltm_ctx*, ltm_cloud map, const uint8_t* labels_dev, ltm_cloud* kept, ltm_cloud* flagged);
 /* vote over all keyframes + partition (single-GPU convenience).  host_labels (M bytes) may be NULL. */

@@ -95,6 +95,7 @@ SIGNATURES = {
     "ltm_voxel_grid_scanset": (_i, [_vp, _u64, _f, _pu64]),
     "ltm_voxel_grid_scanset_begin": (_i, [_vp, _u64, _f, C.POINTER(_vp)]),
     "ltm_voxel_grid_scanset_end": (_i, [_vp, _vp, _pu64]),
+    "ltm_scanset_prepare_range_images": (_i, [_vp, _u64, _sz, _sz, C.POINTER(_f), _sz]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
     "ltm_visibility_partition": (_i, [_vp, _u64, _u64, _u64, _f, _f, _i, _pu64, _pu64, _vp]),
@@ -425,6 +426,11 @@ class Context:
         out = _u64()
         self._ck(self.lib.ltm_voxel_grid_scanset_end(self.h, t, C.byref(out)))
         return ScanSet(self, out.value)
+
+    def prepare_scan_images(self, scans, alphas, kf_begin=0, kf_end=None):
+        """scan range images of all the listed resolutions in one pass over the scans (kept for the votes that follow)"""
+        a = (_f * len(alphas))(*[float(x) for x in alphas])
+        self._ck(self.lib.ltm_scanset_prepare_range_images(self.h, scans.h, kf_begin, scans.n_kf if kf_end is None else kf_end, a, len(alphas)))
 
     def visibility_vote(self, cmap, scans, poses, kf_begin, kf_end, alpha, thr, mode, labels_dev_ptr):
         self._ck(self.lib.ltm_visibility_vote(self.h, cmap.h, scans.h, poses.h, kf_begin, kf_end, alpha, thr, mode, labels_dev_ptr))

@@ -102,6 +102,54 @@ const uint32_t* scan_images(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, s
     return buf;
 }
 
+// the finished scan images of keyframes [kb, kb+nb) for SEVERAL shapes, the missing ones computed in one pass over the scans (k_scan_rimg_multi) and cached
+void scan_images_prepare(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size_t kb, size_t nb, const std::vector<Geom>& geoms)
+{
+    std::vector<Geom> todo;
+    for (const Geom& g : geoms) {
+        bool have = false;
+        for (ScanImgEntry& e : c->scan_cache)
+            if (e.ss == ss_handle && e.rows == g.rows && e.cols == g.cols && e.kb == kb && e.nb == nb) { e.stamp = ++c->scan_cache_stamp; have = true; }
+        for (const Geom& t : todo) have = have || (t.rows == g.rows && t.cols == g.cols);
+        if (!have && g.rows > 0 && g.cols > 0) todo.push_back(g);
+    }
+    if (todo.empty() || !nb) return;
+    const uint64_t first = ss.off[kb], npts = ss.off[kb + nb] - first;
+    uint64_t longest = 0;
+    for (size_t k = kb; k < kb + nb; ++k) longest = std::max<uint64_t>(longest, ss.off[k + 1] - ss.off[k]);
+    for (size_t at = 0; at < todo.size(); at += kMaxScanShapes) {
+        const int n = (int)std::min<size_t>(kMaxScanShapes, todo.size() - at);
+        int rows[kMaxScanShapes], cols[kMaxScanShapes];
+        uint32_t *imgs[kMaxScanShapes], *smax[kMaxScanShapes];
+        size_t need = 0;
+        for (int j = 0; j < n; ++j) { rows[j] = todo[at + j].rows; cols[j] = todo[at + j].cols; need += nb * (size_t)rows[j] * cols[j] * sizeof(uint32_t); }
+        size_t held = 0;
+        for (const ScanImgEntry& e : c->scan_cache) held += e.bytes;
+        while (!c->scan_cache.empty() && held + need > c->scan_cache_cap) {      // evict least recently used (the shapes asked for were stamped above)
+            size_t lru = 0;
+            for (size_t i = 1; i < c->scan_cache.size(); ++i) if (c->scan_cache[i].stamp < c->scan_cache[lru].stamp) lru = i;
+            held -= c->scan_cache[lru].bytes;
+            c->pool.free(c->scan_cache[lru].buf); c->pool.free(c->scan_cache[lru].smax); c->pool.free(c->scan_cache[lru].qbound);
+            c->scan_cache.erase(c->scan_cache.begin() + lru);
+        }
+        double px_all = 0;
+        for (int j = 0; j < n; ++j) {
+            const size_t npx = (size_t)rows[j] * cols[j];
+            imgs[j] = reinterpret_cast<uint32_t*>(c->pool.alloc(nb * npx * sizeof(uint32_t)));
+            smax[j] = reinterpret_cast<uint32_t*>(c->pool.alloc(nb * sizeof(uint32_t)));
+            c->scan_cache.push_back(ScanImgEntry{ss_handle, rows[j], cols[j], kb, nb, imgs[j], smax[j], nb * npx * sizeof(uint32_t), ++c->scan_cache_stamp, nullptr, -1.0f});
+            px_all += (double)(nb * npx);
+        }
+        // algorithmic bytes as SURVEY 8d counts them: every shape is one scan2RangeImg of every scan (16 B per point read, 4 B per pixel written)
+        ProfScope p(c, "vote_scan", (double)npts * n, (double)npts * 16 * n + px_all * 4, (double)npts * 16 + px_all * 4);
+        for (int j = 0; j < n; ++j) {
+            LTM_HIP(fill_u32(imgs[j], kNoPointBits, nb * (size_t)rows[j] * cols[j], c->stream));
+            LTM_HIP(hipMemsetAsync(smax[j], 0, nb * sizeof(uint32_t), c->stream));
+        }
+        LTM_HIP(scan_range_images_multi(ss.d, ss.off_dev, kb, nb, npts, longest, todo[at], n, rows, cols, imgs, smax, c->stream));
+    }
+}
+
 // first use of an image shape by this context: is the bounded-error projection inside its bounds for it?  (see ltm_ctx::cull_geom_ok)
 bool cull_geometry_ok(ltm_ctx* c, const Geom& g, const Poses& ps, size_t kf)
 {
@@ -284,6 +332,20 @@ void do_partition(ltm_ctx* c, const Cloud& map, const uint8_t* labels, ltm_cloud
 
 // =========================================================================================== C ABI
 extern "C" {
+
+int ltm_scanset_prepare_range_images(ltm_ctx* c, ltm_scanset hs, size_t kf_begin, size_t kf_end, const float* alphas, size_t n_alphas)
+{
+    return guarded(c, [&] {
+        LTM_REQUIRE(alphas || n_alphas == 0, "null argument");
+        const ScanSet& ss = get_ss(c, hs);
+        LTM_REQUIRE(kf_begin <= kf_end && kf_end <= ss.nkf(), "keyframe range out of bounds");
+        if (kf_begin == kf_end || n_alphas == 0) return;
+        std::vector<Geom> geoms;
+        for (size_t i = 0; i < n_alphas; ++i) geoms.push_back(geom_for(c, alphas[i]));
+        const size_t KB = std::min(c->kf_batch, kf_end - kf_begin);      // the batches ltm_visibility_vote will ask for
+        for (size_t kb = kf_begin; kb < kf_end; kb += KB) scan_images_prepare(c, hs, ss, kb, std::min(KB, kf_end - kb), geoms);
+    });
+}
 
 int ltm_visibility_vote(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_poses hp, size_t kf_begin, size_t kf_end, float alpha,
                         float thr, int mode, uint8_t* labels_dev)

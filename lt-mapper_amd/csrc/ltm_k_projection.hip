@@ -50,6 +50,36 @@ k_scan_rimg(const float4* __restrict__ scans, const uint64_t* __restrict__ offse
     img_min_u32(img + (lo - kb) * (size_t)(g.rows * g.cols) + px, f2u(s.r));
 }
 
+// The same for up to kMaxScanShapes image shapes at once (round 6): the remove / revert passes of selfRemovert project every scan into six shapes
+// (2.5, 2.375, 2.0, 1.9, 1.5, 1.425 pixels per degree).  The point is read once, the exact atan2f / sqrtf chain and the two divisions by the field of
+// view (shape-independent) run once, and each shape costs a multiply, a round, a clamp and its atomic -- bit for bit pixel_row_col's arithmetic.
+struct ScanShapes { int n; int rows[kMaxScanShapes], cols[kMaxScanShapes]; uint32_t* img[kMaxScanShapes]; };
+__global__ void __launch_bounds__(kBlock)
+k_scan_rimg_multi(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, Geom gg, ScanShapes sh)
+{
+    const size_t lo = kb + blockIdx.y;
+    const uint64_t a = offsets[lo], local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (local >= offsets[lo + 1] - a) return;
+    const RimgGeom g = make_geom(gg);      // rows / cols of gg are not used: only the field of view and the fast-form switch
+    const float4 p = scans[a + local];
+    const Sph s = cart2sph(p.x, p.y, p.z);
+    const float el_deg = g.fast ? rad2deg_fast(s.el) : rad2deg_exact(s.el);
+    const float az_deg = g.fast ? rad2deg_fast(s.az) : rad2deg_exact(s.az);
+    const float u = 1.0f - div_by_const(el_deg + g.half_v, g.vfov, g.inv_v, g.fast);
+    const float w = div_by_const(az_deg + g.half_h, g.hfov, g.inv_h, g.fast);
+    const uint32_t rbits = f2u(s.r);
+#pragma unroll
+    for (int j = 0; j < kMaxScanShapes; ++j) {
+        if (j >= sh.n) break;
+        const float frows = (float)sh.rows[j], fcols = (float)sh.cols[j];
+        float fr = roundf(frows * u), fc = roundf(fcols * w);
+        fr = (fr < 0.0f) ? 0.0f : fr;  fr = (frows - 1.0f < fr) ? frows - 1.0f : fr;
+        fc = (fc < 0.0f) ? 0.0f : fc;  fc = (fcols - 1.0f < fc) ? fcols - 1.0f : fc;
+        const size_t npx = (size_t)sh.rows[j] * (size_t)sh.cols[j];
+        img_min_u32(sh.img[j] + (size_t)blockIdx.y * npx + (size_t)((int)fr * sh.cols[j] + (int)fc), rbits);
+    }
+}
+
 // smax[kf] = float bits of the largest NON-EMPTY (< 10000) pixel of the finished scan image of keyframe kf: a map point farther than
 // smax - thr cannot be flagged in mode 0.  grid = (chunks, keyframes); positive floats order like their bit patterns.
 __global__ void __launch_bounds__(kBlock)
@@ -115,6 +145,29 @@ hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, s
         const uint32_t npx = (uint32_t)(g.rows * g.cols);
         k_image_max<<<dim3(std::min<unsigned>(grid_for(npx, kBlock * 8), 64), (unsigned)nb), dim3(kBlock), 0, s>>>(scan_img, npx, smax_bits);
     }
+    return hipGetLastError();
+}
+
+hipError_t scan_range_images_multi(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t n_pts, uint64_t max_kf_pts, Geom g,
+                                   int n_shapes, const int* rows, const int* cols, uint32_t* const* imgs, uint32_t* const* smax_bits, hipStream_t s)
+{
+    if (n_shapes < 1 || n_shapes > kMaxScanShapes) return hipErrorInvalidValue;
+    ScanShapes sh{};
+    sh.n = n_shapes;
+    for (int j = 0; j < n_shapes; ++j) { sh.rows[j] = rows[j]; sh.cols[j] = cols[j]; sh.img[j] = imgs[j]; }
+    if (n_pts && max_kf_pts)
+        for (size_t k0 = 0; k0 < nb; k0 += 65535) {       // gridDim.y limit
+            const size_t nk = std::min<size_t>(65535, nb - k0);
+            ScanShapes part = sh;
+            for (int j = 0; j < n_shapes; ++j) part.img[j] = sh.img[j] + k0 * (size_t)rows[j] * (size_t)cols[j];
+            k_scan_rimg_multi<<<dim3(grid_for(max_kf_pts), (unsigned)nk), dim3(kBlock), 0, s>>>(scans, offsets_dev, kb + k0, g, part);
+        }
+    if (nb)
+        for (int j = 0; j < n_shapes; ++j) {
+            if (!smax_bits || !smax_bits[j]) continue;
+            const uint32_t npx = (uint32_t)(rows[j] * cols[j]);
+            k_image_max<<<dim3(std::min<unsigned>(grid_for(npx, kBlock * 8), 64), (unsigned)nb), dim3(kBlock), 0, s>>>(imgs[j], npx, smax_bits[j]);
+        }
     return hipGetLastError();
 }
 

@@ -37,6 +37,11 @@ hipError_t fill_u64(uint64_t* p, uint64_t v, size_t n, hipStream_t s);
 hipError_t scan_range_images(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb,
                              uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts, Geom g, uint32_t* scan_img, uint32_t* smax_bits, hipStream_t s);
 // squared-range bound image of the range-culled vote kernel from finished scan images (see k_scan_qbound)
+// scan2RangeImg of keyframes [kb, kb+nb) into n_shapes (<= kMaxScanShapes) image shapes of one field of view in ONE pass over the points; imgs[j] pre-filled
+// with the empty range, smax_bits[j] (nullable) zeroed.  Bit-identical to n_shapes calls of scan_range_images.
+static constexpr int kMaxScanShapes = 8;
+hipError_t scan_range_images_multi(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t nb, uint64_t n_pts, uint64_t max_kf_pts, Geom g,
+                                   int n_shapes, const int* rows, const int* cols, uint32_t* const* imgs, uint32_t* const* smax_bits, hipStream_t s);
 hipError_t scan_qbound(const uint32_t* scan_img, size_t n, float thr, float* qbound, hipStream_t s);
 // bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);

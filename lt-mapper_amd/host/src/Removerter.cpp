@@ -304,6 +304,15 @@ void Removerter::resetCurrrentMapAsStatic(const Session& _sess) { resetCurrrentM
 
 void Removerter::selfRemovert(const Session& _sess, int _repeat = 1)                     // Removerter.cpp:1378-1393
 {
+    if (_repeat > 0 && !remove_resolution_list_.empty()) {
+        // every scan range image the passes below will ask for (res and 0.95 res of each list entry), in ONE pass over the scans
+        std::vector<float> alphas(remove_resolution_list_.begin(), remove_resolution_list_.end());
+        for (float _res : remove_resolution_list_) alphas.push_back((float)(0.95 * _res));
+        ltm_poses ph = 0; size_t kb = 0, ke = 0;
+        _sess.stageArgs(_sess.keyframe_scans_, &ph, &kb, &ke);
+        ltm_ctx* ctx = _sess.dev_->ctx;
+        ltmCheck(ctx, ltm_scanset_prepare_range_images(ctx, _sess.keyframe_scans_->h, kb, ke, alphas.data(), alphas.size()), "ltm_scanset_prepare_range_images");
+    }
     for (float _res : remove_resolution_list_) {
         for (int i = 0; i < _repeat; i++) {
             removeOnce(_sess, _sess, _res);

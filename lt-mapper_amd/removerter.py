@@ -65,6 +65,7 @@ class HipOps:
     def voxel_grid_scanset_end(self, ticket): return self.ctx.voxel_grid_scanset_end(ticket)
     def preclean(self, s, radius): return self.ctx.preclean(s, radius)                      # Session.cpp:506-533
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
+    def prepare_scan_images(self, scans, alphas): self.ctx.prepare_scan_images(scans, alphas)
     def reproject(self, cmap, poses, alpha): return self.ctx.reproject(cmap, poses, alpha)
     def knn_partition(self, target, scans, poses, k, thr): return self.ctx.knn_partition(target, scans, poses, k, thr)
     def knn_split(self, target, query, k, thr): return self.ctx.knn_split_cloud(target, query, k, thr)
@@ -239,6 +240,10 @@ class Removerter:
         target.map_global_curr_ = target.map_global_curr_dynamic_
 
     def selfRemovert(self, sess, repeat=1, ops=None):   # Removerter.cpp:1378-1393
+        prepare = getattr(ops or self.ops, "prepare_scan_images", None)
+        if prepare is not None and repeat > 0:      # every scan image the passes below will ask for, in one pass over the scans
+            rs = [float(np.float32(r)) for r in self.P.remove_resolution_list]
+            prepare(sess.keyframe_scans_, rs + [float(np.float32(0.95 * r)) for r in rs])
         for res in self.P.remove_resolution_list:
             res = float(np.float32(res))
             for _ in range(repeat):                                            # `i < _repeat`, Removerter.cpp:1381: repeat 0 runs nothing
