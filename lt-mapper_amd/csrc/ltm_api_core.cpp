@@ -274,8 +274,6 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         }
         if (const char* v = getenv("LTM_KNN_STATS")) c->knn_stats_on = atoi(v);
         if (const char* v = getenv("LTM_KNN_SORT_QUEUE")) c->knn_sort_queue = atoi(v);
-        if (const char* v = getenv("LTM_KNN_COOP")) c->knn_coop = atoi(v);
-        if (const char* v = getenv("LTM_KNN_QUEUE_FROM_PHASE1")) c->knn_direct_queue = atoi(v);
         if (const char* v = getenv("LTM_CULL_SELFCHECK")) c->cull_selfcheck = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
@@ -1017,7 +1015,6 @@ int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
         c->occlusion_min_pairs = parent->occlusion_min_pairs; c->occlusion_r_near = parent->occlusion_r_near; c->occlusion_incremental = parent->occlusion_incremental;
         c->voxel_key_compress = parent->voxel_key_compress; c->voxel_fused_tail = parent->voxel_fused_tail; c->voxel_identity = parent->voxel_identity;
         c->knn_two_phase = parent->knn_two_phase; c->knn_sort_queue = parent->knn_sort_queue; c->knn_stats_on = parent->knn_stats_on;
-        c->knn_coop = parent->knn_coop; c->knn_direct_queue = parent->knn_direct_queue;
         c->cull_eps_scale = parent->cull_eps_scale; c->cull_eps_floor = parent->cull_eps_floor;
         c->cull_selfcheck = parent->cull_selfcheck; c->cull_geom_ok = parent->cull_geom_ok;      // shapes the parent has checked already (same device, field of view, extrinsic)
         c->el_fit = parent->el_fit; for (int i = 0; i < 4; ++i) c->el_c[i] = parent->el_c[i]; c->el_fit_err = parent->el_fit_err;

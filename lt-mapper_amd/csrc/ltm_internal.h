@@ -305,8 +305,6 @@ struct ltm_ctx {
     uint64_t voxel_identity_hits = 0, voxel_calls = 0;
     int knn_two_phase = 1;                      // LTM_KNN_FAST=0: the one-kernel exact search for every query (A/B switch)
     int knn_sort_queue = 1;                     // LTM_KNN_SORT_QUEUE=0: phase 2 walks the undecided queries in scan order instead of sorted by cell (A/B switch)
-    int knn_coop = 1;                           // LTM_KNN_COOP=0: phase 2 with one lane per query (round 4's k_knn_slow_sorted) instead of half a wavefront per query (A/B switch)
-    int knn_direct_queue = 1;                   // LTM_KNN_QUEUE_FROM_PHASE1=0: flag scan + k_knn_queue_scatter_keyed instead of phase 1 writing phase 2's queue (A/B switch)
     int knn_stats_on = 0;                       // LTM_KNN_STATS=1: count the queries phase 1 leaves undecided (one host round trip per call)
     uint64_t knn_undecided = 0, knn_queries = 0;
     // The culled kernels rest on error bounds of the bounded-error projection that were validated empirically (tools/eps_sweep.py, ltm_debug_cull_check in the

@@ -379,16 +379,14 @@ hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts,
 // phase-1 verdict from the query's own cell: 1 = certainly coexist (bucket), 0 = certainly diff (outside the grid), 2 = undecided
 template <int KT>
 __device__ __forceinline__ int knn_bucket_coexist(float qx, float qy, float qz, const KnnGrid& g, const KnnBucketRaw* __restrict__ buckets, uint32_t n_buckets,
-                                                   float cell_m, float dist_slack, float k_thr_lo, uint64_t& key_out)
+                                                   float cell_m, float dist_slack, float k_thr_lo)
 {
-    key_out = 0;
     const double tx = ((double)qx - g.ox) * g.inv_cell, ty = ((double)qy - g.oy) * g.inv_cell, tz = ((double)qz - g.oz) * g.inv_cell;
     const double fx = floor(tx), fy = floor(ty), fz = floor(tz);
     // outside the grid (NaN included): the occupied cells are 1 .. n-2 on every axis, so no target point is within a cell edge of such a
     // query: fewer than k neighbours inside the provably-complete radius, "diff" exactly as knn_near decides it
     if (!(fx >= 0.0 && fy >= 0.0 && fz >= 0.0 && fx < (double)g.nx && fy < (double)g.ny && fz < (double)g.nz)) return 0;
     const uint64_t key = ((uint64_t)(uint32_t)(int)fx * (uint32_t)g.ny + (uint32_t)(int)fy) * (uint32_t)g.nz + (uint32_t)(int)fz;   // == cell_id()
-    key_out = key;
     const float ux = (float)(tx - fx), uy = (float)(ty - fy), uz = (float)(tz - fz);
     const uint4* bp = reinterpret_cast<const uint4*>(buckets + bucket_of(hash64(key), n_buckets));
     uint4 v0 = bp[0];
@@ -431,40 +429,20 @@ __global__ void __launch_bounds__(kBlock)
 k_knn_fast(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, uint64_t first_pt,
            const double* __restrict__ poses, const double* __restrict__ inv_poses, HostMat34 b2l_h, KnnGrid g,
            const KnnBucketRaw* __restrict__ buckets, uint32_t n_buckets, float cell_m, float dist_slack, float k_thr_lo,
-           uint8_t* __restrict__ coexist, float4* __restrict__ local_out, uint64_t* __restrict__ queue, uint32_t* __restrict__ queue_count, unsigned ibits)
+           uint8_t* __restrict__ coexist, float4* __restrict__ local_out)
 {
     const size_t kf = kb + blockIdx.y;
     const uint64_t a = offsets[kf], local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const bool live = local < offsets[kf + 1] - a;
-    int verdict = 1;
-    uint64_t key = 0, i = 0;
-    if (live) {
-        const uint64_t gi = a + local;
-        i = gi - first_pt;
-        const float4 p4 = scans[gi];
-        float3 p = make_float3(p4.x, p4.y, p4.z);
-        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);      // Session.cpp:545 / :618 (quirk Q7)
-        const float3 gp = xform(load_mat(poses + 12 * kf), p);
-        float3 l = xform(load_mat(inv_poses + 12 * kf), gp);                               // :603-604
-        if (B2L_IDENTITY) l = xform_identity(l); else l = xform(to_dev(b2l_h), l);
-        local_out[i] = make_float4(l.x, l.y, l.z, p4.w);
-        verdict = knn_bucket_coexist<KT>(gp.x, gp.y, gp.z, g, buckets, n_buckets, cell_m, dist_slack, k_thr_lo, key);      // 2 = undecided
-        coexist[i] = (uint8_t)verdict;
-    }
-    // round 6: the undecided queries go straight into phase 2's queue as (cell id << index bits | query index) -- one atomic per wavefront -- instead of
-    // a flag scan + a second kernel that re-derived the cell from the point and its pose.  The queue's order is arbitrary; it is sorted by cell next and
-    // every answer is written through the query index.
-    if (queue) {
-        const bool und = live && verdict == 2;
-        const uint64_t b = __builtin_amdgcn_ballot_w64(und);
-        if (b) {
-            const uint32_t below = __builtin_amdgcn_mbcnt_hi((uint32_t)(b >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)b, 0u));
-            uint32_t base = 0;
-            if (below == 0u && und) base = atomicAdd(queue_count, (uint32_t)__popcll(b));
-            base = (uint32_t)__shfl((int)base, __ffsll((long long)b) - 1, 64);
-            if (und) queue[base + below] = (key << ibits) | i;
-        }
-    }
+    if (local >= offsets[kf + 1] - a) return;
+    const uint64_t gi = a + local, i = gi - first_pt;
+    const float4 p4 = scans[gi];
+    float3 p = make_float3(p4.x, p4.y, p4.z);
+    if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);      // Session.cpp:545 / :618 (quirk Q7)
+    const float3 gp = xform(load_mat(poses + 12 * kf), p);
+    float3 l = xform(load_mat(inv_poses + 12 * kf), gp);                               // :603-604
+    if (B2L_IDENTITY) l = xform_identity(l); else l = xform(to_dev(b2l_h), l);
+    local_out[i] = make_float4(l.x, l.y, l.z, p4.w);
+    coexist[i] = (uint8_t)knn_bucket_coexist<KT>(gp.x, gp.y, gp.z, g, buckets, n_buckets, cell_m, dist_slack, k_thr_lo);      // 2 = undecided
 }
 
 // queue[pos[i]] = i for the undecided queries (pos = exclusive scan of flag == 2); *count = their number
@@ -502,9 +480,8 @@ struct FlagUndecided { __host__ __device__ uint32_t operator()(uint8_t v) const 
 
 hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
                               const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity, KnnGrid g, const void* buckets,
-                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s, uint64_t* queue, uint32_t* queue_count, unsigned ibits)
+                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s)
 {
-    if (queue_count) { const hipError_t e0 = hipMemsetAsync(queue_count, 0, 4, s); if (e0 != hipSuccess) return e0; }
     if (!n_pts || !max_kf_pts) return hipSuccess;
     if (k < 1 || k > 4) return hipErrorInvalidValue;
     const float cell_m = (float)(1.0 / g.inv_cell);
@@ -515,7 +492,7 @@ hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, 
         for (size_t k0 = kb; k0 < ke; k0 += 65535) {
             const size_t k1 = std::min(ke, k0 + 65535);
             k_knn_fast<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(grid_for(max_kf_pts), (unsigned)(k1 - k0)), dim3(kBlock), 0, s>>>(
-                scans, offsets_dev, k0, first_pt, poses_dev, inv_poses_dev, b2l, g, bk, n_buckets, cell_m, dist_slack, k_thr_lo, coexist, local_out, queue, queue_count, ibits);
+                scans, offsets_dev, k0, first_pt, poses_dev, inv_poses_dev, b2l, g, bk, n_buckets, cell_m, dist_slack, k_thr_lo, coexist, local_out);
         }
     };
     auto by_kt = [&](auto b2l_tag) {
@@ -607,89 +584,6 @@ k_knn_slow_sorted(const float4* __restrict__ scans, const uint64_t* __restrict__
         coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo, bitmap, bitmap_mask) ? 1 : 0;
     }
 }
-// ---- phase 2, cooperative form (round 6).  k_knn_slow_sorted walks a query's 27 cells from ONE lane: probe -> entry -> one point after the other, cell
-// after cell, and the lanes of a wavefront diverge -- measured ~190 us per wavefront of 64 queries, i.e. on the order of a hundred dependent memory round
-// trips.  Here HALF A WAVEFRONT serves one query: lane l < 27 of the half takes cell l of the 3 x 3 x 3 block (bitmap word, table probe, its cell's few
-// points with the exact L2_Simple arithmetic, its own k best), then five xor-shuffle steps merge the 27 sorted k-lists and lane 0 evaluates the predicate
-// of Session.cpp:590-599 on the k smallest squared distances of ALL 27 cells.  That is knn_near's answer: its early exits return "coexist" only once the
-// predicate holds on a subset of the candidates, and more candidates can only lower the k smallest values and their monotonically rounded sum.  The chain
-// per query is bitmap -> entry -> points (1-3 loads) -> shuffles, the 27 cells in parallel.
-template <bool B2L_IDENTITY, int KT>
-__global__ void __launch_bounds__(kBlock)
-k_knn_coop_sorted(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
-                  const double* __restrict__ poses, HostMat34 b2l_h, const float4* __restrict__ tgt, KnnGrid g,
-                  const HashEntry* __restrict__ table, uint32_t mask, const unsigned long long* __restrict__ bitmap, uint32_t bitmap_mask, int k_param, float thr, float cell2_lo,
-                  const uint64_t* __restrict__ queue, uint32_t n, uint64_t imask, uint8_t* __restrict__ coexist)
-{
-    const uint32_t l = threadIdx.x & 31u;
-    const uint32_t group = (blockIdx.x * blockDim.x + threadIdx.x) >> 5, n_groups = (gridDim.x * blockDim.x) >> 5;
-    const int dx = (int)(l / 9u) - 1, dy = (int)((l / 3u) % 3u) - 1, dz = (int)(l % 3u) - 1;
-    const int nx = (int)g.nx, ny = (int)g.ny, nz = (int)g.nz;
-    for (uint32_t q = group; q < n; q += n_groups) {
-        // the query (every lane of the half computes it: same addresses, one transaction each)
-        const uint64_t i = queue[q] & imask;
-        const uint64_t gi = first_pt + i;
-        const size_t kf = find_kf(offsets, kb, ke, gi);
-        const float4 p4 = scans[gi];
-        float3 p = make_float3(p4.x, p4.y, p4.z);
-        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
-        const float3 gp = xform(load_mat(poses + 12 * kf), p);
-        const double fx = floor(((double)gp.x - g.ox) * g.inv_cell), fy = floor(((double)gp.y - g.oy) * g.inv_cell), fz = floor(((double)gp.z - g.oz) * g.inv_cell);
-        const int cx = (fx >= -1.0 && fx <= (double)nx) ? (int)fx : -2;
-        const int cy = (fy >= -1.0 && fy <= (double)ny) ? (int)fy : -2;
-        const int cz = (fz >= -1.0 && fz <= (double)nz) ? (int)fz : -2;
-        float best[KT];
-#pragma unroll
-        for (int j = 0; j < KT; ++j) best[j] = __builtin_inff();
-        auto push = [&](float d) {
-#pragma unroll
-            for (int j = KT - 1; j >= 0; --j) {
-                if (j > 0) best[j] = (d < best[j - 1]) ? best[j - 1] : fminf(best[j], d);
-                else best[0] = fminf(best[0], d);
-            }
-        };
-        if (l < 27u) {
-            const int x = cx + dx, y = cy + dy, z = cz + dz;
-            const bool in = !((unsigned)x >= (unsigned)nx || (unsigned)y >= (unsigned)ny || (unsigned)z >= (unsigned)nz);
-            if (in && (!bitmap || occ_test(bitmap, bitmap_mask, x, y, z))) {
-                const uint64_t key = ((uint64_t)(uint32_t)x * (uint32_t)ny + (uint32_t)y) * (uint32_t)nz + (uint32_t)z;   // == cell_id()
-                uint32_t h = hash64(key) & mask;
-                HashEntry e = table[h];
-                while (e.key != key && e.key != kEmptyKey) { h = (h + 1) & mask; e = table[h]; }
-                if (e.key == key) {
-                    // the cell's run, three points per round trip (runs are short where phase 1 could not decide)
-                    for (uint32_t j = e.start; j < e.end; j += 3) {
-                        const float4 t0 = tgt[j], t1 = tgt[min(j + 1, e.end - 1)], t2 = tgt[min(j + 2, e.end - 1)];
-                        push(sqdist_l2simple(gp.x, gp.y, gp.z, t0.x, t0.y, t0.z));
-                        if (j + 1 < e.end) push(sqdist_l2simple(gp.x, gp.y, gp.z, t1.x, t1.y, t1.z));
-                        if (j + 2 < e.end) push(sqdist_l2simple(gp.x, gp.y, gp.z, t2.x, t2.y, t2.z));
-                    }
-                }
-            }
-        }
-        // merge the 32 sorted k-lists of the half wavefront (a value pushed twice would be wrong: each step takes the PARTNER's list as it was before the step)
-#pragma unroll
-        for (int off = 16; off > 0; off >>= 1) {
-            float other[KT];
-#pragma unroll
-            for (int j = 0; j < KT; ++j) other[j] = __shfl_xor(best[j], off, 32);
-#pragma unroll
-            for (int j = 0; j < KT; ++j) push(other[j]);
-        }
-        if (l == 0u) {
-            // knn_near's final test: fewer than k candidates inside the provably complete radius => the k-th neighbour is >= a cell away => "diff"
-            bool near = false;
-            if (best[KT - 1] < cell2_lo) {      // (an unfilled slot holds +inf)
-                double acc = 0.0;
-#pragma unroll
-                for (int j = 0; j < KT; ++j) acc = acc + (double)best[j];
-                near = fabsf((float)acc / (float)k_param) < thr;
-            }
-            coexist[i] = near ? 1 : 0;
-        }
-    }
-}
-
 // bits of the largest cell id + bits of the largest query index; 0 if they do not fit one word (the caller then keeps the unsorted queue)
 unsigned knn_sorted_queue_bits(KnnGrid g, uint64_t n_pts, unsigned* ibits_out)
 {
@@ -715,7 +609,7 @@ hipError_t knn_two_phase_compact_keyed(const float4* scans, const uint64_t* offs
 hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, const double* poses_dev, HostMat34 b2l,
                                       int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask, const void* bitmap,
                                       uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist, const uint64_t* queue_in, uint64_t* queue_sorted, uint32_t n_und,
-                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s, bool cooperative)
+                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s)
 {
     if (!n_und) return hipSuccess;
     if (k < 1 || k > 4 || Mt < (size_t)k) return hipErrorInvalidValue;
@@ -723,15 +617,7 @@ hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offse
     if (e != hipSuccess) return e;
     const unsigned blocks = (unsigned)std::min<uint64_t>(grid_for(n_und), 8192);
     const uint64_t imask = (1ull << ibits) - 1ull;
-    const bool coop = cooperative && Mt > 64;      // (tiny targets are brute-forced inside knn_near)
     auto slow = [&](auto b2l_tag, auto kt_tag) {
-        if (coop) {
-            const unsigned cblocks = (unsigned)std::min<uint64_t>(((uint64_t)n_und * 32 + kBlock - 1) / kBlock, 16384);
-            k_knn_coop_sorted<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(cblocks), dim3(kBlock), 0, s>>>(
-                scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, g, table, table_mask, reinterpret_cast<const unsigned long long*>(bitmap), bitmap_mask, k, thr,
-                cell2_lo, queue_sorted, n_und, imask, coexist);
-            return;
-        }
         k_knn_slow_sorted<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(blocks), dim3(kBlock), 0, s>>>(
             scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, reinterpret_cast<const unsigned long long*>(bitmap), bitmap_mask, k, thr,
             cell2_lo, queue_sorted, n_und, imask, coexist);

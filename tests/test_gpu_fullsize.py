@@ -135,25 +135,19 @@ def test_two_phase_knn_equals_exact_search_at_full_size(ltm, full):
     Q = synth.make_session(2, 200, "os1-64", device="cuda:0")
     torch.cuda.synchronize()
     out = {}
-    # fast 1 = the shipped form: phase 1 writes phase 2's queue, phase 2 is the cooperative search (half a wavefront per query, round 6);
-    # "lane": phase 2 with one lane per query and the queue from a flag scan (round 4's form); 0: the one-kernel exact search for every query
-    variants = {1: dict(LTM_KNN_FAST=1), "lane": dict(LTM_KNN_FAST=1, LTM_KNN_COOP=0, LTM_KNN_QUEUE_FROM_PHASE1=0),
-                "coop_scan_queue": dict(LTM_KNN_FAST=1, LTM_KNN_QUEUE_FROM_PHASE1=0), 0: dict(LTM_KNN_FAST=0)}
-    for name, env in variants.items():
-        ctx = _ctx(ltm, LTM_KNN_STATS=1, **env)
+    for fast in (1, 0):
+        ctx = _ctx(ltm, LTM_KNN_FAST=fast, LTM_KNN_STATS=1)
         _, _, cmap = _load(ctx, full)
         q_scans, q_poses, _ = _load(ctx, Q)
         for k, thr in ((2, 0.01), (3, 0.04), (1, 0.003)):
             co, di = ctx.knn_partition(cmap, q_scans, q_poses, k, thr)
-            out[(name, k, thr)] = (co.download(), di.download())
+            out[(fast, k, thr)] = (co.download(), di.download())
         ctx.close()
     for k, thr in ((2, 0.01), (3, 0.04), (1, 0.003)):
-        (a_co, a_di) = out[(1, k, thr)]
+        (a_co, a_di), (b_co, b_di) = out[(1, k, thr)], out[(0, k, thr)]
         assert len(a_co[0]) > 1000 and len(a_di[0]) > 1000, "degenerate: one of the two classes is empty"
-        for other in ("lane", "coop_scan_queue", 0):
-            (b_co, b_di) = out[(other, k, thr)]
-            for (ap, ao), (bp, bo) in ((a_co, b_co), (a_di, b_di)):
-                assert (ao == bo).all() and (ap.view(np.uint32) == bp.view(np.uint32)).all(), f"k={k} thr={thr}: the shipped kNN split and variant {other!r} differ"
+        for (ap, ao), (bp, bo) in ((a_co, b_co), (a_di, b_di)):
+            assert (ao == bo).all() and (ap.view(np.uint32) == bp.view(np.uint32)).all(), f"k={k} thr={thr}: two-phase and exact kNN split differ"
 
 
 def test_voxel_sort_on_compressed_keys_equals_full_keys_at_full_size(ltm, full):
