@@ -266,6 +266,8 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_VOXEL_FUSED_TAIL")) c->voxel_fused_tail = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_IDENTITY")) c->voxel_identity = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION")) c->occlusion_cull = atoi(v);
+        if (const char* v = getenv("LTM_OCCLUSION_SUBTILE")) c->occlusion_subtile = atoi(v);
+        if (getenv("LTM_OCCLUSION_STATS")) c->occlusion_stats_on = 1;
         if (const char* v = getenv("LTM_OCCLUSION_MIN_PAIRS")) c->occlusion_min_pairs = (size_t)atoll(v);
         if (const char* v = getenv("LTM_OCCLUSION_INCREMENTAL")) c->occlusion_incremental = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) {      // a non-positive first shell would select no pair in any shell; NaN / inf fall back to the default
@@ -303,6 +305,9 @@ void ltm_destroy(ltm_ctx* c)
         fprintf(stderr, "[ltm] occlusion cull of the exact-image kernel: %llu (tile, keyframe) pairs, %.2f %% in the first shell, %.2f %% projected in all, %.2f %% dropped\n",
                 (unsigned long long)c->occl_pairs, 100.0 * c->occl_near / c->occl_pairs, 100.0 * c->occl_far_live / c->occl_pairs,
                 100.0 * (c->occl_pairs - c->occl_far_live) / c->occl_pairs);
+    if (getenv("LTM_OCCLUSION_STATS") && c->occl_quarters)
+        fprintf(stderr, "[ltm] occlusion cull, second look: %llu 1024-point quarters in the pairs left alive, %.2f %% of them projected\n",
+                (unsigned long long)c->occl_quarters, 100.0 * c->occl_quarters_live / c->occl_quarters);
     if (c->knn_stats_on && c->knn_queries)
         fprintf(stderr, "[ltm] kNN two-phase: %llu of %llu scan queries left undecided by the bucket test (%.2f %%)\n", (unsigned long long)c->knn_undecided,
                 (unsigned long long)c->knn_queries, 100.0 * (double)c->knn_undecided / (double)c->knn_queries);
@@ -1013,6 +1018,7 @@ int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
         for (int i = 0; i < 3; ++i) c->selfcheck[i] = parent->selfcheck[i];
         c->scan_cache_cap = parent->scan_cache_cap; c->voxel_packed_sort = parent->voxel_packed_sort; c->occlusion_cull = parent->occlusion_cull;
         c->occlusion_min_pairs = parent->occlusion_min_pairs; c->occlusion_r_near = parent->occlusion_r_near; c->occlusion_incremental = parent->occlusion_incremental;
+        c->occlusion_subtile = parent->occlusion_subtile; c->occlusion_stats_on = parent->occlusion_stats_on;
         c->voxel_key_compress = parent->voxel_key_compress; c->voxel_fused_tail = parent->voxel_fused_tail; c->voxel_identity = parent->voxel_identity;
         c->knn_two_phase = parent->knn_two_phase; c->knn_sort_queue = parent->knn_sort_queue; c->knn_stats_on = parent->knn_stats_on;
         c->cull_eps_scale = parent->cull_eps_scale; c->cull_eps_floor = parent->cull_eps_floor;

@@ -202,7 +202,8 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     // taking it from the pool every time changes which blocks the stages around it find there
     const size_t tbytes = scan_temp_bytes(n_pairs);
     const size_t dwords = (rbs + 31) / 32;         // dirty-row bitmap of the incremental coarse maximum
-    const size_t need = n_tiles * 24 + n_pairs * (1 + 1 + 4 + 4) + 64 + nb * rbs * cbs * 4 + nb * dwords * 4 + tbytes + 9 * 256;
+    const bool subtiles = c->occlusion_subtile != 0;      // second look at the 1024-point quarters of a live tile (round 6)
+    const size_t need = n_tiles * 24 + n_pairs * (1 + 1 + 4 + 4) + 64 + nb * rbs * cbs * 4 + nb * dwords * 4 + tbytes + (subtiles ? n_tiles * 96 + n_pairs + 64 : 0) + 12 * 256;
     if (c->occl_scratch_bytes < need) {
         if (c->occl_scratch) { sync(c); c->pool.free(c->occl_scratch); c->occl_scratch = nullptr; c->occl_scratch_bytes = 0; }   // (the alloc below may throw)
         c->occl_scratch = c->pool.alloc(need + need / 4);
@@ -219,7 +220,14 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     uint32_t* cmax = reinterpret_cast<uint32_t*>(carve(nb * rbs * cbs * 4));
     uint32_t* dirty = c->occlusion_incremental ? reinterpret_cast<uint32_t*>(carve(nb * dwords * 4)) : nullptr;
     void* temp = carve(tbytes);
+    float* tbq = subtiles ? reinterpret_cast<float*>(carve(n_tiles * 96)) : nullptr;
+    uint8_t* submask = subtiles ? reinterpret_cast<uint8_t*>(carve(n_pairs)) : nullptr;
+    unsigned long long* sub_stats = subtiles ? reinterpret_cast<unsigned long long*>(carve(64)) : nullptr;
     LTM_HIP(tile_bounds(map.d, map.n, tb, c->stream));
+    if (subtiles) {
+        LTM_HIP(subtile_bounds(map.d, map.n, tbq, c->stream));
+        LTM_HIP(hipMemsetAsync(sub_stats, 0, 16, c->stream));
+    }
     LTM_HIP(hipMemsetAsync(done, 0, n_pairs, c->stream));
     if (dirty) {      // rows no projection has touched yet hold empty pixels: their coarse maximum is the empty range (10000 m, utility.h:93)
         LTM_HIP(hipMemsetAsync(dirty, 0, nb * dwords * 4, c->stream));
@@ -230,12 +238,13 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     for (int shell = 0; shell < 12; ++shell) {
         const bool last = shell == 11 || r_hi > 1.0e4f;
         if (last) r_hi = 3.0e38f;
-        LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream, dirty));
+        LTM_HIP(occlusion_shell_pairs(ps.approx_dev, kb, nb, tb, n_tiles, g, r_lo, r_hi, img, shell > 0, cmax, done, flags, pos, list, count, temp, tbytes, c->stream, dirty,
+                                      tbq, submask, c->occlusion_stats_on ? sub_stats : nullptr));
         uint32_t n_live = 0;
         d2h(c, &n_live, count, 4);
         {
             HeavyScope hs(c, n_live);
-            LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, hs.stream(), ko));
+            LTM_HIP(map_range_images_pairs(map.d, map.n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, g, img, list, n_live, hs.stream(), ko, submask));
             hs.done();
         }
         n_proj += n_live;
@@ -244,6 +253,11 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
         r_lo = r_hi; r_hi *= 2.0f;
     }
     (void)n_done;
+    if (subtiles && c->occlusion_stats_on) {
+        unsigned long long st[2] = {0, 0};
+        d2h(c, st, sub_stats, 16);
+        c->occl_quarters += st[0]; c->occl_quarters_live += st[1];
+    }
     c->occl_pairs += n_pairs; c->occl_far_live += n_proj;
 }
 

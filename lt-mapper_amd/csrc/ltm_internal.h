@@ -297,6 +297,9 @@ struct ltm_ctx {
     size_t occlusion_min_pairs = (size_t)1 << 21;   // LTM_OCCLUSION_MIN_PAIRS: smaller launches are not worth the two extra passes (2 M pairs = 4096 tiles x 512 keyframes)
     float occlusion_r_near = 60.0f;             // LTM_OCCLUSION_RNEAR [m]: tiles nearer than this are projected first and serve as occluders
     int occlusion_incremental = 1;              // LTM_OCCLUSION_INCREMENTAL=0: the coarse maximum is re-reduced over every image row before every shell (A/B switch)
+    int occlusion_subtile = 1;                  // LTM_OCCLUSION_SUBTILE=0: the cull looks at whole 4096-point tiles only (round 5's form, A/B switch)
+    int occlusion_stats_on = 0;                 // LTM_OCCLUSION_STATS: also count the quarters of live pairs and those left alive (one more host round trip per batch)
+    uint64_t occl_quarters = 0, occl_quarters_live = 0;
     uint64_t occl_pairs = 0, occl_near = 0, occl_far_live = 0;      // statistics (LTM_OCCLUSION_STATS): pairs seen, in the first shell, projected in all
     void* occl_scratch = nullptr; size_t occl_scratch_bytes = 0;
     int voxel_key_compress = 1;                 // LTM_VOXEL_KEYBITS=0: sort over all 3*depth Morton bits (A/B switch)

@@ -201,6 +201,32 @@ k_tile_bounds(const float4* __restrict__ map, uint32_t M, float* __restrict__ bo
         bounds[6 * (size_t)blockIdx.x + d] = a; bounds[6 * (size_t)blockIdx.x + 3 + d] = b;
     }
 }
+// bounds of the four 1024-point quarters of every 4096-point tile (24 floats per tile): the occlusion cull's second look (k_pair_shell_select).
+// One wavefront per quarter; a quarter beyond the end of the map gets an inverted box (never live).
+__global__ void __launch_bounds__(kBlock)
+k_subtile_bounds(const float4* __restrict__ map, uint32_t M, float* __restrict__ bounds)
+{
+    const uint32_t sub = blockIdx.x * 4u + (threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t base = sub * 1024u;
+    float mn[3] = {3.0e38f, 3.0e38f, 3.0e38f}, mx[3] = {-3.0e38f, -3.0e38f, -3.0e38f};
+    for (uint32_t li = lane; li < 1024u; li += 64u) {
+        if (base + li >= M) break;
+        const float4 p = map[base + li];
+        mn[0] = fminf(mn[0], p.x); mn[1] = fminf(mn[1], p.y); mn[2] = fminf(mn[2], p.z);
+        mx[0] = fmaxf(mx[0], p.x); mx[1] = fmaxf(mx[1], p.y); mx[2] = fmaxf(mx[2], p.z);
+    }
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { mn[d] = fminf(mn[d], __shfl_xor(mn[d], off, 64)); mx[d] = fmaxf(mx[d], __shfl_xor(mx[d], off, 64)); }
+    if (lane < 3u) { bounds[6 * (size_t)sub + lane] = mn[lane]; bounds[6 * (size_t)sub + 3 + lane] = mx[lane]; }
+}
+hipError_t subtile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s)
+{
+    if (!M) return hipSuccess;
+    k_subtile_bounds<<<dim3((unsigned)((M + 4095) / 4096)), dim3(kBlock), 0, s>>>(map, (uint32_t)M, bounds);
+    return hipGetLastError();
+}
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s)
 {
     if (!M) return hipSuccess;
@@ -810,7 +836,8 @@ static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain sur
 template <bool B2L_IDENTITY, bool EL3, int SLOT_ROWS = 16>
 __global__ void __launch_bounds__(kBlock)
 k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs, int stop_after)
+                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs, int stop_after,
+                    const uint8_t* __restrict__ submask)
 {
     constexpr int kBmSlots = SLOT_ROWS * 64;
     static_assert(kBmSlots <= kBmSlotsMax, "");
@@ -824,6 +851,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
     __shared__ uint32_t qcount, ucount;
     const uint32_t per_block = (uint32_t)(kBlock * kPtsPerThread);
     TileKf tk;
+    uint32_t quarters = 0xfu;
     if (pairs) {
         // the list is sorted by (tile, keyframe); workgroup b runs on XCD b % 8 (see tile_kf_of_block), so XCD x walks the x-th eighth of
         // the list front to back: consecutive workgroups of one XCD share a tile and it is served from that XCD's L2, as in the plain launch
@@ -831,6 +859,7 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         if ((blockIdx.x >> 3) >= seg || at >= n_pairs) return;
         const uint32_t pr = pairs[at];
         tk.tile = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr / nb)); tk.kfb = (uint32_t)__builtin_amdgcn_readfirstlane((int)(pr % nb)); tk.valid = true;
+        if (submask) quarters = (uint32_t)__builtin_amdgcn_readfirstlane((int)submask[pr]);      // quarters of the tile the occlusion cull left alive
     } else {
         tk = tile_kf_of_block(blockIdx.x, (M + per_block - 1) / per_block, nb, kfg);
     }
@@ -861,6 +890,12 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         // ---- phase 1a (four points per lane in flight, as in k_vote_map_cull)
 #pragma unroll
         for (int j0 = 0; j0 < kPtsPerThread; j0 += 4) {
+            // points (j0 .. j0+3) * 256 + lane are the 1024 consecutive points of quarter j0 / 4: a hidden quarter costs nothing (uniform branch)
+            if (!((quarters >> (j0 >> 2)) & 1u)) {
+#pragma unroll
+                for (int u = 0; u < 4; ++u) { rlo[j0 + u] = -1.0f; rec[j0 + u] = 0u; }
+                continue;
+            }
             float4 pt[4];
             CullCand cc[4];
 #pragma unroll
@@ -902,8 +937,9 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
                 am[u] = u2f(amin[rec[j0 + u] >> 20]);
             }
             bool sv[4];
+            const bool quarter_live = ((quarters >> (j0 >> 2)) & 1u) != 0u;
 #pragma unroll
-            for (int u = 0; u < 4; ++u) sv[u] = !(rlo[j0 + u] > am[u]);
+            for (int u = 0; u < 4; ++u) sv[u] = quarter_live & !(rlo[j0 + u] > am[u]);
             // one LDS atomic per wave and group of four (see k_vote_map_cull)
             const uint64_t b0 = __builtin_amdgcn_ballot_w64(sv[0]), b1 = __builtin_amdgcn_ballot_w64(sv[1]),
                            b2 = __builtin_amdgcn_ballot_w64(sv[2]), b3 = __builtin_amdgcn_ballot_w64(sv[3]);
@@ -981,7 +1017,7 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
         const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, ko.bm_stop)
+#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, ko.bm_stop, nullptr)
         const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;
         if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true); else LTM_LAUNCH_BM(false, false); }
         else { if (el3) LTM_LAUNCH_BM(true, true); else LTM_LAUNCH_BM(true, false); }
@@ -1058,7 +1094,7 @@ __device__ __forceinline__ SphereRect sphere_rect(const RimgGeom& g, const float
 __global__ void __launch_bounds__(kBlock)
 k_pair_shell_select(const float* __restrict__ approx_poses, uint32_t kb, uint32_t nb, const float* __restrict__ tile_bounds, uint32_t n_tiles, Geom gg,
                     float r_lo, float r_hi, const uint32_t* __restrict__ cmax, uint32_t rbs, uint32_t cbs, uint8_t* __restrict__ done, uint8_t* __restrict__ flags,
-                    uint32_t* __restrict__ dirty, uint32_t dw)
+                    uint32_t* __restrict__ dirty, uint32_t dw, const float* __restrict__ sub_bounds, uint8_t* __restrict__ submask, unsigned long long* __restrict__ sub_stats)
 {
     const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_tiles * nb) return;
@@ -1082,6 +1118,34 @@ k_pair_shell_select(const float* __restrict__ approx_poses, uint32_t kb, uint32_
                 for (int cb = cb0; cb <= cb1; ++cb) m = max(m, cmax[((size_t)kfb * rbs + r) * cbs + cb]);
             live = !(u2f(m) < sr.d_lo);
         }
+    }
+    // round 6: a second look at the four 1024-point quarters of a tile that stays live -- a quarter's bounding sphere has about half the tile's radius,
+    // so its pixel rectangle is a quarter of the area and its nearest point is farther: quarters behind the image built so far are masked out of the
+    // projection kernel's phase 1 (the same argument as for the whole tile: every pixel the quarter can touch already holds a strictly nearer return)
+    if (submask) {
+        uint32_t m4 = 0xfu;
+        if (live && cmax && sr.cullable && sub_bounds) {
+            m4 = 0u;
+            for (int qd = 0; qd < 4; ++qd) {
+                const float* sb = sub_bounds + 6 * ((size_t)tile * 4 + qd);
+                if (!(sb[0] <= sb[3])) continue;                      // empty quarter (past the end of the map)
+                const SphereRect qr = sphere_rect(g, ap, sb);
+                bool ql = true;
+                if (qr.cullable) {
+                    const int qb0 = qr.c0 >> 3, qb1 = qr.c1 >> 3;
+                    if ((qr.r1 - qr.r0 + 1) * (qb1 - qb0 + 1) <= 256) {
+                        uint32_t m = 0;
+                        for (int r = qr.r0; r <= qr.r1; ++r)
+                            for (int cb = qb0; cb <= qb1; ++cb) m = max(m, cmax[((size_t)kfb * rbs + r) * cbs + cb]);
+                        ql = !(u2f(m) < qr.d_lo);
+                    }
+                }
+                if (ql) m4 |= 1u << qd;
+            }
+            if (m4 == 0u) live = false;
+        }
+        submask[t] = (uint8_t)m4;
+        if (sub_stats && live) { atomicAdd(&sub_stats[0], 4ull); atomicAdd(&sub_stats[1], (unsigned long long)__popc(m4)); }
     }
     done[t] = 1;
     flags[t] = live ? 1 : 0;
@@ -1134,7 +1198,7 @@ k_pair_list_scatter(const uint8_t* __restrict__ flags, uint8_t v, const uint32_t
 // the second shell: the first one is not tracked); out, those of this shell's
 hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
                                  const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
-                                 void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty)
+                                 void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty, const float* sub_bounds_dev, uint8_t* submask, unsigned long long* sub_stats)
 {
     const uint32_t n = (uint32_t)(n_tiles * nb);
     const uint32_t rbs = (uint32_t)g.rows, cbs = (uint32_t)(g.cols + 7) / 8;
@@ -1142,7 +1206,7 @@ hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_
     if (use_cmax) k_coarse_max<<<dim3(grid_for((size_t)nb * rbs * cbs)), dim3(kBlock), 0, s>>>(img, (uint32_t)g.rows, (uint32_t)g.cols, cbs, (uint32_t)nb, cmax, dirty, dw);
     if (dirty) { hipError_t e0 = hipMemsetAsync(dirty, 0, (size_t)nb * dw * 4, s); if (e0 != hipSuccess) return e0; }
     k_pair_shell_select<<<dim3(grid_for(n)), dim3(kBlock), 0, s>>>(approx_poses_dev, (uint32_t)kb, (uint32_t)nb, tile_bounds_dev, (uint32_t)n_tiles, g, r_lo, r_hi,
-                                                                use_cmax ? cmax : nullptr, rbs, cbs, done, flags, dirty, dw);
+                                                                use_cmax ? cmax : nullptr, rbs, cbs, done, flags, dirty, dw, sub_bounds_dev, submask, sub_stats);
     auto it = rocprim::make_transform_iterator(flags, FlagIs{1});
     hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, (size_t)n, rocprim::plus<uint32_t>(), s);
     if (e != hipSuccess) return e;
@@ -1151,11 +1215,12 @@ hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_
 }
 // k_map_rimg_blockmin over an explicit list of n_pairs (tile * nb + keyframe) pairs
 hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s, const KernelOpts& ko)
+                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s, const KernelOpts& ko,
+                                  const uint8_t* submask)
 {
     if (!n_pairs) return hipSuccess;
     dim3 grid((unsigned)(((n_pairs + 7) / 8) * 8));
-#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, ko.bm_stop)
+#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, ko.bm_stop, submask)
     const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;
     if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true); else LTM_LAUNCH_BMP(false, false); }
     else { if (el3) LTM_LAUNCH_BMP(true, true); else LTM_LAUNCH_BMP(true, false); }

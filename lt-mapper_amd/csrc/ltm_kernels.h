@@ -45,6 +45,7 @@ hipError_t scan_range_images_multi(const float4* scans, const uint64_t* offsets_
 hipError_t scan_qbound(const uint32_t* scan_img, size_t n, float thr, float* qbound, hipStream_t s);
 // bounds[6*t..] = {min xyz, max xyz} of map points [4096 t, 4096 (t+1))
 hipError_t tile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);
+hipError_t subtile_bounds(const float4* map, size_t M, float* bounds, hipStream_t s);   // 4 x 6 floats per 4096-point tile: its 1024-point quarters
 // Kernel variants and diagnostics, held by the context (ltm_ctx::kopts, read from the environment at ltm_create) and handed to the launchers: K contexts
 // on K host threads (ltm_run --gpus K) share no mutable state.  The non-default values are A/B baselines and timing diagnostics, not product paths.
 struct KernelOpts {
@@ -64,9 +65,11 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
 // done: n_tiles * nb zeroed bytes, pos / list: n_tiles * nb uint32, count: one uint32, cmax: nb * rows * ceil(cols/8) uint32, temp: scan_temp_bytes(n_tiles * nb)
 hipError_t occlusion_shell_pairs(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles, Geom g, float r_lo, float r_hi,
                                  const uint64_t* img, int use_cmax, uint32_t* cmax, uint8_t* done, uint8_t* flags, uint32_t* pos, uint32_t* list, uint32_t* count,
-                                 void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty_rows = nullptr);
+                                 void* temp, size_t temp_bytes, hipStream_t s, uint32_t* dirty_rows = nullptr,
+                                 const float* sub_bounds_dev = nullptr, uint8_t* submask = nullptr, unsigned long long* sub_stats = nullptr);   // submask[pair]: live 1024-point quarters of the tile (bit q), sub_stats: {quarters of live pairs, quarters left alive}
 hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
-                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s, const KernelOpts& ko);
+                                  HostMat34 b2l, int b2l_identity, Geom g, uint64_t* map_img, const uint32_t* pairs, size_t n_pairs, hipStream_t s, const KernelOpts& ko,
+                                  const uint8_t* submask = nullptr);
 // calcDescrepancyAndParseDynamicPointIdx over nb images; labels[idx] = 1 for flagged points
 hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, size_t n_px_total, float thr, int mode,
                             uint8_t* labels, hipStream_t s);
