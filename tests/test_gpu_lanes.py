@@ -41,6 +41,37 @@ def test_two_lanes_give_the_one_lane_outputs(three_res):
     ctx.close()
 
 
+def test_cascade_on_two_lanes_gives_the_one_lane_cascade():
+    """configs[2]'s driver with every pair run on two lanes (the deferred hand-over ends on the main lane while the query session's chain is already
+    running on the other): the same outputs, run for run, as the one-lane cascade"""
+    from ltmapper_amd import capi
+    from ltmapper_amd.cascade import run_cascade
+    from ltmapper_amd.removerter import HipOps, Params
+    from tools import synth
+    sess = [synth.to_numpy(synth.make_session(s, 10, "small")) for s in (1, 2, 3)]
+    P = Params(gpu_use_self_removert=True, remove_resolution_list=[2.5, 2.0])
+    outs = {}
+    for lanes in (1, 2):
+        ctx = capi.Context()
+        loaded = [(ctx.preclean(ctx.upload_scans(S["scans"], S["offsets"]), 2.5), ctx.poses(S["poses"], S["inv"])) for S in sess]
+        ops = HipOps(ctx)
+        runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:], lane_ops=ops.lane() if lanes == 2 else None)
+        got = {}
+        for j, rm in enumerate(runs):
+            for k, v in rm.outputs.items():
+                if v is not None:
+                    got[(j, k)] = v.download()
+            for k, v in rm.scan_outputs().items():
+                got[(j, "scans:" + k)], got[(j, "off:" + k)] = v.download()
+        outs[lanes] = got
+        del runs, loaded
+        ctx.close()
+    assert set(outs[1]) == set(outs[2]) and len(outs[1]) > 30
+    for k in outs[1]:
+        a, b = outs[1][k], outs[2][k]
+        assert a.shape == b.shape and ((a.view(np.uint32) == b.view(np.uint32)).all() if a.dtype == np.float32 else (a == b).all()), k
+
+
 def test_lend_give_fence_events():
     from ltmapper_amd import capi
     rng = np.random.default_rng(5)

@@ -21,7 +21,8 @@ COMMIT=$(cat "$ROOT/.commit_for_profiles" 2>/dev/null || echo unknown)
 
 kernel_trace() {   # $1 = workload, $2 = output stem
   rm -rf /tmp/prof_kt
-  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o bench -- $BENCH --workload $1 --steps 1 --warmup 0 --no-cpu-baseline --no-t-total \
+  # round 6: --lanes 1 -- per-kernel durations and counters are taken from the ONE-lane order (launches that overlap count each other's time); the bench line itself runs two lanes
+  rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/prof_kt -o bench -- $BENCH --workload $1 --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-t-total \
       --extra-out "$OUT/${2}_bench_under_rocprof_extra.json" 2>/dev/null | tail -1 > "$OUT/${2}_bench_under_rocprof.json"
   f=$(find /tmp/prof_kt -name "*kernel_stats.csv" | head -1)
   python3 - "$f" "$OUT/${2}_rocprofv3_kernel_stats.csv" <<'PY'
@@ -37,7 +38,7 @@ PY
 pmc_passes() {   # $1 = workload, $2 = output file
   for C in FETCH_SIZE WRITE_SIZE SQ_INSTS_VALU; do
     rm -rf /tmp/prof_$C
-    rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -o bench -- $BENCH --workload $1 --steps 1 --warmup 0 --no-cpu-baseline --no-t-total --extra-out /tmp/extra_$C.json > /dev/null 2>&1
+    rocprofv3 --pmc $C --output-format csv -d /tmp/prof_$C -o bench -- $BENCH --workload $1 --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-t-total --extra-out /tmp/extra_$C.json > /dev/null 2>&1
   done
   python3 - "$2" "$ROOT" "$COMMIT" "$1" <<'PY'
 import csv, glob, json, sys, collections
@@ -58,7 +59,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE", "SQ_INSTS_VALU"):
             else:
                 k = k.split("(")[0]
             e = agg[k][c]; e["sum"] += float(r["Counter_Value"]); e["dispatches"] += 1
-out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU, one pass each, on `python bench.py --workload W --steps 1 --warmup 0 --no-cpu-baseline --no-t-total`; "
+out = {"note": "rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE / --pmc SQ_INSTS_VALU, one pass each, on `python bench.py --workload W --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-t-total` (the one-lane order: non-overlapped launches); "
                "FETCH/WRITE are in KiB; FETCH_SIZE is doubled per MI355X_MICROARCH.md (gfx950 reports half of a wide coalesced read stream); "
                "SQ_INSTS_VALU counts wave instructions (x64 lanes); sums over all dispatches of each kernel = per step",
        "workload": sys.argv[4], "kernels_sha": bench.kernels_sha(), "commit": sys.argv[3], "all_kernels": agg}

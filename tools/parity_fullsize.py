@@ -57,7 +57,7 @@ def _compare_run(np, rm, ref, MAPS, report, prefix=""):
     return bad
 
 
-def run_cascade_parity(kf=None, threads=None, device="cuda:0", n_sessions=3):
+def run_cascade_parity(kf=None, threads=None, device="cuda:0", n_sessions=3, lanes=2):
     """configs[2]: the device cascade (lt-mapper_amd/cascade.py) against the oracle chain in which every link re-loads scans_updated like the
     reference (per-scan pcl::VoxelGrid, Session.cpp:284-289, then precleaningKeyframes(2.5), Removerter.cpp:1658-1660)"""
     import numpy as np
@@ -82,7 +82,8 @@ def run_cascade_parity(kf=None, threads=None, device="cuda:0", n_sessions=3):
         loaded.append((scans, ctx.poses(S["poses"], S["inv"])))
     P = Params(gpu_use_self_removert=True, remove_resolution_list=list(res), num_nn_points_within=k, dist_nn_points_within=thr, downsample_voxel_size=voxel)
     t0 = time.perf_counter()
-    runs = run_cascade(HipOps(ctx), P, loaded[0][0], loaded[0][1], loaded[1:])
+    ops = HipOps(ctx)
+    runs = run_cascade(ops, P, loaded[0][0], loaded[0][1], loaded[1:], lane_ops=ops.lane() if lanes == 2 else None)      # the shipped schedule: two lanes
     ctx.synchronize()
     t_gpu = time.perf_counter() - t0
     cpu = []
@@ -110,16 +111,17 @@ def run_cascade_parity(kf=None, threads=None, device="cuda:0", n_sessions=3):
     except OSError:
         commit = None
     return {"what": "device cascade (C ABI, lt-mapper_amd/cascade.py) vs the CPU oracle chain, every output of every pair run compared bitwise",
-            "config": "BASELINE configs[2]", "workload": f"{scene} cascade 01 -> 02..{n_sessions:02d}, {kf} keyframes per session, {sensor}, 3-res",
+            "config": "BASELINE configs[2]", "lanes": lanes, "workload": f"{scene} cascade 01 -> 02..{n_sessions:02d}, {kf} keyframes per session, {sensor}, 3-res",
             "scan_points": [int(c["offsets"][-1]) for c in cpu], "gpu_run_s": round(t_gpu, 3), "oracle_run_s": round(t_cpu, 1), "oracle_threads": threads,
             "outputs_compared": len(report), "outputs_differing": bad, "product_sha": provenance.product_sha(), "kernels_sha": provenance.kernels_sha(),
             "oracle_sha": provenance.oracle_sha(), "commit": commit, "outputs": report}
 
 
-def run_parity(config=1, kf=None, threads=None, device="cuda:0", sessions=3):
-    """returns the report dict; report["outputs_differing"] == 0 means bitwise parity of all outputs"""
+def run_parity(config=1, kf=None, threads=None, device="cuda:0", sessions=3, lanes=2):
+    """returns the report dict; report["outputs_differing"] == 0 means bitwise parity of all outputs.  lanes = 2: the schedule the hosts ship (independent
+    chains side by side on the context and its lane, Removerter.run_two_lanes); 1: the one-lane order"""
     if config == 2:
-        return run_cascade_parity(kf, threads, device, n_sessions=sessions)
+        return run_cascade_parity(kf, threads, device, n_sessions=sessions, lanes=lanes)
     import numpy as np
     import torch
     import ltmapper_amd  # noqa: F401
@@ -142,7 +144,8 @@ def run_parity(config=1, kf=None, threads=None, device="cuda:0", sessions=3):
     P = Params(gpu_use_self_removert=three_res, remove_resolution_list=list(res), num_nn_points_within=k, dist_nn_points_within=thr,
                downsample_voxel_size=voxel)
     t0 = time.perf_counter()
-    rm = Removerter(HipOps(ctx), P, Session("Central", *loaded[0]), Session("Query", *loaded[1]))
+    ops = HipOps(ctx)
+    rm = Removerter(ops, P, Session("Central", *loaded[0]), Session("Query", *loaded[1]), lane_ops=ops.lane() if lanes == 2 else None)
     rm.run()
     ctx.synchronize()
     t_gpu = time.perf_counter() - t0
@@ -178,7 +181,7 @@ def run_parity(config=1, kf=None, threads=None, device="cuda:0", sessions=3):
     except OSError:
         commit = None
     return {"what": "GPU (C ABI) vs CPU oracle, every output of Removerter::run() compared bitwise",
-            "config": f"BASELINE configs[{3 if config == 33 else config}]", "workload": f"{scene} 2x{kf} {sensor} {'3-res' if three_res else 'single-res'} voxel {voxel} k {k} thr {thr}",
+            "config": f"BASELINE configs[{3 if config == 33 else config}]", "lanes": lanes, "workload": f"{scene} 2x{kf} {sensor} {'3-res' if three_res else 'single-res'} voxel {voxel} k {k} thr {thr}",
             "scan_points": [int(c["offsets"][-1]) for c in cpu], "gpu_run_s": round(t_gpu, 3), "oracle_run_s": round(t_cpu, 1),
             "oracle_threads": threads, "outputs_compared": len(report), "outputs_differing": bad,
             "product_sha": provenance.product_sha(), "kernels_sha": provenance.kernels_sha(), "oracle_sha": provenance.oracle_sha(), "commit": commit,

@@ -5,7 +5,7 @@ cd /tmp && export TMPDIR=/tmp
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_INSTS_SALU" \
            "SQ_WAVE_CYCLES SQ_ACTIVE_INST_LDS SQ_INSTS_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_VMEM_RD SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_WAVES"; do
   rm -rf /tmp/pmc_sq
-  rocprofv3 --pmc $SET --output-format csv -d /tmp/pmc_sq -- python $ROOT/bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-t-total > /tmp/pmc_sq.log 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d /tmp/pmc_sq -- python $ROOT/bench.py --steps 1 --warmup 0 --lanes 1 --no-cpu-baseline --no-t-total > /tmp/pmc_sq.log 2>&1
   f=$(find /tmp/pmc_sq -name "*counter_collection.csv" | head -1)
   python3 - "$f" <<'PY'
 import csv, sys, collections
