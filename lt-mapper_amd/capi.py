@@ -419,13 +419,10 @@ class Context:
         voxel_grid_scanset_end(ticket).  Work submitted in between runs beside the transfer and the host sort."""
         t = C.c_void_p()
         self._ck(self.lib.ltm_voxel_grid_scanset_begin(self.h, scans.h, leaf, C.byref(t)))
-        return (t, scans)
+        return VgsTicket(self, t, scans)
 
     def voxel_grid_scanset_end(self, ticket):
-        t, _scans = ticket
-        out = _u64()
-        self._ck(self.lib.ltm_voxel_grid_scanset_end(self.h, t, C.byref(out)))
-        return ScanSet(self, out.value)
+        return ticket.end()
 
     def prepare_scan_images(self, scans, alphas, kf_begin=0, kf_end=None):
         """scan range images of all the listed resolutions in one pass over the scans (kept for the votes that follow)"""
@@ -551,6 +548,30 @@ class Context:
         nb_c = (C.c_double * cap)()
         self._ck(min(self.lib.ltm_profile_read_compulsory(self.h, nb_c, cap), 0))
         return {names[i].decode(): dict(ms=ms[i], launches=int(launches[i]), units=units[i], bytes=nbytes[i], bytes_c=nb_c[i]) for i in range(min(n, cap))}
+
+
+class VgsTicket:
+    """an open ltm_voxel_grid_scanset_begin: end() finishes the grid; a ticket dropped without it (an exception between the halves) is ended and its result
+    freed when the object goes (and ltm_destroy joins whatever is still open), so the coordinator thread never outlives its buffers"""
+
+    def __init__(self, ctx, t, scans):
+        self.ctx, self.t, self.scans = ctx, t, scans
+
+    def end(self):
+        t, self.t = self.t, None
+        if t is None:
+            raise LtmError(-1, "the ticket was ended already")
+        out = _u64()
+        self.ctx._ck(self.ctx.lib.ltm_voxel_grid_scanset_end(self.ctx.h, t, C.byref(out)))
+        self.scans = None
+        return ScanSet(self.ctx, out.value)
+
+    def __del__(self):
+        try:
+            if self.t is not None and self.ctx.h:
+                self.end().free()
+        except Exception:
+            pass
 
 
 class Event:

@@ -294,6 +294,7 @@ void ltm_destroy(ltm_ctx* c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     (void)hipStreamSynchronize(c->stream);
+    vgs_release_all(c);      // before the pinned blocks and the pool go: a coordinator thread of an abandoned ticket reads and writes them
     for (Pending& p : c->pending) { (void)hipEventDestroy(p.a); (void)hipEventDestroy(p.b); }
     for (hipEvent_t e : c->event_pool) (void)hipEventDestroy(e);
     if (c->copy_stream) { (void)hipStreamSynchronize(c->copy_stream); (void)hipStreamDestroy(c->copy_stream); }

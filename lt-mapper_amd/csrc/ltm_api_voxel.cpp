@@ -591,12 +591,20 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
     LTM_REQUIRE(ticket, "null argument");
     LTM_REQUIRE(leaf > 0.0f, "leaf size must be positive");
     const ScanSet& s = get_ss(c, hin);
-    std::unique_ptr<ltm_vgs> v(new ltm_vgs);
+    // every way out of this function before the ticket is handed over goes through ONE cleanup: the copy stream drained (a transfer may still read the
+    // keys), the coordinator joined, pinned buffers and the event released
+    struct Guard {
+        ltm_ctx* c; ltm_vgs* p;
+        ~Guard() { if (p) { if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream); vgs_release(c, p); } }
+        ltm_vgs* operator->() const { return p; }
+        ltm_vgs* get() const { return p; }
+        ltm_vgs* release() { ltm_vgs* r = p; p = nullptr; return r; }
+    } v{c, new ltm_vgs};
     v->in = hin; v->leaf = leaf; v->nk = s.nkf(); v->n = s.n_pts;
     v->t_begin = v->t_sorted = std::chrono::steady_clock::now();
     const size_t nk = v->nk, n = v->n;
     LTM_REQUIRE(n < 0xffffffffull, "scan set too large for 32-bit point indices");
-    if (n == 0 || nk == 0) { v->trivial = true; *ticket = v.release(); return; }
+    if (n == 0 || nk == 0) { v->trivial = true; c->vgs_open.push_back(v.get()); *ticket = v.release(); return; }
     ProfScope ps(c, "voxel_grid_scanset", (double)n, 64.0 * n);
     DevBuf bb(c, nk * 6 * sizeof(uint32_t));
     LTM_HIP(bbox_reduce_seg(s.d, s.off_dev, nk, n, bb.as<uint32_t>(), c->stream));
@@ -658,7 +666,7 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
         if (e == hipSuccess) e = hipEventCreateWithFlags(&v->ev_keys, hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventRecord(v->ev_keys, copy_stream(c));
         (void)hipEventDestroy(made);
-        if (e != hipSuccess) { ltm_vgs* raw = v.release(); (void)hipStreamSynchronize(copy_stream(c)); vgs_release(c, raw); LTM_HIP(e); }
+        LTM_HIP(e);
         const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
         const bool use_std_sort = std_env && atoi(std_env) != 0;
         // one keyframe per task.  A scans_updated set of 500 keyframes x 107-134 k points is ~1 s of host CPU time with ltm_pclsort (2.5 s
@@ -696,6 +704,7 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
             vp->t_sorted = std::chrono::steady_clock::now();
         });
     }
+    c->vgs_open.push_back(v.get());      // the context joins and releases whatever is still open when it is destroyed
     *ticket = v.release();
 }
 void vgs_end(ltm_ctx* c, ltm_vgs* v, ltm_scanset* out)
@@ -708,6 +717,7 @@ void vgs_end(ltm_ctx* c, ltm_vgs* v, ltm_scanset* out)
     LTM_REQUIRE(s.nkf() == nk && s.n_pts == n, "the scan set changed between begin and end");
     auto ms = [](std::chrono::steady_clock::time_point a, std::chrono::steady_clock::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     DevBuf keys2(c, n * 8), idx2(c, n * 4);
+    ProfScope ps(c, "voxel_grid_scanset", 0.0, 0.0, -1.0, false);      // the second half of the launch counted by _begin: order upload / sort, gather, segments, centroids
     if (v->pcl_order) {
         const auto t_wait = std::chrono::steady_clock::now();
         v->coordinator.join();
@@ -725,7 +735,6 @@ void vgs_end(ltm_ctx* c, ltm_vgs* v, ltm_scanset* out)
         DevBuf stemp(c, stb);
         LTM_HIP(sort_pairs_u64(v->keys->as<uint64_t>(), keys2.as<uint64_t>(), v->idx->as<uint32_t>(), idx2.as<uint32_t>(), n, 32 + v->kf_bits, stemp.p, stb, c->stream));
     }
-    ProfScope ps(c, "voxel_grid_scanset", 0.0, 0.0);
     DevBuf heads(c, n), pos(c, n * 4);
     LTM_HIP(head_flags(keys2.as<uint64_t>(), n, heads.as<uint8_t>(), c->stream));
     const size_t tb = scan_temp_bytes(n);
@@ -756,7 +765,12 @@ int ltm_voxel_grid_scanset_end(ltm_ctx* c, ltm_vgs* ticket, ltm_scanset* out)
 {
     if (!ticket) return LTM_E_INVALID;
     const int rc = guarded(c, [&] { vgs_end(c, ticket, out); });
-    if (c) { (void)hipStreamSynchronize(c->stream); vgs_release(c, ticket); }      // the ticket is consumed either way (its buffers may still be read by queued work)
+    if (c) {      // the ticket is consumed either way (its buffers may still be read by queued work)
+        std::lock_guard<std::recursive_mutex> lk(c->mx);
+        (void)hipStreamSynchronize(c->stream);
+        c->vgs_open.erase(std::remove(c->vgs_open.begin(), c->vgs_open.end(), ticket), c->vgs_open.end());
+        vgs_release(c, ticket);
+    }
     return rc;
 }
 
@@ -792,3 +806,11 @@ int ltm_debug_voxel_stats(ltm_ctx* c, uint64_t* grids, uint64_t* identity_hits, 
 }
 
 } // extern "C"
+
+void ltm_detail::vgs_release_all(ltm_ctx* c)      // ltm_destroy: tickets nobody ended (an exception between _begin and _end on the host side)
+{
+    if (c->copy_stream) (void)hipStreamSynchronize(c->copy_stream);
+    for (ltm_vgs* t : c->vgs_open) vgs_release(c, t);
+    c->vgs_open.clear();
+}
+

@@ -327,6 +327,7 @@ struct ltm_ctx {
     hipStream_t copy_stream = nullptr;
     std::vector<PinnedBlock> pinned;
     std::unordered_map<uint64_t, UploadState> uploads;
+    std::vector<struct ltm_vgs*> vgs_open;      // ltm_voxel_grid_scanset_begin tickets not ended yet: joined and released by ltm_destroy at the latest
 };
 
 namespace ltm_detail {
@@ -354,11 +355,11 @@ inline hipEvent_t get_event(ltm_ctx* c)
 }
 struct ProfScope {   // HIP-event bracket around one kernel class on the context's stream
     ltm_ctx* c; int cls = -1; hipEvent_t a = nullptr;
-    ProfScope(ltm_ctx* c_, const char* name, double units, double bytes, double bytes_c = -1.0) : c(c_)
+    ProfScope(ltm_ctx* c_, const char* name, double units, double bytes, double bytes_c = -1.0, bool count_launch = true) : c(c_)
     {
         if (!c->prof_on) return;
         cls = prof_class(c, name);
-        c->prof[cls].launches++; c->prof[cls].units += units; c->prof[cls].bytes += bytes; c->prof[cls].bytes_c += bytes_c < 0.0 ? bytes : bytes_c;
+        if (count_launch) c->prof[cls].launches++; c->prof[cls].units += units; c->prof[cls].bytes += bytes; c->prof[cls].bytes_c += bytes_c < 0.0 ? bytes : bytes_c;
         a = get_event(c);
         LTM_HIP(hipEventRecord(a, c->stream));
     }
@@ -643,6 +644,7 @@ size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, siz
 void scan_cache_drop(ltm_ctx* c, uint64_t ss_handle);                             // ltm_api_vote.cpp
 void do_partition(ltm_ctx* c, const Cloud& map, const uint8_t* labels, ltm_cloud* kept, ltm_cloud* flagged);   // ltm_api_vote.cpp
 void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3]);  // ltm_api_voxel.cpp
+void vgs_release_all(ltm_ctx* c);                                                 // ltm_api_voxel.cpp: open ltm_voxel_grid_scanset tickets, at ltm_destroy
 void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n, const std::vector<uint64_t>& bounds, const uint64_t* offsets_dev,
                    size_t kf0, uint64_t first, float4** d_set, std::vector<uint64_t>* off_set, float4** d_unset, std::vector<uint64_t>* off_unset);   // ltm_api_knn.cpp
 

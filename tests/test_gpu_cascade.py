@@ -57,6 +57,32 @@ def test_voxel_grid_scanset_matches_pcl_voxelgrid_restatement(gpu_ctx, orc):
     assert order_dependent > 0, "the data must contain leaves whose float sum depends on the order (otherwise this test cannot tell the two orders apart)"
 
 
+def test_abandoned_voxel_grid_tickets_are_released(ltm, orc):
+    """ltm_voxel_grid_scanset_begin without its _end (an exception on the host between the halves): a dropped Python ticket ends itself, and a
+    context destroyed with a ticket still open joins the coordinator thread and releases its pinned buffers -- in both cases the context keeps
+    working / closes cleanly, and an ended ticket cannot be ended twice"""
+    import gc
+    rng = np.random.default_rng(5)
+    kfs = [np.c_[rng.normal(0, 0.5, (20000, 3)), rng.uniform(0, 255, 20000)].astype(np.float32) for _ in range(3)]
+    off = np.cumsum([0] + [len(k) for k in kfs]).astype(np.uint64)
+    ctx = ltm.Context(vfov=50.0, hfov=360.0, device=0)
+    scans = ctx.upload_scans(np.concatenate(kfs), off)
+    t = ctx.voxel_grid_scanset_begin(scans, 0.05)
+    del t
+    gc.collect()                                                    # the finalizer ends the ticket and frees its result
+    t = ctx.voxel_grid_scanset_begin(scans, 0.05)
+    got = ctx.voxel_grid_scanset_end(t)
+    with pytest.raises(ltm.LtmError):
+        t.end()
+    g_pts, g_off = got.download()
+    for k, pts in enumerate(kfs):
+        assert_clouds_equal(g_pts[int(g_off[k]):int(g_off[k + 1])], orc.voxel_grid(pts, 0.05), f"keyframe {k} after an abandoned ticket")
+    t = ctx.voxel_grid_scanset_begin(scans, 0.05)
+    raw, t.t = t.t, None                                            # the host forgets the ticket altogether: ltm_destroy must release it
+    ctx.close()
+    assert raw is not None
+
+
 def _roi(central_poses, query_poses):
     """Session::parseKeyframesInROI (Session.cpp:230-263): query keyframes within 10 m of any central pose"""
     c = central_poses.reshape(-1, 4, 4)[:, :3, 3]
