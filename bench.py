@@ -477,7 +477,12 @@ def slim_line(full, extra_path):
         o["sample"] = str(cb.get("sample_short") or cb.get("sample") or "")[:200]
         ac = cb.get("all_cores")
         if isinstance(ac, dict):
-            o["all_cores"] = _num(ac, "value", "cores", "cgroup_cpu_quota_cpus", "measured_s")
+            o["all_cores"] = _num(ac, "value", "cores", "cgroup_cpu_quota_cpus", "measured_s", "not_quoted")
+            if ac.get("quoted_from"):      # a number carried over from a file is labelled as such in the line itself
+                o["all_cores"]["quoted_from"] = str(ac["quoted_from"]).split(" ")[0]
+                o["all_cores"]["measured_now"] = False
+            elif ac.get("value") is not None:
+                o["all_cores"]["measured_now"] = True
         rc = cb.get("reference_compiled")
         if isinstance(rc, dict) and "port_speedup_over_reference_compiled" in rc:
             o["port_speedup_over_reference_compiled"] = rc["port_speedup_over_reference_compiled"]

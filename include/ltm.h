@@ -220,7 +220,7 @@ int ltm_voxel_centroid_scanset(ltm_ctx*, ltm_scanset in, float leaf, ltm_scanset
  * would exceed INT32_MAX cells is returned unchanged (PCL's "leaf size is too small" early-out -- the common case for a raw 0.05 m
  * scan).  The float sums of a leaf run in the order PCL's std::sort on the leaf index leaves its points in (the permutation
  * is computed on host threads, one keyframe per task, by a restatement of libstdc++'s introsort that makes the same element moves without
- * the branch mispredictions -- csrc/ltm_pclsort.h, checked against std::sort itself; LTM_VOXELGRID_STDSORT=1 calls std::sort; bit-identical to
+ * the branch mispredictions -- csrc/ltm_pclsort.h, checked against std::sort itself; bit-identical to
  * the reference's sources compiled against stand-in PCL headers, oracle/_ref -- PCL itself is not available, so "as PCL 1.10 is understood to do it").  LTM_VOXELGRID_ORDER=input sums in input
  * order entirely on the device: faster, but the last bit of a centroid of three or more points may differ.  This is what makes a device-resident cascade hand over the scans the reference would
  * re-load from scans_updated/ (README.md:115-118; Removerter.cpp:1658-1660). */

@@ -243,9 +243,6 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
     auto env_int = [](const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; };
     c->kopts.map_kernel_variant = env_int("LTM_MAP_KERNEL", 2);
     c->kopts.vote_cull = env_int("LTM_VOTE_CULL", 1);
-    c->kopts.cull_variant = env_int("LTM_CULL_VARIANT", 0);
-    c->kopts.kf_per_block = env_int("LTM_KF_PER_BLOCK", 8);
-    c->kopts.bm_stop = env_int("LTM_BM_STOP", 0);
     c->kopts.tile_cull = env_int("LTM_TILE_CULL", 1);
     c->kopts.stats_blockmin = env_int("LTM_STATS_BLOCKMIN", 0);
     // Exhaustive (2^32 inputs, a few ms) device check of the fast rad2deg / divide-by-FOV forms for THIS context's
@@ -260,28 +257,23 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (!ok) { (void)hipStreamDestroy(c->stream); delete c; return LTM_E_DEVICE; }
         c->fast_math = (c->selfcheck[0] == 0 && c->selfcheck[1] == 0 && c->selfcheck[2] == 0) ? 1 : 0;
         if (const char* v = getenv("LTM_FAST_MATH")) c->fast_math = c->fast_math && atoi(v);
-        if (const char* v = getenv("LTM_VOXEL_PACKED")) c->voxel_packed_sort = atoi(v);
         if (const char* v = getenv("LTM_KNN_FAST")) c->knn_two_phase = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_KEYBITS")) c->voxel_key_compress = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_FUSED_TAIL")) c->voxel_fused_tail = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_IDENTITY")) c->voxel_identity = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION")) c->occlusion_cull = atoi(v);
-        if (const char* v = getenv("LTM_OCCLUSION_SUBTILE")) c->occlusion_subtile = atoi(v);
         if (getenv("LTM_OCCLUSION_STATS")) c->occlusion_stats_on = 1;
         if (const char* v = getenv("LTM_OCCLUSION_MIN_PAIRS")) c->occlusion_min_pairs = (size_t)atoll(v);
-        if (const char* v = getenv("LTM_OCCLUSION_INCREMENTAL")) c->occlusion_incremental = atoi(v);
         if (const char* v = getenv("LTM_OCCLUSION_RNEAR")) {      // a non-positive first shell would select no pair in any shell; NaN / inf fall back to the default
             const float r = (float)atof(v);
             c->occlusion_r_near = std::isfinite(r) ? std::max(1.0f, r) : 60.0f;
         }
         if (const char* v = getenv("LTM_KNN_STATS")) c->knn_stats_on = atoi(v);
-        if (const char* v = getenv("LTM_KNN_SORT_QUEUE")) c->knn_sort_queue = atoi(v);
         if (const char* v = getenv("LTM_CULL_SELFCHECK")) c->cull_selfcheck = atoi(v);
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
         c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
         if (const char* v = getenv("LTM_HEAVY_CHAIN")) c->heavy_chain_on = atoi(v);
-        if (const char* v = getenv("LTM_HEAVY_PRIORITY")) c->heavy_priority_on = atoi(v);
         if (const char* v = getenv("LTM_HEAVY_MIN_BLOCKS")) c->heavy_min_blocks = (size_t)atoll(v);
     }
     c->heavy = std::make_shared<HeavyChain>();
@@ -316,7 +308,6 @@ void ltm_destroy(ltm_ctx* c)
         fprintf(stderr, "[ltm] device pool: %zu hipMalloc calls, %.1f MB held, %.1f ms inside hipMalloc; pinned host blocks: %zu, %.1f MB, %.1f ms inside hipHostMalloc\n",
                 c->pool.n_malloc, c->pool.bytes_total / 1048576.0, 1e3 * c->pool.malloc_s, c->pinned.size(), c->pinned_bytes / 1048576.0, 1e3 * c->pinned_s);
     c->pool.release_all();
-    if (c->heavy_stream) { (void)hipStreamSynchronize(c->heavy_stream); (void)hipStreamDestroy(c->heavy_stream); }
     (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1017,22 +1008,16 @@ int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
         c->l2b_identity = parent->l2b_identity; c->b2l_identity = parent->b2l_identity; c->kf_batch = parent->kf_batch; c->kopts = parent->kopts;
         c->fast_math = parent->fast_math;      // the exhaustive create-time self-check is a property of (device, vfov, hfov): not repeated
         for (int i = 0; i < 3; ++i) c->selfcheck[i] = parent->selfcheck[i];
-        c->scan_cache_cap = parent->scan_cache_cap; c->voxel_packed_sort = parent->voxel_packed_sort; c->occlusion_cull = parent->occlusion_cull;
-        c->occlusion_min_pairs = parent->occlusion_min_pairs; c->occlusion_r_near = parent->occlusion_r_near; c->occlusion_incremental = parent->occlusion_incremental;
+        c->scan_cache_cap = parent->scan_cache_cap; c->occlusion_cull = parent->occlusion_cull;
+        c->occlusion_min_pairs = parent->occlusion_min_pairs; c->occlusion_r_near = parent->occlusion_r_near;
         c->occlusion_subtile = parent->occlusion_subtile; c->occlusion_stats_on = parent->occlusion_stats_on;
         c->voxel_key_compress = parent->voxel_key_compress; c->voxel_fused_tail = parent->voxel_fused_tail; c->voxel_identity = parent->voxel_identity;
-        c->knn_two_phase = parent->knn_two_phase; c->knn_sort_queue = parent->knn_sort_queue; c->knn_stats_on = parent->knn_stats_on;
+        c->knn_two_phase = parent->knn_two_phase; c->knn_stats_on = parent->knn_stats_on;
         c->cull_eps_scale = parent->cull_eps_scale; c->cull_eps_floor = parent->cull_eps_floor;
         c->cull_selfcheck = parent->cull_selfcheck; c->cull_geom_ok = parent->cull_geom_ok;      // shapes the parent has checked already (same device, field of view, extrinsic)
         c->el_fit = parent->el_fit; for (int i = 0; i < 4; ++i) c->el_c[i] = parent->el_c[i]; c->el_fit_err = parent->el_fit_err;
     }
-    int prio_least = 0, prio_greatest = 0;
-    bool prio = false;
-    { std::lock_guard<std::recursive_mutex> lk(parent->mx); prio = parent->heavy_priority_on != 0; }
-    if (hipSetDevice(c->device) != hipSuccess || hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest) != hipSuccess ||
-        hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
-        (prio && hipStreamCreateWithPriority(&c->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess)) {
-        if (c->stream) (void)hipStreamDestroy(c->stream);
+    if (hipSetDevice(c->device) != hipSuccess || hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) {
         delete c;
         return LTM_E_DEVICE;
     }
@@ -1040,13 +1025,7 @@ int ltm_lane_create(ltm_ctx* parent, ltm_ctx** out)
     {      // the parent joins the family: from now on its heavy launches are chained with the lane's
         std::lock_guard<std::recursive_mutex> lk(parent->mx);
         c->heavy = parent->heavy;
-        c->heavy_chain_on = parent->heavy_chain_on; c->heavy_priority_on = parent->heavy_priority_on; c->heavy_min_blocks = parent->heavy_min_blocks;
-        if (prio && !parent->heavy_stream && hipStreamCreateWithPriority(&parent->heavy_stream, hipStreamNonBlocking, prio_least) != hipSuccess) {
-            parent->heavy_stream = nullptr;
-            (void)hipStreamDestroy(c->heavy_stream); (void)hipStreamDestroy(c->stream);
-            delete c;
-            return LTM_E_DEVICE;
-        }
+        c->heavy_chain_on = parent->heavy_chain_on; c->heavy_min_blocks = parent->heavy_min_blocks;
         c->in_lane_family = parent->in_lane_family = true;
     }
     *out = c;

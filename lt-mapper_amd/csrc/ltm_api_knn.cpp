@@ -149,7 +149,7 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
                                            index.n_buckets, k, thr, flag.as<uint8_t>(), local.as<float4>(), c->stream));
             }
             unsigned ibits = 0;
-            const unsigned kbits = c->knn_sort_queue ? knn_sorted_queue_bits(index.g, n, &ibits) : 0u;
+            const unsigned kbits = knn_sorted_queue_bits(index.g, n, &ibits);      // 0: the keys do not fit, phase 2 walks the queue in scan order
             if (kbits) {
                 // phase 2 on a queue sorted by cell (round 4): one host round trip for the undecided count (four kNN stages per step)
                 DevBuf pos(c, n * 4), count(c, 4);

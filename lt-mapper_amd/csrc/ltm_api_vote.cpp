@@ -218,7 +218,7 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     uint32_t* list = reinterpret_cast<uint32_t*>(carve(n_pairs * 4));
     uint32_t* count = reinterpret_cast<uint32_t*>(carve(64));
     uint32_t* cmax = reinterpret_cast<uint32_t*>(carve(nb * rbs * cbs * 4));
-    uint32_t* dirty = c->occlusion_incremental ? reinterpret_cast<uint32_t*>(carve(nb * dwords * 4)) : nullptr;
+    uint32_t* dirty = reinterpret_cast<uint32_t*>(carve(nb * dwords * 4));
     void* temp = carve(tbytes);
     float* tbq = subtiles ? reinterpret_cast<float*>(carve(n_tiles * 96)) : nullptr;
     uint8_t* submask = subtiles ? reinterpret_cast<uint8_t*>(carve(n_pairs)) : nullptr;

@@ -146,8 +146,8 @@ size_t voxel_centroid_raw(ltm_ctx* c, const float4* pts, size_t n_in, float leaf
     while (ib < 32 && ((size_t)1 << ib) < n_in) ++ib;
     // packed (code << index bits | index in one word, keys-only sort) whenever the COMPRESSED code fits beside the index: a 45 M-point
     // street map (depth 13, 26 index bits) misses 64 bits by one with the full code and fits easily without the undecidable bits
-    const KeyCompress kc = key_compress_for(mn, mx, f, c->voxel_packed_sort && c->voxel_key_compress);
-    const bool packed = c->voxel_packed_sort && kc.bits + ib <= 64;
+    const KeyCompress kc = key_compress_for(mn, mx, f, c->voxel_key_compress != 0);
+    const bool packed = kc.bits + ib <= 64;
     const unsigned mbits = packed ? kc.bits : 3 * f.depth;        // code bits the sort has to look at
     const unsigned kshift = packed ? ib : 0;                       // Morton code = key >> kshift
     size_t n = n_in;
@@ -271,8 +271,8 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
             continue;
         }
         while (j.ib < 32 && ((size_t)1 << j.ib) < j.n) ++j.ib;
-        const KeyCompress kc = key_compress_for(mn, mx, j.f, c->voxel_packed_sort && c->voxel_key_compress);
-        j.packed = c->voxel_packed_sort && kc.bits + j.ib <= 64;
+        const KeyCompress kc = key_compress_for(mn, mx, j.f, c->voxel_key_compress != 0);
+        j.packed = kc.bits + j.ib <= 64;
         j.mbits = j.packed ? kc.bits : 3 * j.f.depth;
         j.kshift = j.packed ? j.ib : 0;
         const size_t n = j.n;
@@ -295,10 +295,6 @@ void voxel_centroid_batch_impl(ltm_ctx* c, std::vector<VoxelJob>& jobs)
     }
     std::vector<uint32_t> nv(nj);
     d2h(c, nv.data(), counts.p, nj * 4);
-    if (getenv("LTM_VOXEL_LOG"))
-        for (size_t k = 0; k < nj; ++k)
-            fprintf(stderr, "[ltm] voxel batch %zu/%zu: n %zu -> %u voxels, leaf %.3f, depth %u, code bits sorted %u, index bits %u, packed %d\n", k, nj, jobs[k].n, nv[k],
-                    jobs[k].leaf, jobs[k].f.depth, jobs[k].mbits, jobs[k].ib, (int)jobs[k].packed);
     // phase C: centroids
     for (size_t k = 0; k < nj; ++k) {
         VoxelJob& j = jobs[k];
@@ -652,7 +648,7 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
         // The pinned buffer receives the 64-bit keys (keyframe id << 32 | leaf index) and is read as the (leaf index, point index) pairs PCL
         // sorts: on this little-endian host a key's low word IS the pair's first member, and the high word -- the keyframe id, which the
         // keyframe-by-keyframe sort does not need -- is overwritten with the point index.  ltm_pclsort::sort performs std::sort's element moves
-        // without its branch mispredictions (ltm_pclsort.h: checked against std::sort itself); LTM_VOXELGRID_STDSORT=1 calls std::sort.
+        // without its branch mispredictions (ltm_pclsort.h: checked against std::sort itself).
         using Entry = ltm_pclsort::Entry;
         static_assert(sizeof(Entry) == sizeof(uint64_t) && offsetof(Entry, idx) == 0 && offsetof(Entry, cloud_point_index) == 4, "a pair overlays a key");
         v->he = static_cast<Entry*>(pinned_alloc(c, n * 8));
@@ -667,8 +663,6 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
         if (e == hipSuccess) e = hipEventRecord(v->ev_keys, copy_stream(c));
         (void)hipEventDestroy(made);
         LTM_HIP(e);
-        const char* std_env = getenv("LTM_VOXELGRID_STDSORT");
-        const bool use_std_sort = std_env && atoi(std_env) != 0;
         // one keyframe per task.  A scans_updated set of 500 keyframes x 107-134 k points is ~1 s of host CPU time with ltm_pclsort (2.5 s
         // with std::sort): 20 ms on 64 threads of the GPU box (profiles/r4_hostsort_pclsort_vs_stdsort.txt); LTM_VOXELGRID_THREADS
         // overrides the cap of 64
@@ -679,7 +673,7 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
         ltm_vgs* vp = v.get();
         const ScanSet* sp = &s;          // (the input scan set stays alive until the ticket is ended: the caller's contract)
         const int device = c->device;
-        vp->coordinator = std::thread([vp, sp, nt, use_std_sort, device] {
+        vp->coordinator = std::thread([vp, sp, nt, device] {
             // the only wait of the whole order: for the keys.  One thread waits; the workers never touch the runtime
             if (hipSetDevice(device) != hipSuccess || hipEventSynchronize(vp->ev_keys) != hipSuccess) { vp->failed = true; return; }
             std::atomic<size_t> next{0};
@@ -691,8 +685,7 @@ void vgs_begin(ltm_ctx* c, ltm_scanset hin, float leaf, ltm_vgs** ticket)
                     Entry* he = vp->he; uint32_t* hi = vp->hi;
                     if (vp->frames[k].passthrough) { for (size_t i = a; i < b; ++i) hi[i] = (uint32_t)i; continue; }
                     for (size_t i = a; i < b; ++i) he[i].cloud_point_index = (uint32_t)i;
-                    if (use_std_sort) std::sort(he + a, he + b, ltm_pclsort::Less());
-                    else ltm_pclsort::sort(he + a, he + b);
+                    ltm_pclsort::sort(he + a, he + b);
                     for (size_t i = a; i < b; ++i) hi[i] = he[i].cloud_point_index;
                 }
             };

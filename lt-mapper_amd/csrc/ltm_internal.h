@@ -257,14 +257,13 @@ struct ltm_ctx {
     ltm_config cfg;
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t heavy_stream = nullptr;          // LTM_HEAVY_PRIORITY=1 only: lowest priority, created with the first lane of the family
     bool in_lane_family = false;                 // this context has lanes / is one: its heavy launches are chained with theirs
     std::shared_ptr<HeavyChain> heavy;           // shared by a context and its lanes
-    // LTM_HEAVY_CHAIN=0: no chaining (A/B).  LTM_HEAVY_PRIORITY=1: the heavy launches go to a stream of the lowest priority of their own -- off by default:
-    // it buys nothing measurable (profiles/r6_lanes_*) and every extra stream is one more hardware queue: with five queues on the four compute pipes one
-    // lane's projection stream shared a pipe with the OTHER lane's stream and held up its small launches for the length of a vote (seen with the C++ host,
+    // LTM_HEAVY_CHAIN=0: no chaining (A/B).  A lowest-priority stream of their own for the heavy launches was built, measured and removed in round 6: it
+    // bought nothing (profiles/r6_lanes_*) and every extra stream is one more hardware queue: with five queues on the four compute pipes one lane's
+    // projection stream shared a pipe with the OTHER lane's stream and held up its small launches for the length of a vote (seen with the C++ host,
     // whose loader had created a copy stream first: 170 instead of 157 ms per step)
-    int heavy_chain_on = 1, heavy_priority_on = 0;
+    int heavy_chain_on = 1;
     size_t heavy_min_blocks = 100000;            // LTM_HEAVY_MIN_BLOCKS: launches below this many workgroups (revert passes on the small dynamic map, ND / PD filters) run unchained
     HostMat34 L2B, B2L;
     int l2b_identity = 1, b2l_identity = 1;
@@ -292,12 +291,10 @@ struct ltm_ctx {
     std::vector<ScanImgEntry> scan_cache;
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
-    int voxel_packed_sort = 1;                  // LTM_VOXEL_PACKED=0: key/index pair sort (A/B switch)
     int occlusion_cull = 1;                     // LTM_OCCLUSION=0: the exact-image kernel runs every (tile, keyframe) pair (A/B switch)
     size_t occlusion_min_pairs = (size_t)1 << 21;   // LTM_OCCLUSION_MIN_PAIRS: smaller launches are not worth the two extra passes (2 M pairs = 4096 tiles x 512 keyframes)
     float occlusion_r_near = 60.0f;             // LTM_OCCLUSION_RNEAR [m]: tiles nearer than this are projected first and serve as occluders
-    int occlusion_incremental = 1;              // LTM_OCCLUSION_INCREMENTAL=0: the coarse maximum is re-reduced over every image row before every shell (A/B switch)
-    int occlusion_subtile = 1;                  // LTM_OCCLUSION_SUBTILE=0: the cull looks at whole 4096-point tiles only (round 5's form, A/B switch)
+    int occlusion_subtile = 1;                  // 0: the cull looks at whole 4096-point tiles only (round 5's form; the A/B is profiles/r6_ab_occlusion_second_look_at_tile_quarters.txt)
     int occlusion_stats_on = 0;                 // LTM_OCCLUSION_STATS: also count the quarters of live pairs and those left alive (one more host round trip per batch)
     uint64_t occl_quarters = 0, occl_quarters_live = 0;
     uint64_t occl_pairs = 0, occl_near = 0, occl_far_live = 0;      // statistics (LTM_OCCLUSION_STATS): pairs seen, in the first shell, projected in all
@@ -307,7 +304,6 @@ struct ltm_ctx {
     int voxel_identity = 1;                     // LTM_VOXEL_IDENTITY=0: never take the "already gridded under this frame" shortcut (A/B switch)
     uint64_t voxel_identity_hits = 0, voxel_calls = 0;
     int knn_two_phase = 1;                      // LTM_KNN_FAST=0: the one-kernel exact search for every query (A/B switch)
-    int knn_sort_queue = 1;                     // LTM_KNN_SORT_QUEUE=0: phase 2 walks the undecided queries in scan order instead of sorted by cell (A/B switch)
     int knn_stats_on = 0;                       // LTM_KNN_STATS=1: count the queries phase 1 leaves undecided (one host round trip per call)
     uint64_t knn_undecided = 0, knn_queries = 0;
     // The culled kernels rest on error bounds of the bounded-error projection that were validated empirically (tools/eps_sweep.py, ltm_debug_cull_check in the
@@ -372,37 +368,29 @@ struct ProfScope {   // HIP-event bracket around one kernel class on the context
         c->pending.push_back(Pending{cls, a, b});
     }
 };
-// One heavy (vector-issue bound) launch of a lane family: see HeavyChain.  stream() is where the launch goes.  Without lanes (no heavy stream) this is a no-op
-// on the context's own stream.
+// One heavy (vector-issue bound) launch of a lane family: see HeavyChain.  Without lanes this is a no-op.  (A separate lowest-priority stream for these
+// launches was measured in round 6 and lost: a fifth hardware queue shares a compute pipe with the other lane's stream, NOTEBOOK §6.)
 struct HeavyScope {
-    ltm_ctx* c; bool hop = false, chained = false;
+    ltm_ctx* c; bool chained = false;
     std::unique_lock<std::mutex> turn;      // held from the wait for the predecessor until this launch has become the family's latest: two lanes that get here
                                             // together must not both queue behind the SAME predecessor (they would run side by side -- seen with the C++ host's two threads)
     HeavyScope(ltm_ctx* c_, size_t n_blocks) : c(c_)
     {
         if (!c->in_lane_family || n_blocks < c->heavy_min_blocks) return;
-        hop = c->heavy_priority_on != 0 && c->heavy_stream;
         chained = c->heavy_chain_on != 0;
-        if (hop) {
-            hipEvent_t e = get_event(c);
-            LTM_HIP(hipEventRecord(e, c->stream));
-            LTM_HIP(hipStreamWaitEvent(c->heavy_stream, e, 0));
-            c->event_pool.push_back(e);
-        }
         if (chained) {
             turn = std::unique_lock<std::mutex>(c->heavy->mx);
             if (c->heavy->last) LTM_HIP(hipStreamWaitEvent(stream(), c->heavy->last, 0));
         }
     }
-    hipStream_t stream() const { return hop ? c->heavy_stream : c->stream; }
-    void done()      // after the launch: the family's next heavy launch and this context's own stream continue behind it
+    hipStream_t stream() const { return c->stream; }
+    void done()      // after the launch: the family's next heavy launch continues behind it
     {
-        if (!hop && !chained) return;
+        if (!chained) return;
         hipEvent_t e = nullptr;
         LTM_HIP(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        hipError_t rc = hipEventRecord(e, stream());
-        if (rc == hipSuccess && hop) rc = hipStreamWaitEvent(c->stream, e, 0);
-        if (rc != hipSuccess || !chained) { (void)hipEventDestroy(e); LTM_HIP(rc); return; }
+        const hipError_t rc = hipEventRecord(e, stream());
+        if (rc != hipSuccess) { (void)hipEventDestroy(e); LTM_HIP(rc); return; }
         if (c->heavy->last) (void)hipEventDestroy(c->heavy->last);      // waits already enqueued on it keep it alive inside the runtime
         c->heavy->last = e;
         turn.unlock();

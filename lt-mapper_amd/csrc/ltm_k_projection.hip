@@ -269,6 +269,7 @@ static constexpr uint32_t kEmptyTag = 0xffffffffu;
 // only, any other placement is still correct).  Consecutive workgroups of one XCD take the SAME map tile for `kfg`
 // consecutive keyframes, so the tile (64 KB) is fetched from HBM / Infinity Cache once and served from that XCD's L2
 // for the other kfg-1 keyframes: with ~224 resident workgroups per XCD the live tile set is ~28 x 64 KB << 4 MiB of L2.
+static constexpr unsigned kKfPerTile = 8;      // keyframes that reuse one map tile on an XCD (4 / 16 measured no better in round 2)
 struct TileKf { uint32_t tile, kfb; bool valid; };
 __device__ __forceinline__ TileKf tile_kf_of_block(uint32_t b, uint32_t n_tiles, uint32_t nb, uint32_t kfg)
 {
@@ -721,10 +722,10 @@ hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_
     if (!M || !nb) return hipSuccess;
     if (mode != 0 || !ko.vote_cull || !approx_poses_dev || !qbound_img) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s, ko);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
-    const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
+    const unsigned kfg = kKfPerTile;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
     const float* tb = (ko.tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
-    const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;       // LTM_CULL_VARIANT=1: generic elevation polynomial (A/B)
+    const bool el3 = g.el_fit != 0;
 #define LTM_LAUNCH_CULL(ID, E) k_vote_map_cull<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
     if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL(false, true); else LTM_LAUNCH_CULL(false, false); }
     else { if (el3) LTM_LAUNCH_CULL(true, true); else LTM_LAUNCH_CULL(true, false); }
@@ -836,7 +837,7 @@ static constexpr int kBmUQueue = 1024;    // dense re-queue of the uncertain sur
 template <bool B2L_IDENTITY, bool EL3, int SLOT_ROWS = 16>
 __global__ void __launch_bounds__(kBlock)
 k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
-                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs, int stop_after,
+                    uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, uint64_t* __restrict__ img, const uint32_t* __restrict__ pairs, uint32_t n_pairs,
                     const uint8_t* __restrict__ submask)
 {
     constexpr int kBmSlots = SLOT_ROWS * 64;
@@ -961,8 +962,6 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
         }
     }
     __syncthreads();
-    // stop_after: DIAGNOSTIC (LTM_BM_STOP): the image is wrong then
-    if (stop_after == 1) return;
     for (int s = threadIdx.x; s < kBmSlots; s += kBlock) vals[s] = ~0ull;        // amin is dead from here on
     __syncthreads();
     // ---- phase 2: survivors.  Certain pixel: only the exact range; the others are re-queued densely and get the full exact projection
@@ -994,13 +993,11 @@ k_map_rimg_blockmin(const float4* __restrict__ map, uint32_t M, const double* __
             else img_min_u64(imgk + px, v);
         }
         __syncthreads();
-        if (stop_after == 2) return;
         const uint32_t nu = min(ucount, (uint32_t)kBmUQueue);
         for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
             exact_insert<B2L_IDENTITY, SLOT_ROWS, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
     }
     __syncthreads();
-    if (stop_after == 3) return;
     for (int s = threadIdx.x; s < kBmSlots; s += kBlock) {
         const uint32_t t = tags[s];
         if (t != kEmptyTag && vals[s] != ~0ull) img_min_u64(imgk + t, vals[s]);
@@ -1015,10 +1012,10 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
     if (!M || !nb) return hipSuccess;
     if (ko.map_kernel_variant >= 2 && approx_poses_dev) {
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
-        const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
+        const unsigned kfg = kKfPerTile;
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
-#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, ko.bm_stop, nullptr)
-        const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;
+#define LTM_LAUNCH_BM(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img, nullptr, 0u, nullptr)
+        const bool el3 = g.el_fit != 0;
         if (!b2l_identity) { if (el3) LTM_LAUNCH_BM(false, true); else LTM_LAUNCH_BM(false, false); }
         else { if (el3) LTM_LAUNCH_BM(true, true); else LTM_LAUNCH_BM(true, false); }
 #undef LTM_LAUNCH_BM
@@ -1026,7 +1023,7 @@ hipError_t map_range_images(const float4* map, size_t M, const double* inv_poses
     }
     if (ko.map_kernel_variant >= 1) {
         const size_t per_block = (size_t)kBlock * kPtsPerThread;
-        const unsigned kfg = (unsigned)(ko.kf_per_block < 1 ? 1 : (ko.kf_per_block > 64 ? 64 : ko.kf_per_block));
+        const unsigned kfg = kKfPerTile;
         dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
         if (b2l_identity) k_map_rimg_lds<true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
         else k_map_rimg_lds<false><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, map_img);
@@ -1220,8 +1217,8 @@ hipError_t map_range_images_pairs(const float4* map, size_t M, const double* inv
 {
     if (!n_pairs) return hipSuccess;
     dim3 grid((unsigned)(((n_pairs + 7) / 8) * 8));
-#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, ko.bm_stop, submask)
-    const bool el3 = g.el_fit != 0 && ko.cull_variant != 1;
+#define LTM_LAUNCH_BMP(ID, E) k_map_rimg_blockmin<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, 1u, b2l, g, map_img, pairs, (uint32_t)n_pairs, submask)
+    const bool el3 = g.el_fit != 0;
     if (!b2l_identity) { if (el3) LTM_LAUNCH_BMP(false, true); else LTM_LAUNCH_BMP(false, false); }
     else { if (el3) LTM_LAUNCH_BMP(true, true); else LTM_LAUNCH_BMP(true, false); }
 #undef LTM_LAUNCH_BMP

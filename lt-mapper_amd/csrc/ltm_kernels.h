@@ -52,9 +52,6 @@ struct KernelOpts {
     int map_kernel_variant = 2;   // LTM_MAP_KERNEL   exact arg-min image: 0 one global atomic per point, 1 LDS pre-reduction, 2 + workgroup-local arg-min pre-filter
     int vote_cull = 1;            // LTM_VOTE_CULL    1: mode-0 votes use k_vote_map_cull, 0: the exact-image kernel
     int tile_cull = 1;            // LTM_TILE_CULL    whole-tile range cull inside k_vote_map_cull
-    int cull_variant = 0;         // LTM_CULL_VARIANT 1: generic elevation polynomial even where the fitted one applies
-    int kf_per_block = 8;         // LTM_KF_PER_BLOCK keyframes that reuse one map tile on an XCD (tile_kf_of_block)
-    int bm_stop = 0;              // LTM_BM_STOP      DIAGNOSTIC: k_map_rimg_blockmin leaves after phase 1 (1) / the certain survivors (2) / before the flush (3)
     int stats_blockmin = 0;       // LTM_STATS_BLOCKMIN  ltm_debug_cull_stats reports the exact-image kernel's survivor counts instead of the vote kernel's
 };
 // transformGlobalMapToLocal + map2RangeImg: map_img[(kf-kb)*npx+px] = min (range_bits<<32 | idx)

@@ -14,7 +14,7 @@
 //     <= everything in it) and is stable, so each segment is sorted stably where the recursion ends (a branch-free rank sort);
 //   * the heap-sort fallback is the library's own std::partial_sort(first, last, last).
 // Checked against std::sort itself: tests/test_abi.py (random sizes and key ranges, duplicates, sorted / reversed / organ-pipe inputs, McIlroy's
-// adversary, which drives std::sort into the fallback) through ltm_debug_pcl_sort_order; LTM_VOXELGRID_STDSORT=1 makes the library call std::sort.
+// adversary, which drives std::sort into the fallback) through ltm_debug_pcl_sort_order.
 #pragma once
 #include <algorithm>
 #include <cstddef>

@@ -26,7 +26,8 @@ def _synthetic_full():
                          definitions=prose, algorithmic_bytes_per_launch=2.9e10, compulsory_bytes_per_launch=5.0e9),
         "cpu_baseline": {"value": 0.3314, "unit": "keyframe-pairs/s", "cores": 1, "kind": "port", "reference_compiled": {"what": prose, "port_speedup_over_reference_compiled": 1.41},
                          "sample": prose * 2, "sample_short": prose, "measured_s": 52.1, "keyframe_stride": 50, "extrapolated_step_s": 1509.0, "host_cores": 256, "cgroup_cpu_quota_cpus": 16.0,
-                         "all_cores": {"value": 2.7171, "cores": 256, "quota_note": prose * 2, "cgroup_cpu_quota_cpus": 16.0, "measured_s": 187.0},
+                         "all_cores": {"value": 2.7171, "cores": 256, "quota_note": prose * 2, "cgroup_cpu_quota_cpus": 16.0, "measured_s": 187.0,
+                                       "quoted_from": "profiles/cpu_allcore_latest.json (same oracle sources, " + prose + ")"},
                          "full_unsampled_runs_committed": {"1thread": {"cpu": prose}, "allcore": {"cpu": prose}}},
         "rooflines": rl, "traffic_groups": [{"group": prose, "classes": classes}] * 5,
         "t_total": {"what": prose, "configs[1] 2x500 3-res": {"T_total_s": 0.416, "T_step0_s": 0.189, "T_steps123_s": 0.2, "x": prose}, "cxx_host_bench": {"classes": {c: 1.0 for c in classes}}},
@@ -54,6 +55,8 @@ def test_printed_line_is_short_and_parses_from_an_8000_byte_tail():
     for k in ("value", "unit", "cores", "kind", "sample"):
         assert k in got["cpu_baseline"], k
     assert all(isinstance(v, (int, float, str, bool, type(None))) for v in got["roofline"].values())      # numbers and names, no prose objects
+    # a number that was not measured in this run says so in the printed line itself, with the file it comes from
+    assert got["cpu_baseline"]["all_cores"]["quoted_from"] == "profiles/cpu_allcore_latest.json" and got["cpu_baseline"]["all_cores"]["measured_now"] is False
 
 
 def test_the_committed_round4_record_also_slims_down():

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """A/B timing of kernel variants inside ONE process on ONE box (box-to-box differences exceed the effects being measured).
 
-    python tools/ab_kernels.py --env LTM_CULL_VARIANT=0 --env LTM_CULL_VARIANT=1 [--rounds 3] [--kf 500]
+    python tools/ab_kernels.py --env LTM_TILE_CULL=1 --env LTM_TILE_CULL=0 [--rounds 3] [--kf 500]
 
 Builds the 2x500 `lot` central session once, then for every environment setting (applied before ltm_create, which reads the
 A/B switches) runs the stages that dominate the step and prints the HIP-event time per kernel class:
