@@ -62,15 +62,13 @@ WORKLOADS = {
 }
 CASCADE_SESSIONS = {"lot-cascade-6x500": 6, "lot-cascade-4x50-small": 4}
 
-VALU_CLASSES = ("vote_map_cull", "vote_map_exact", "reproject_map", "vote_plan_build")      # projection kernels: bound by VALU issue, not HBM
-DOMINANT_KERNEL = {"vote_map_cull": "k_vote_map_cull", "vote_plan_build": "k_vote_plan_build", "vote_replay": "k_vote_replay", "vote_map_exact": "k_map_rimg_blockmin", "reproject_map": "k_map_rimg_blockmin", "knn_query": "k_knn_fast",
+VALU_CLASSES = ("vote_map_cull", "vote_map_exact", "reproject_map")      # projection kernels: bound by VALU issue, not HBM
+DOMINANT_KERNEL = {"vote_map_cull": "k_vote_map_cull", "vote_map_exact": "k_map_rimg_blockmin", "reproject_map": "k_map_rimg_blockmin", "knn_query": "k_knn_fast",
                    "knn_query_p2": "k_knn_slow_sorted", "voxel": "rocprim onesweep + k_voxel_centroids_packed", "merge": "k_transform_scans"}
 
 # kernel class (ltm_profile_read) -> kernels behind it; bytes are the algorithmic bytes of DESIGN.md section 4
 CLASS_KERNELS = {
     "vote_map_cull": "k_vote_map_cull", "vote_map_exact": "k_map_rimg_blockmin", "reproject_map": "k_map_rimg_blockmin",
-    "vote_plan_build": "k_vote_plan_build (selfRemovert's candidate lists: one bounded-error projection pass for all resolutions)",
-    "vote_replay": "k_plan_lookup + k_vote_replay + k_vote_untracked (a full-map vote served from the lists)",
     "vote_scan": "k_scan_rimg + k_image_max", "vote_compare": "k_compare_flag", "vote_fill": "k_fill_u64",
     "partition": "rocprim scan + k_partition_scatter", "voxel": "bbox + Morton keys + rocprim radix sort + k_voxel_centroids",
     "voxel_scanset": "per-keyframe bbox + composite keys + rocprim radix sort + k_voxel_centroids",
@@ -287,7 +285,6 @@ def main():
             else:
                 prof[k] = dict(v)
     cull_surv, cull_pts = ctx.cull_stats()
-    plan_stats = ctx.vote_plan_stats(reset=False)      # since ltm_create: warm-up + timed + profiling steps, this context only (the other lane keeps its own)
     vox_grids, vox_identity = ctx.voxel_stats()
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -425,7 +422,6 @@ def main():
             "voxel_grids": {"per_step": round(vox_grids / max(psteps, 1), 2), "recognised_as_identity_per_step": round(vox_identity / max(psteps, 1), 2),
                             "what": "voxel grids of clouds per step and how many of them the bounding-box pass recognised as the identity (DESIGN.md 4.2)"},
             "vote_cull": {"points_tested": cull_pts, "needed_exact_path": cull_surv, "fraction": round(cull_surv / max(cull_pts, 1), 4)},
-            "vote_plans": dict(plan_stats, what="ltm_debug_vote_plan_stats of the main context since ltm_create (all steps of this run): list builds, votes served from lists, ..."),
             "synth_generation_s": round(t_gen, 2),
         }
         extra_path = write_extra(full, args)
@@ -516,7 +512,6 @@ def kernels_sha():
 # stages share one group and the streaming rest another.
 TRAFFIC_GROUPS = [
     ("vote_map_cull", ["k_vote_map_cull"], ["vote_map_cull"]),
-    ("vote_plan (list build + replays)", ["k_vote_plan_build", "k_vote_replay", "k_vote_untracked", "k_plan_"], ["vote_plan_build", "vote_replay"]),
     ("map_rimg_blockmin", ["k_map_rimg_blockmin", "k_map_rimg_lds"], ["reproject_map", "vote_map_exact"]),
     ("knn_query", ["k_knn_query", "k_knn_fast", "k_knn_slow", "k_knn_queue"], ["knn_query", "knn_query_p2"]),
     ("sort_based (voxel grids, kNN grid build)", ["radix_sort", "merge_sort", "k_voxel", "k_morton", "k_head_flags", "k_segment_starts", "k_bbox", "k_scan_total",
@@ -529,8 +524,6 @@ TRAFFIC_GROUPS = [
 # rocPRIM's scans / sorts serve several classes and cannot be told apart by caller: classes that contain them also report the group figure
 CLASS_OWN_KERNELS = {
     "vote_map_cull": ["k_vote_map_cull"],
-    "vote_plan_build": ["k_vote_plan_build"],
-    "vote_replay": ["k_vote_replay", "k_vote_untracked", "k_plan_table_build", "k_plan_lookup", "k_plan_remap_fix"],
     # one kernel, two classes (ND votes and reprojections): its counters are split between them by their share of its event time (SHARED_KERNEL_CLASSES)
     "vote_map_exact": ["k_map_rimg_blockmin", "k_map_rimg_lds", "k_pair_shell_select", "k_coarse_max"],
     "reproject_map": ["k_map_rimg_blockmin", "k_map_rimg_lds", "k_pair_shell_select", "k_coarse_max"],

@@ -247,18 +247,6 @@ int ltm_visibility_vote(ltm_ctx*, ltm_cloud map, ltm_scanset scans, ltm_poses po
  * kept for the votes that follow (selfRemovert projects every scan at res and 0.95 res for each entry of remove_resolution_list: six image shapes whose
  * spherical coordinates are the same).  ltm_visibility_vote computes what it does not find, one shape at a time; the images are identical either way. */
 int ltm_scanset_prepare_range_images(ltm_ctx*, ltm_scanset scans, size_t kf_begin, size_t kf_end, const float* res_alphas, size_t n_alphas);
-/* Optional: announce a SEQUENCE of mode-0 votes against `scans` / `poses` at these resolutions and this threshold, of maps that derive from one another --
- * selfRemovert (Removerter.cpp:1378-1393): remove, revert, remove again at every entry of remove_resolution_list; between two of its full-map votes the map
- * only loses points (Removerter.cpp:675-687) or is re-gridded into itself (utility.cpp:204-219 on one-point-per-voxel clouds).  Whether a map point can be
- * flagged in a keyframe at a resolution depends on its coordinates, the keyframe and the finished scan image only, so the first ltm_visibility_vote /
- * ltm_visibility_partition over all keyframes that the plan covers evaluates the bounded-error projection once for ALL planned resolutions and keeps, per
- * (keyframe, resolution), the points that can matter with their exact pixel and range; the votes that follow find their map's points in that map by
- * coordinates and stream the lists (points the plan's map does not hold get the exact projection; a map that has drifted away gets new lists).  Labels are
- * identical with and without a plan (LTM_VOTE_PLAN=0 ignores plans).  At most 4 resolutions per plan; one plan per scan set, replaced by the next _begin,
- * dropped by _end, by freeing the scan set or the poses, and by ltm_clear_caches.  The lists live in device memory (configs[1]: ~5 GB per session;
- * LTM_VOTE_PLAN_BUDGET_GB, default 64, refuses plans that would need more -- their votes take the un-planned kernels). */
-int ltm_vote_plan_begin(ltm_ctx*, ltm_scanset scans, ltm_poses poses, const float* res_alphas, size_t n_alphas, float diff_thres);
-int ltm_vote_plan_end(ltm_ctx*, ltm_scanset scans);
 /* partitionCurrentMap tail (Removerter.cpp:816-824, :675-687, :933-946): index-ascending split */
 int ltm_partition_by_labels(ltm_ctx*, ltm_cloud map, const uint8_t* labels_dev, ltm_cloud* kept, ltm_cloud* flagged);
 /* vote over all keyframes + partition (single-GPU convenience).  host_labels (M bytes) may be NULL. */
@@ -354,10 +342,6 @@ int ltm_debug_cull_check(ltm_ctx*, const float* xyz, size_t n, const double* inv
  * probe points on and beside the pixel-rounding boundaries, in the sensor frame and through one keyframe pose of the call -- and a shape that leaves the
  * bounds is served by the exact kernels from then on (a line on stderr says so).  Counters since ltm_create: shapes checked / shapes that failed. */
 int ltm_debug_cull_validation(ltm_ctx*, uint64_t* shapes_checked, uint64_t* shapes_failed);
-/* counters of the planned votes since ltm_create / the last reset: out8 = {list builds, votes served from lists, untracked points handed to the exact
- * kernel, rebuilds because the voted map had drifted from the plan's, builds repeated after a record-space overflow, plans refused (budget / geometry),
- * records written, record capacity} */
-int ltm_debug_vote_plan_stats(ltm_ctx*, uint64_t* out8, int reset);
 /* diagnostic counters of the occlusion cull in front of the exact-image kernel on large maps (reprojection, ND votes) since the
  * last reset: (tile, keyframe) pairs seen by culled launches, pairs of the first distance shell, pairs projected in all (the rest was
  * proven hidden and dropped) */

@@ -96,9 +96,6 @@ SIGNATURES = {
     "ltm_voxel_grid_scanset_begin": (_i, [_vp, _u64, _f, C.POINTER(_vp)]),
     "ltm_voxel_grid_scanset_end": (_i, [_vp, _vp, _pu64]),
     "ltm_scanset_prepare_range_images": (_i, [_vp, _u64, _sz, _sz, C.POINTER(_f), _sz]),
-    "ltm_vote_plan_begin": (_i, [_vp, _u64, _u64, C.POINTER(_f), _sz, _f]),
-    "ltm_vote_plan_end": (_i, [_vp, _u64]),
-    "ltm_debug_vote_plan_stats": (_i, [_vp, C.POINTER(_u64), _i]),
     "ltm_visibility_vote": (_i, [_vp, _u64, _u64, _u64, _sz, _sz, _f, _f, _i, _vp]),
     "ltm_partition_by_labels": (_i, [_vp, _u64, _vp, _pu64, _pu64]),
     "ltm_visibility_partition": (_i, [_vp, _u64, _u64, _u64, _f, _f, _i, _pu64, _pu64, _vp]),
@@ -431,20 +428,6 @@ class Context:
         """scan range images of all the listed resolutions in one pass over the scans (kept for the votes that follow)"""
         a = (_f * len(alphas))(*[float(x) for x in alphas])
         self._ck(self.lib.ltm_scanset_prepare_range_images(self.h, scans.h, kf_begin, scans.n_kf if kf_end is None else kf_end, a, len(alphas)))
-
-    def vote_plan_begin(self, scans, poses, alphas, thr):
-        """announce selfRemovert's sequence of mode-0 votes against these scans (ltm_vote_plan_begin): labels unchanged, votes after the first stream lists"""
-        a = (_f * len(alphas))(*[float(x) for x in alphas])
-        self._ck(self.lib.ltm_vote_plan_begin(self.h, scans.h, poses.h, a, len(alphas), thr))
-
-    def vote_plan_end(self, scans):
-        self._ck(self.lib.ltm_vote_plan_end(self.h, scans.h))
-
-    def vote_plan_stats(self, reset=True):
-        out = (_u64 * 8)()
-        self._ck(self.lib.ltm_debug_vote_plan_stats(self.h, out, 1 if reset else 0))
-        keys = ("builds", "replays", "untracked_points", "rebuilds_for_untracked", "overflows", "refused", "records", "record_capacity")
-        return dict(zip(keys, [int(v) for v in out]))
 
     def visibility_vote(self, cmap, scans, poses, kf_begin, kf_end, alpha, thr, mode, labels_dev_ptr):
         self._ck(self.lib.ltm_visibility_vote(self.h, cmap.h, scans.h, poses.h, kf_begin, kf_end, alpha, thr, mode, labels_dev_ptr))

@@ -273,10 +273,6 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (const char* v = getenv("LTM_CULL_EPS_SCALE")) c->cull_eps_scale = (float)atof(v);
         if (const char* v = getenv("LTM_CULL_EPS_FLOOR")) c->cull_eps_floor = (float)atof(v);
         c->el_fit = elevation_fit_for(c->cfg.vfov, c->el_c, &c->el_fit_err);
-        if (const char* v = getenv("LTM_VOTE_PLAN")) c->vote_plan_on = atoi(v);
-        if (const char* v = getenv("LTM_VOTE_PLAN_SKIP")) c->vote_plan_skip = std::max(0, atoi(v));
-        if (const char* v = getenv("LTM_VOTE_PLAN_FRACTION")) { const double f = atof(v); if (f > 0.0) c->vote_plan_fraction = f; }
-        if (const char* v = getenv("LTM_VOTE_PLAN_BUDGET_GB")) { const double f = atof(v); if (f >= 0.0) c->vote_plan_budget = (size_t)(f * 1073741824.0); }
         if (const char* v = getenv("LTM_HEAVY_CHAIN")) c->heavy_chain_on = atoi(v);
         if (const char* v = getenv("LTM_HEAVY_MIN_BLOCKS")) c->heavy_min_blocks = (size_t)atoll(v);
     }
@@ -320,7 +316,7 @@ const char* ltm_last_error(const ltm_ctx* c) { return c ? c->err.c_str() : "null
 
 int ltm_synchronize(ltm_ctx* c) { return guarded(c, [&] { sync(c); }); }
 
-int ltm_clear_caches(ltm_ctx* c) { return guarded(c, [&] { sync(c); scan_cache_drop(c, 0); vote_plan_drop(c, 0, 0); }); }
+int ltm_clear_caches(ltm_ctx* c) { return guarded(c, [&] { sync(c); scan_cache_drop(c, 0); }); }
 
 void* ltm_stream(ltm_ctx* c) { return c ? (void*)c->stream : nullptr; }
 
@@ -626,7 +622,7 @@ int ltm_scanset_alloc(ltm_ctx* c, const uint64_t* off, size_t n_kf, ltm_scanset*
 
 int ltm_scanset_free(ltm_ctx* c, ltm_scanset h)
 {
-    return guarded(c, [&] { ScanSet& s = get_ss(c, h); scan_cache_drop(c, h); vote_plan_drop(c, h, 0); if (!s.borrowed) { c->pool.free(s.d); c->pool.free(s.off_dev); } c->scansets.erase(h); });
+    return guarded(c, [&] { ScanSet& s = get_ss(c, h); scan_cache_drop(c, h); if (!s.borrowed) { c->pool.free(s.d); c->pool.free(s.off_dev); } c->scansets.erase(h); });
 }
 
 // ------------------------------------------------------------------ pipelined upload / async fetch
@@ -977,7 +973,7 @@ int ltm_inverse4x4(const double* m16, double* inv16)
 
 int ltm_poses_free(ltm_ctx* c, ltm_poses h)
 {
-    return guarded(c, [&] { Poses& p = get_poses(c, h); vote_plan_drop(c, 0, h); c->pool.free(p.pose_dev); c->pool.free(p.inv_dev); c->pool.free(p.approx_dev); c->poses.erase(h); });
+    return guarded(c, [&] { Poses& p = get_poses(c, h); c->pool.free(p.pose_dev); c->pool.free(p.inv_dev); c->pool.free(p.approx_dev); c->poses.erase(h); });
 }
 
 int ltm_merge_to_global(ltm_ctx* c, ltm_scanset hs, ltm_poses hp, ltm_cloud* out)
@@ -1103,7 +1099,7 @@ static int scanset_pass(ltm_ctx* from, ltm_scanset h, ltm_ctx* to, ltm_scanset* 
         dst.d = src.d; dst.n_pts = src.n_pts; dst.off = src.off; dst.off_dev = src.off_dev; dst.borrowed = !give;
         if (give) {
             LTM_REQUIRE(from->pool.owns(src.d) && from->pool.owns(src.off_dev), "scan set memory is not owned by this context's pool");
-            scan_cache_drop(from, h); vote_plan_drop(from, h, 0);
+            scan_cache_drop(from, h);
             from->pool.move_to(src.d, to->pool); from->pool.move_to(src.off_dev, to->pool);
             from->scansets.erase(h);
         }

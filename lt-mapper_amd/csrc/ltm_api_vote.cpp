@@ -261,189 +261,8 @@ void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, 
     c->occl_pairs += n_pairs; c->occl_far_live += n_proj;
 }
 
-// --------------------------------------------------------------------------------- planned votes (ltm_k_vote_plan.inc)
-static void vote_plan_release_lists(ltm_ctx* c, VotePlan& pl)
-{
-    for (VotePlanBatch& b : pl.batches) { c->pool.free(b.rec); c->pool.free(b.chunks); }
-    pl.batches.clear();
-    c->pool.free(pl.m0); pl.m0 = nullptr; pl.m0_n = 0;
-    c->pool.free(pl.slots); pl.slots = nullptr; pl.mask = 0;
-    pl.built = false; pl.bytes = 0;
-}
-void vote_plan_drop(ltm_ctx* c, uint64_t ss_handle, uint64_t poses_handle)
-{
-    for (size_t i = 0; i < c->vote_plans.size();) {
-        VotePlan& pl = c->vote_plans[i];
-        const bool hit = (ss_handle == 0 && poses_handle == 0) || (ss_handle != 0 && pl.ss == ss_handle) || (poses_handle != 0 && pl.poses == poses_handle);
-        if (hit) { vote_plan_release_lists(c, pl); c->vote_plans.erase(c->vote_plans.begin() + i); }
-        else ++i;
-    }
-}
-// the plan that covers this vote and the index of its resolution, or null
-static VotePlan* vote_plan_for(ltm_ctx* c, uint64_t ss_handle, uint64_t poses_handle, const Geom& g, float thr, int mode, int* res_index)
-{
-    if (!c->vote_plan_on || mode != 0 || poses_handle == 0) return nullptr;
-    for (VotePlan& pl : c->vote_plans) {
-        if (pl.ss != ss_handle || pl.poses != poses_handle || pl.thr != thr || pl.disabled) continue;
-        for (size_t j = 0; j < pl.geoms.size(); ++j)
-            if (pl.geoms[j].rows == g.rows && pl.geoms[j].cols == g.cols) { *res_index = (int)j; return &pl; }
-    }
-    return nullptr;
-}
-// Lists of `map` against every keyframe batch at every planned resolution.  false: not possible (budget, geometry, overflow twice) -- the caller votes un-planned.
-static bool vote_plan_build_lists(ltm_ctx* c, VotePlan& pl, const Cloud& map, uint64_t ss_handle, const ScanSet& ss, const Poses& ps)
-{
-    const int nr = (int)pl.geoms.size();
-    for (int attempt = 0; attempt < 2; ++attempt) {
-        vote_plan_release_lists(c, pl);
-        const size_t n = map.n, n_tiles = (n + 4095) / 4096;
-        const size_t KB = std::min(c->kf_batch, ps.n);
-        DevBuf tb(c, n_tiles * 6 * sizeof(float));
-        LTM_HIP(tile_bounds(map.d, n, tb.as<float>(), c->stream));
-        bool overflowed = false, refused = false;
-        size_t records = 0, capacity = 0;
-        for (size_t kb = 0; kb < ps.n && !overflowed && !refused; kb += KB) {
-            const size_t nb = std::min(KB, ps.n - kb);
-            PlanBuildArgs pa{};
-            pa.n = nr;
-            for (int j = 0; j < nr; ++j) {
-                pa.g[j] = pl.geoms[j];
-                (void)scan_images(c, ss_handle, ss, kb, nb, pl.geoms[j], &pa.smax[j], pl.thr, &pa.qbound[j]);
-            }
-            DevBuf smax_c(c, nb * sizeof(uint32_t));
-            LTM_HIP(plan_smax(pa, nb, smax_c.as<uint32_t>(), c->stream));
-            // record space: a fraction of the point-projections that are in reach of their keyframe (counted on the device: one round trip per batch and build)
-            DevBuf live(c, 8);
-            LTM_HIP(hipMemsetAsync(live.p, 0, 8, c->stream));
-            LTM_HIP(count_live_tiles(ps.approx_dev, kb, nb, tb.as<float>(), n_tiles, smax_c.as<uint32_t>(), pl.thr, live.as<unsigned long long>(), c->stream));
-            unsigned long long live_pairs = 0;
-            d2h(c, &live_pairs, live.p, 8);
-            const double want = (double)live_pairs * 4096.0 * c->vote_plan_fraction * pl.cap_scale * 1.25 / kPlanSubStreams + 8192.0;
-            const size_t cap_sub = (size_t)want;
-            const size_t rec_bytes = cap_sub * kPlanSubStreams * sizeof(uint64_t) * nr, chunk_bytes = n_tiles * nb * sizeof(PlanChunk) * nr;
-            size_t held = 0;
-            for (const VotePlan& o : c->vote_plans) held += o.bytes;
-            if (cap_sub * (size_t)kPlanSubStreams >= 0xffffffffull || held + rec_bytes + chunk_bytes > c->vote_plan_budget) { refused = true; break; }
-            VotePlanBatch b;
-            b.kb = kb; b.nb = nb; b.cap_sub = cap_sub;
-            DevBuf cursors(c, (size_t)nr * kPlanSubStreams * 4 + 4);
-            LTM_HIP(hipMemsetAsync(cursors.p, 0, (size_t)nr * kPlanSubStreams * 4 + 4, c->stream));
-            b.rec = reinterpret_cast<uint64_t*>(c->pool.alloc(rec_bytes));
-            pl.batches.push_back(b);      // (owned by the plan from here on: released with it on any failure below)
-            pl.batches.back().chunks = reinterpret_cast<PlanChunk*>(c->pool.alloc(chunk_bytes));
-            b = pl.batches.back();
-            LTM_HIP(hipMemsetAsync(b.chunks, 0, chunk_bytes, c->stream));
-            pa.rec = b.rec; pa.chunks = b.chunks; pa.cursor = cursors.as<uint32_t>();
-            pl.bytes += rec_bytes + chunk_bytes;
-            pa.cap_sub = (uint32_t)cap_sub;
-            pa.overflow = cursors.as<uint32_t>() + (size_t)nr * kPlanSubStreams;
-            {
-                const double pts = (double)live_pairs * 4096.0;
-                double img_bytes = 0;
-                for (int j = 0; j < nr; ++j) img_bytes += (double)nb * 4.0 * pl.geoms[j].rows * pl.geoms[j].cols;
-                ProfScope p(c, "vote_plan_build", pts, 16.0 * pts + img_bytes, 16.0 * n + img_bytes);
-                HeavyScope hs(c, n_tiles * nb);
-                LTM_HIP(vote_plan_build(map.d, n, ps.inv_dev, ps.approx_dev, kb, nb, c->B2L, c->b2l_identity, pa, smax_c.as<uint32_t>(), tb.as<float>(), pl.thr, hs.stream()));
-                hs.done();
-            }
-            std::vector<uint32_t> fill((size_t)nr * kPlanSubStreams + 1);
-            d2h(c, fill.data(), cursors.p, fill.size() * 4);
-            if (fill.back()) overflowed = true;
-            for (size_t i = 0; i + 1 < fill.size(); ++i) records += fill[i];
-            capacity += cap_sub * (size_t)kPlanSubStreams * nr;
-        }
-        if (refused) { ++c->vote_plan_stats.refused; vote_plan_release_lists(c, pl); pl.disabled = true; return false; }
-        if (overflowed) { ++c->vote_plan_stats.overflows; pl.cap_scale *= 2.5; continue; }
-        // the plan's own copy of the map and the hash set of its coordinates
-        pl.m0 = reinterpret_cast<float4*>(c->pool.alloc(n * sizeof(float4)));
-        d2d(c, pl.m0, map.d, n * sizeof(float4));
-        size_t slots = 1024;
-        while (slots < 2 * n) slots <<= 1;
-        pl.slots = reinterpret_cast<uint32_t*>(c->pool.alloc(slots * 4));
-        pl.mask = (uint32_t)(slots - 1);
-        pl.bytes += n * sizeof(float4) + slots * 4;
-        {
-            ProfScope p(c, "vote_replay", 0.0, (double)n * 16 + (double)slots * 4, -1.0, false);
-            LTM_HIP(hipMemsetAsync(pl.slots, 0xff, slots * 4, c->stream));
-            LTM_HIP(plan_table_build(pl.m0, n, pl.slots, pl.mask, c->stream));
-        }
-        pl.m0_n = n; pl.n_tiles = n_tiles; pl.built = true;
-        ++c->vote_plan_stats.builds;
-        c->vote_plan_stats.records += records; c->vote_plan_stats.record_capacity += capacity;
-        return true;
-    }
-    vote_plan_release_lists(c, pl);
-    pl.disabled = true;
-    return false;
-}
-// One vote through the plan: labels exactly as the un-planned kernels set them.  false: the plan could not be used, nothing was written.
-static bool vote_planned(ltm_ctx* c, VotePlan& pl, int j, const Cloud& map, uint64_t ss_handle, const ScanSet& ss, const Poses& ps, float thr, uint8_t* labels_dev)
-{
-    const Geom g = pl.geoms[j];
-    const size_t npx = (size_t)g.rows * g.cols, n = map.n;
-    std::unique_ptr<DevBuf> origin, remap, ulist, ucount;
-    size_t n_untracked = 0;
-    bool identity = false;
-    if (pl.built) {
-        ProfScope p(c, "vote_replay", 0.0, (double)n * 24 + (double)pl.m0_n * 4, -1.0, false);
-        origin.reset(new DevBuf(c, n * 4)); remap.reset(new DevBuf(c, std::max<size_t>(pl.m0_n, 1) * 4)); ulist.reset(new DevBuf(c, n * 4)); ucount.reset(new DevBuf(c, 4));
-        LTM_HIP(hipMemsetAsync(remap->p, 0xff, pl.m0_n * 4, c->stream));
-        LTM_HIP(hipMemsetAsync(ucount->p, 0, 4, c->stream));
-        LTM_HIP(plan_lookup(map.d, n, pl.m0, pl.slots, pl.mask, origin->as<uint32_t>(), remap->as<uint32_t>(), ulist->as<uint32_t>(), ucount->as<uint32_t>(), c->stream));
-        uint32_t nu = 0;
-        d2h(c, &nu, ucount->p, 4);
-        n_untracked = nu;
-        if (n_untracked > std::max<size_t>(65536, n / 3)) {      // the map has drifted away from the plan's: new lists from this map
-            ++c->vote_plan_stats.rebuilds_for_untracked;
-            pl.built = false;
-        }
-    }
-    if (!pl.built) {
-        if (pl.votes_seen++ < c->vote_plan_skip) return false;
-        if (!vote_plan_build_lists(c, pl, map, ss_handle, ss, ps)) return false;
-        identity = true; n_untracked = 0;
-    }
-    c->vote_plan_stats.untracked_points += n_untracked;
-    ++c->vote_plan_stats.replays;
-    const size_t KB = std::min(c->kf_batch, ps.n);
-    DevBuf map_img(c, KB * npx * sizeof(uint64_t));
-    // the untracked points as a cloud of their own: k_vote_map_cull in its INDEXED form (image values carry their index in the voted map)
-    std::unique_ptr<DevBuf> xu, tbu;
-    const size_t nu_tiles = (n_untracked + 4095) / 4096;
-    if (n_untracked) {
-        ProfScope p(c, "vote_replay", 0.0, (double)n_untracked * 36, -1.0, false);
-        xu.reset(new DevBuf(c, n_untracked * sizeof(float4))); tbu.reset(new DevBuf(c, nu_tiles * 6 * sizeof(float)));
-        LTM_HIP(plan_gather(map.d, ulist->as<uint32_t>(), n_untracked, xu->as<float4>(), c->stream));
-        LTM_HIP(tile_bounds(xu->as<float4>(), n_untracked, tbu->as<float>(), c->stream));
-    }
-    for (const VotePlanBatch& b : pl.batches) {
-        const uint32_t* smax = nullptr;
-        const float* qbound = nullptr;
-        const uint32_t* scan_img = scan_images(c, ss_handle, ss, b.kb, b.nb, g, &smax, thr, &qbound);
-        {
-            ProfScope p(c, "vote_fill", (double)(b.nb * npx), (double)(b.nb * npx * 8));
-            LTM_HIP(fill_u64(map_img.as<uint64_t>(), (uint64_t)kNoPointBits << 32, b.nb * npx, c->stream));
-        }
-        {
-            // units: the point-projections this vote stands for; bytes: SURVEY 8(d)'s formula for them (what the un-planned launch is charged)
-            const double pts = (double)n * b.nb;
-            ProfScope p(c, "vote_replay", pts, 16.0 * pts + (double)b.nb * 8.0 * npx, (double)b.nb * 8.0 * npx);
-            LTM_HIP(vote_replay(b.rec + (size_t)j * kPlanSubStreams * b.cap_sub, b.chunks + (size_t)j * pl.n_tiles * b.nb, identity ? nullptr : remap->as<uint32_t>(), pl.n_tiles, b.nb, g,
-                                map_img.as<uint64_t>(), c->stream));
-            if (n_untracked)
-                LTM_HIP(vote_map_range_images(xu->as<float4>(), n_untracked, ps.inv_dev, ps.approx_dev, b.kb, b.nb, c->B2L, c->b2l_identity, g, qbound, tbu->as<float>(), smax, thr, 0,
-                                              map_img.as<uint64_t>(), c->stream, c->kopts, ulist->as<uint32_t>()));
-        }
-        {
-            ProfScope p(c, "vote_compare", (double)(b.nb * npx), (double)(b.nb * npx) * 12 + (double)b.nb * n / 8.0);
-            LTM_HIP(compare_and_flag(scan_img, map_img.as<uint64_t>(), b.nb * npx, thr, 0, labels_dev, c->stream));
-        }
-    }
-    return true;
-}
-
 void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss, const Poses& ps, size_t kf_begin, size_t kf_end, float alpha, float thr,
-             int mode, uint8_t* labels_dev, uint64_t poses_handle = 0)
+             int mode, uint8_t* labels_dev)
 {
     LTM_REQUIRE(ss.nkf() == ps.n, "scan set and poses have different keyframe counts");
     LTM_REQUIRE(kf_begin <= kf_end && kf_end <= ps.n, "keyframe range out of bounds");
@@ -453,15 +272,6 @@ void do_vote(ltm_ctx* c, const Cloud& map, uint64_t ss_handle, const ScanSet& ss
     const Geom g = geom_for(c, alpha);
     LTM_REQUIRE(g.rows > 0 && g.cols > 0, "empty range image");
     const size_t npx = (size_t)g.rows * g.cols;
-    if (kf_begin == 0 && kf_end == ps.n && ps.approx_dev && c->kopts.vote_cull != 0 && npx <= ((size_t)1 << 20)) {
-        int j = 0;
-        if (VotePlan* pl = vote_plan_for(c, ss_handle, poses_handle, g, thr, mode, &j)) {
-            bool ok = true;
-            for (const Geom& pg : pl->geoms) ok = ok && pg.el_fit != 0 && (size_t)pg.rows * pg.cols <= ((size_t)1 << 17) && cull_geometry_ok(c, pg, ps, 0);      // (17 pixel bits in the build's queue word)
-            if (!ok) pl->disabled = true;
-            else if (vote_planned(c, *pl, j, map, ss_handle, ss, ps, thr, labels_dev)) return;
-        }
-    }
     const size_t KB = std::min(c->kf_batch, kf_end - kf_begin);
     DevBuf map_img(c, KB * npx * sizeof(uint64_t));
     const size_t n_tiles = (map.n + 4095) / 4096;
@@ -551,52 +361,12 @@ int ltm_scanset_prepare_range_images(ltm_ctx* c, ltm_scanset hs, size_t kf_begin
     });
 }
 
-int ltm_vote_plan_begin(ltm_ctx* c, ltm_scanset hs, ltm_poses hp, const float* alphas, size_t n_alphas, float thr)
-{
-    return guarded(c, [&] {
-        LTM_REQUIRE(alphas || n_alphas == 0, "null argument");
-        const ScanSet& ss = get_ss(c, hs);
-        const Poses& ps = get_poses(c, hp);
-        LTM_REQUIRE(ss.nkf() == ps.n, "scan set and poses have different keyframe counts");
-        vote_plan_drop(c, hs, 0);
-        if (n_alphas == 0) return;
-        VotePlan pl;
-        pl.ss = hs; pl.poses = hp; pl.thr = thr;
-        for (size_t i = 0; i < n_alphas; ++i) {
-            const Geom g = geom_for(c, alphas[i]);
-            LTM_REQUIRE(g.rows > 0 && g.cols > 0, "empty range image");
-            bool dup = false;
-            for (const Geom& o : pl.geoms) dup = dup || (o.rows == g.rows && o.cols == g.cols);
-            if (dup) continue;
-            if (pl.geoms.size() == (size_t)kPlanMaxRes) break;      // more resolutions than one build covers: the later ones vote un-planned
-            pl.alphas.push_back(alphas[i]); pl.geoms.push_back(g);
-        }
-        c->vote_plans.push_back(std::move(pl));
-    });
-}
-
-int ltm_vote_plan_end(ltm_ctx* c, ltm_scanset hs)
-{
-    return guarded(c, [&] { vote_plan_drop(c, hs, 0); });
-}
-
-int ltm_debug_vote_plan_stats(ltm_ctx* c, uint64_t* out8, int reset)
-{
-    return guarded(c, [&] {
-        LTM_REQUIRE(out8, "null argument");
-        const VotePlanStats& s = c->vote_plan_stats;
-        out8[0] = s.builds; out8[1] = s.replays; out8[2] = s.untracked_points; out8[3] = s.rebuilds_for_untracked; out8[4] = s.overflows; out8[5] = s.refused;
-        out8[6] = s.records; out8[7] = s.record_capacity;
-        if (reset) c->vote_plan_stats = VotePlanStats{};
-    });
-}
-
 int ltm_visibility_vote(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_poses hp, size_t kf_begin, size_t kf_end, float alpha,
                         float thr, int mode, uint8_t* labels_dev)
 {
     return guarded(c, [&] {
         LTM_REQUIRE(labels_dev, "null labels buffer");
-        do_vote(c, get_cloud(c, hmap), hs, get_ss(c, hs), get_poses(c, hp), kf_begin, kf_end, alpha, thr, mode, labels_dev, hp);
+        do_vote(c, get_cloud(c, hmap), hs, get_ss(c, hs), get_poses(c, hp), kf_begin, kf_end, alpha, thr, mode, labels_dev);
         sync(c);   // the caller may hand labels_dev to a collective on another stream
     });
 }
@@ -619,7 +389,7 @@ int ltm_visibility_partition(ltm_ctx* c, ltm_cloud hmap, ltm_scanset hs, ltm_pos
         const Poses& p = get_poses(c, hp);
         DevBuf labels(c, std::max<size_t>(map.n, 1));
         LTM_HIP(hipMemsetAsync(labels.p, 0, std::max<size_t>(map.n, 1), c->stream));
-        do_vote(c, map, hs, get_ss(c, hs), p, 0, p.n, alpha, thr, mode, labels.as<uint8_t>(), hp);
+        do_vote(c, map, hs, get_ss(c, hs), p, 0, p.n, alpha, thr, mode, labels.as<uint8_t>());
         if (host_labels) d2h(c, host_labels, labels.p, map.n);
         do_partition(c, map, labels.as<uint8_t>(), kept, flagged);
     });

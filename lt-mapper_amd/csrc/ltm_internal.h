@@ -194,21 +194,6 @@ struct ProfClass { double ms = 0; uint64_t launches = 0; double units = 0, bytes
 // scan2RangeImg depends only on (scan set, image shape, keyframe range): the remove / revert / remove passes of one
 // resolution and the three ND / PD filter passes project the same scans again, so finished scan images are kept.
 struct ScanImgEntry { uint64_t ss; int rows, cols; size_t kb, nb; uint32_t* buf; uint32_t* smax; size_t bytes; uint64_t stamp; float* qbound; float q_thr; };
-// A planned sequence of mode-0 votes (ltm_vote_plan_begin): candidate lists of one map against one scan set at up to kPlanMaxRes resolutions, see
-// ltm_k_vote_plan.inc.  `m0` is the plan's own copy of the map the lists were built from (the caller may free its cloud), `slots` the hash set of its coordinates.
-struct VotePlanBatch { size_t kb = 0, nb = 0, cap_sub = 0; uint64_t* rec = nullptr; PlanChunk* chunks = nullptr; };      // resolution-major: rec[j * kPlanSubStreams * cap_sub ..], chunks[j * n_tiles * nb ..]
-struct VotePlan {
-    uint64_t ss = 0, poses = 0; float thr = 0.0f;
-    std::vector<float> alphas; std::vector<Geom> geoms;
-    bool built = false, disabled = false;
-    float4* m0 = nullptr; size_t m0_n = 0, n_tiles = 0;
-    uint32_t* slots = nullptr; uint32_t mask = 0;
-    std::vector<VotePlanBatch> batches;
-    double cap_scale = 1.0;          // doubled when a build overflowed its record space
-    int votes_seen = 0;              // planned votes before the lists exist: the first `vote_plan_skip` of them take the un-planned kernel
-    size_t bytes = 0;
-};
-struct VotePlanStats { uint64_t builds = 0, replays = 0, untracked_points = 0, rebuilds_for_untracked = 0, overflows = 0, refused = 0, records = 0, record_capacity = 0; };
 struct Pending { int cls; hipEvent_t a, b; };
 // a vote launch whose algorithmic bytes depend on the number of (tile, keyframe) workgroups that survive the whole-tile cull:
 // counted on the device into slot `slot` of ctx->live_counts, folded into the class totals when the profile is collected
@@ -303,14 +288,6 @@ struct ltm_ctx {
     std::vector<PendingLive> pending_live;
     unsigned long long* live_counts = nullptr;   // device, kLiveSlots entries
     std::vector<hipEvent_t> event_pool;
-    std::vector<VotePlan> vote_plans;           // ltm_vote_plan_begin / _end
-    VotePlanStats vote_plan_stats;
-    int vote_plan_skip = 1;                     // LTM_VOTE_PLAN_SKIP: the lists are built at the (skip+1)-th vote of a plan.  The first full-map vote removes the points that are
-                                                // candidates in very many keyframes (21 % of all point-projections of configs[1] against 8-10 % afterwards): lists built
-                                                // from the map it leaves are less than half the size
-    int vote_plan_on = 1;                       // LTM_VOTE_PLAN=0: plans are accepted and ignored (every vote takes the un-planned kernels; A/B and parity tests)
-    double vote_plan_fraction = 0.14;           // LTM_VOTE_PLAN_FRACTION: record space per resolution as a fraction of the in-reach point-projections of the first build
-    size_t vote_plan_budget = (size_t)64 << 30; // LTM_VOTE_PLAN_BUDGET_GB: upper bound of the lists of one context; a plan that would need more is refused (un-planned kernels)
     std::vector<ScanImgEntry> scan_cache;
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
@@ -655,7 +632,6 @@ size_t scan_total_u8(ltm_ctx* c, const uint8_t* labels, const uint32_t* pos, siz
 void scan_cache_drop(ltm_ctx* c, uint64_t ss_handle);                             // ltm_api_vote.cpp
 void do_partition(ltm_ctx* c, const Cloud& map, const uint8_t* labels, ltm_cloud* kept, ltm_cloud* flagged);   // ltm_api_vote.cpp
 void bbox_of(ltm_ctx* c, const float4* pts, size_t n, float mn[3], float mx[3]);  // ltm_api_voxel.cpp
-void vote_plan_drop(ltm_ctx* c, uint64_t ss_handle, uint64_t poses_handle);            // ltm_api_vote.cpp: plans of a scan set / of poses (0, 0: all)
 void vgs_release_all(ltm_ctx* c);                                                 // ltm_api_voxel.cpp: open ltm_voxel_grid_scanset tickets, at ltm_destroy
 void split_by_flag(ltm_ctx* c, const float4* pts, const uint8_t* flag, size_t n, const std::vector<uint64_t>& bounds, const uint64_t* offsets_dev,
                    size_t kf0, uint64_t first, float4** d_set, std::vector<uint64_t>* off_set, float4** d_unset, std::vector<uint64_t>* off_unset);   // ltm_api_knn.cpp

@@ -481,7 +481,7 @@ __device__ __forceinline__ int table_claim(uint32_t* __restrict__ tags, int row,
 // exact projection of one map point into image `imgk`, reduced through the workgroup's LDS table
 template <bool B2L_IDENTITY, int SLOTS_R, int SLOTS_C>
 __device__ __forceinline__ void exact_insert(const float4* __restrict__ map, uint32_t i, const Mat34& Tinv, const HostMat34& b2l_h, const RimgGeom& g,
-                                             uint64_t* __restrict__ vals, uint32_t* __restrict__ tags, uint64_t* __restrict__ imgk, const uint32_t* __restrict__ imap = nullptr)
+                                             uint64_t* __restrict__ vals, uint32_t* __restrict__ tags, uint64_t* __restrict__ imgk)
 {
     const float4 p4 = map[i];
     float3 p = xform(Tinv, make_float3(p4.x, p4.y, p4.z));
@@ -490,7 +490,7 @@ __device__ __forceinline__ void exact_insert(const float4* __restrict__ map, uin
     int row, col;
     pixel_row_col(g, s.az, s.el, row, col);
     const uint32_t px = (uint32_t)(row * g.cols + col);
-    const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)(imap ? imap[i] : i);
+    const uint64_t v = ((uint64_t)f2u(s.r) << 32) | (uint64_t)i;
     const int slot = table_claim<SLOTS_R, SLOTS_C>(tags, row, col, px);
     if (slot >= 0) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
     else img_min_u64(imgk + px, v);
@@ -562,14 +562,12 @@ hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb,
 
 static constexpr int kCullSlots = 512;   // survivors are ~10 % of a workgroup's points: a small LDS table keeps 8 workgroups per CU
 
-// INDEXED: the cloud is a gathered subset of the voted map (the untracked points of a planned vote, ltm_k_vote_plan.inc): image values carry imap[i]
-template <bool B2L_IDENTITY, bool EL3, bool INDEXED = false>     // EL3: fitted elevation polynomial (Geom::el_fit), see cull_candidates
+template <bool B2L_IDENTITY, bool EL3>     // EL3: fitted elevation polynomial (Geom::el_fit), see cull_candidates
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(8, 8)))
 k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __restrict__ inv_poses, const float* __restrict__ approx_poses,
                 uint32_t kb, uint32_t nb, uint32_t kfg, HostMat34 b2l_h, Geom gg, const float* __restrict__ qbound_img,
-                const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img, const uint32_t* __restrict__ imap_arg = nullptr)
+                const float* __restrict__ tile_bounds, const uint32_t* __restrict__ smax_bits, float thr, uint64_t* __restrict__ img)
 {
-    const uint32_t* __restrict__ imap = INDEXED ? imap_arg : nullptr;
     __shared__ uint64_t vals[kCullSlots];
     __shared__ uint32_t tags[kCullSlots];
     // survivors of phase 1, one word each: tile-local index (12 bits) | row (9) | column (11); row field 511 = pixel not certain,
@@ -678,7 +676,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
         const Mat34 Tinv = load_mat(inv_poses + 12 * (size_t)kf);
         if (__builtin_expect(nq_all > (uint32_t)kCullQueue, 0)) {      // queue overflow: a superset is always correct (min is idempotent)
             for (uint32_t li = threadIdx.x; li < nloc; li += kBlock)
-                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk, imap);
+                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + li, Tinv, b2l_h, g, vals, tags, imgk);
         } else {
             for (uint32_t q = threadIdx.x; q < nq_all; q += kBlock) {
                 const uint32_t e = queue[q];
@@ -686,7 +684,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
                 if (row == 511) { uqueue[atomicAdd(&ucount, 1u)] = (uint16_t)(e >> 20); continue; }
                 const uint32_t i = block_base + (e >> 20);
                 const uint32_t px = (uint32_t)(row * g.cols + col);
-                const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)(INDEXED ? imap[i] : i);
+                const uint64_t v = ((uint64_t)exact_range_bits<B2L_IDENTITY>(map[i], Tinv, b2l_h) << 32) | (uint64_t)i;
                 const int slot = table_claim<8, 64>(tags, row, col, px);
                 if (slot >= 0) { if (v < vals[slot]) atomicMin(reinterpret_cast<unsigned long long*>(&vals[slot]), (unsigned long long)v); }   // vals only decreases: skip hopeless same-address atomics
                 else img_min_u64(imgk + px, v);
@@ -694,7 +692,7 @@ k_vote_map_cull(const float4* __restrict__ map, uint32_t M, const double* __rest
             __syncthreads();
             const uint32_t nu = ucount;
             for (uint32_t q = threadIdx.x; q < nu; q += kBlock)
-                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk, imap);
+                exact_insert<B2L_IDENTITY, 8, 64>(map, block_base + uqueue[q], Tinv, b2l_h, g, vals, tags, imgk);
         }
     }
     __syncthreads();
@@ -719,30 +717,21 @@ hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s, int wh
 
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                  HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
-                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s, const KernelOpts& ko, const uint32_t* imap)
+                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s, const KernelOpts& ko)
 {
     if (!M || !nb) return hipSuccess;
-    if (imap && (mode != 0 || !approx_poses_dev || !qbound_img)) return hipErrorInvalidValue;
-    if (!imap && (mode != 0 || !ko.vote_cull || !approx_poses_dev || !qbound_img)) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s, ko);
+    if (mode != 0 || !ko.vote_cull || !approx_poses_dev || !qbound_img) return map_range_images(map, M, inv_poses_dev, approx_poses_dev, kb, nb, b2l, b2l_identity, g, map_img, s, ko);
     const size_t per_block = (size_t)kBlock * kPtsPerThread;
     const unsigned kfg = kKfPerTile;
     dim3 grid(tile_kf_grid((M + per_block - 1) / per_block, nb, kfg));
     const float* tb = (ko.tile_cull && smax_bits_dev) ? tile_bounds_dev : nullptr;
     const bool el3 = g.el_fit != 0;
 #define LTM_LAUNCH_CULL(ID, E) k_vote_map_cull<ID, E><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img)
-#define LTM_LAUNCH_CULL_IDX(ID, E) k_vote_map_cull<ID, E, true><<<grid, dim3(kBlock), 0, s>>>(map, (uint32_t)M, inv_poses_dev, approx_poses_dev, (uint32_t)kb, (uint32_t)nb, kfg, b2l, g, qbound_img, tb, smax_bits_dev, thr, map_img, imap)
-    if (imap) {
-        if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL_IDX(false, true); else LTM_LAUNCH_CULL_IDX(false, false); }
-        else { if (el3) LTM_LAUNCH_CULL_IDX(true, true); else LTM_LAUNCH_CULL_IDX(true, false); }
-    }
-    else if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL(false, true); else LTM_LAUNCH_CULL(false, false); }
+    if (!b2l_identity) { if (el3) LTM_LAUNCH_CULL(false, true); else LTM_LAUNCH_CULL(false, false); }
     else { if (el3) LTM_LAUNCH_CULL(true, true); else LTM_LAUNCH_CULL(true, false); }
 #undef LTM_LAUNCH_CULL
-#undef LTM_LAUNCH_CULL_IDX
     return hipGetLastError();
 }
-
-#include "ltm_k_vote_plan.inc"
 
 // debug: number of points whose exact pixel is NOT inside the candidate set of the bounded-error projection.
 // T (3x4 double) / ap (16 floats) are the exact and the approximate form of the same keyframe transform, or null.

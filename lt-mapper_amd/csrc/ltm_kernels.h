@@ -74,31 +74,7 @@ hipError_t compare_and_flag(const uint32_t* scan_img, const uint64_t* map_img, s
 // approx_poses_dev: 16 floats per keyframe {A[9], c_hi[3], c_lo[3], ok} with p_local ~= A (p - c) (see xform_approx)
 hipError_t vote_map_range_images(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb,
                                  HostMat34 b2l, int b2l_identity, Geom g, const float* qbound_img, const float* tile_bounds_dev,
-                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s, const KernelOpts& ko,
-                                 const uint32_t* imap = nullptr);      // imap: the cloud is a gathered subset of the voted map, image values carry imap[i] (mode 0, culled form only)
-// ---- planned votes (ltm_k_vote_plan.inc): candidate lists for a sequence of mode-0 votes of maps derived from one another against the same scans
-static const int kPlanMaxRes = 4;
-static const uint32_t kPlanSubStreams = 1024;
-struct PlanChunk { uint32_t first, count; };
-struct PlanBuildArgs {
-    int n;                                       // resolutions
-    Geom g[kPlanMaxRes];
-    const float* qbound[kPlanMaxRes];            // bound images of the batch (k_scan_qbound), nb * rows * cols each
-    const uint32_t* smax[kPlanMaxRes];           // longest return per keyframe of the batch
-    uint64_t* rec;                               // n * kPlanSubStreams * cap_sub records, resolution-major
-    PlanChunk* chunks;                           // n * n_tiles * nb entries, zeroed before the launch
-    uint32_t* cursor;                            // n * kPlanSubStreams fill counts, zeroed before the launch
-    uint32_t cap_sub;
-    uint32_t* overflow;
-};
-hipError_t plan_smax(const PlanBuildArgs& pa, size_t nb, uint32_t* smax_c, hipStream_t s);
-hipError_t vote_plan_build(const float4* map, size_t M, const double* inv_poses_dev, const float* approx_poses_dev, size_t kb, size_t nb, HostMat34 b2l, int b2l_identity,
-                           const PlanBuildArgs& pa, const uint32_t* smax_c, const float* tile_bounds_dev, float thr, hipStream_t s);
-hipError_t plan_gather(const float4* x, const uint32_t* list, size_t n, float4* out, hipStream_t s);
-hipError_t plan_table_build(const float4* m0, size_t n, uint32_t* slots, uint32_t mask, hipStream_t s);
-hipError_t plan_lookup(const float4* x, size_t n, const float4* m0, const uint32_t* slots, uint32_t mask, uint32_t* origin, uint32_t* remap, uint32_t* untracked,
-                       uint32_t* n_untracked, hipStream_t s);
-hipError_t vote_replay(const uint64_t* rec, const PlanChunk* chunks, const uint32_t* remap, size_t n_tiles, size_t nb, Geom g, uint64_t* img, hipStream_t s);
+                                 const uint32_t* smax_bits_dev, float thr, int mode, uint64_t* map_img, hipStream_t s, const KernelOpts& ko);
 hipError_t count_live_tiles(const float* approx_poses_dev, size_t kb, size_t nb, const float* tile_bounds_dev, size_t n_tiles,
                             const uint32_t* smax_bits_dev, float thr, unsigned long long* live_dev, hipStream_t s);
 hipError_t cull_stats(unsigned long long* out2, int reset, hipStream_t s, int which_kernel);   // {survivors, points} since the last reset; 0 vote kernel, 1 exact-image kernel

@@ -312,9 +312,6 @@ void Removerter::selfRemovert(const Session& _sess, int _repeat = 1)            
         _sess.stageArgs(_sess.keyframe_scans_, &ph, &kb, &ke);
         ltm_ctx* ctx = _sess.dev_->ctx;
         ltmCheck(ctx, ltm_scanset_prepare_range_images(ctx, _sess.keyframe_scans_->h, kb, ke, alphas.data(), alphas.size()), "ltm_scanset_prepare_range_images");
-        // the full-map votes below are a sequence over maps that derive from one another: the library evaluates the projection once for all resolutions
-        // (labels unchanged; a plan covers votes over ALL keyframes, so a keyframe-sharded rank simply votes un-planned)
-        ltmCheck(ctx, ltm_vote_plan_begin(ctx, _sess.keyframe_scans_->h, ph, remove_resolution_list_.data(), remove_resolution_list_.size(), 0.1f), "ltm_vote_plan_begin");
     }
     for (float _res : remove_resolution_list_) {
         for (int i = 0; i < _repeat; i++) {
@@ -325,8 +322,6 @@ void Removerter::selfRemovert(const Session& _sess, int _repeat = 1)            
             removeOnce(_sess, _sess, _res);
         }
     }
-    if (_repeat > 0 && !remove_resolution_list_.empty())
-        ltmCheck(_sess.dev_->ctx, ltm_vote_plan_end(_sess.dev_->ctx, _sess.keyframe_scans_->h), "ltm_vote_plan_end");
     saveCurrentStaticAndDynamicPointCloudGlobal(_sess, "_MVM");
 }
 

@@ -66,8 +66,6 @@ class HipOps:
     def preclean(self, s, radius): return self.ctx.preclean(s, radius)                      # Session.cpp:506-533
     def vote_partition(self, cmap, scans, poses, alpha, thr, mode): return self.ctx.visibility_partition(cmap, scans, poses, alpha, thr, mode)
     def prepare_scan_images(self, scans, alphas): self.ctx.prepare_scan_images(scans, alphas)
-    def vote_plan_begin(self, scans, poses, alphas, thr): self.ctx.vote_plan_begin(scans, poses, alphas, thr)
-    def vote_plan_end(self, scans): self.ctx.vote_plan_end(scans)
     def reproject(self, cmap, poses, alpha): return self.ctx.reproject(cmap, poses, alpha)
     def knn_partition(self, target, scans, poses, k, thr): return self.ctx.knn_partition(target, scans, poses, k, thr)
     def knn_split(self, target, query, k, thr): return self.ctx.knn_split_cloud(target, query, k, thr)
@@ -246,23 +244,14 @@ class Removerter:
         if prepare is not None and repeat > 0:      # every scan image the passes below will ask for, in one pass over the scans
             rs = [float(np.float32(r)) for r in self.P.remove_resolution_list]
             prepare(sess.keyframe_scans_, rs + [float(np.float32(0.95 * r)) for r in rs])
-        plan = getattr(ops or self.ops, "vote_plan_begin", None)
-        if plan is not None and repeat > 0 and len(self.P.remove_resolution_list) > 0:
-            # the full-map votes below are a sequence over maps that derive from one another: the library evaluates the projection once for all resolutions
-            # (ltm_vote_plan_begin; labels unchanged)
-            plan(sess.keyframe_scans_, sess.keyframe_poses, [float(np.float32(r)) for r in self.P.remove_resolution_list], 0.1)
-        try:
-            for res in self.P.remove_resolution_list:
-                res = float(np.float32(res))
-                for _ in range(repeat):                                            # `i < _repeat`, Removerter.cpp:1381: repeat 0 runs nothing
-                    self.removeOnce(sess, sess, res, ops)
-                    sess.map_global_curr_ = sess.map_global_curr_dynamic_          # resetCurrrentMapAsDynamic :714-737
-                    self.revertOnce(sess, sess, float(np.float32(0.95 * res)), ops)   # :1385 double product narrowed to float
-                    sess.map_global_curr_ = sess.map_global_curr_static_           # resetCurrrentMapAsStatic
-                    self.removeOnce(sess, sess, res, ops)
-        finally:
-            if plan is not None and repeat > 0 and len(self.P.remove_resolution_list) > 0:
-                (ops or self.ops).vote_plan_end(sess.keyframe_scans_)
+        for res in self.P.remove_resolution_list:
+            res = float(np.float32(res))
+            for _ in range(repeat):                                            # `i < _repeat`, Removerter.cpp:1381: repeat 0 runs nothing
+                self.removeOnce(sess, sess, res, ops)
+                sess.map_global_curr_ = sess.map_global_curr_dynamic_          # resetCurrrentMapAsDynamic :714-737
+                self.revertOnce(sess, sess, float(np.float32(0.95 * res)), ops)   # :1385 double product narrowed to float
+                sess.map_global_curr_ = sess.map_global_curr_static_           # resetCurrrentMapAsStatic
+                self.removeOnce(sess, sess, res, ops)
 
     def _removeHighDynamicOf(self, sess, ops=None):     # one session's share of Removerter.cpp:1584-1591
         if self.P.gpu_use_self_removert and len(self.P.remove_resolution_list) > 0:
