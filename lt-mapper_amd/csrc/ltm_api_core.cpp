@@ -256,7 +256,6 @@ int ltm_create(const ltm_config* cfg, ltm_ctx** out)
         if (d) (void)hipFree(d);
         if (!ok) { (void)hipStreamDestroy(c->stream); delete c; return LTM_E_DEVICE; }
         c->fast_math = (c->selfcheck[0] == 0 && c->selfcheck[1] == 0 && c->selfcheck[2] == 0) ? 1 : 0;
-        if (const char* v = getenv("LTM_FAST_MATH")) c->fast_math = c->fast_math && atoi(v);
         if (const char* v = getenv("LTM_KNN_FAST")) c->knn_two_phase = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_KEYBITS")) c->voxel_key_compress = atoi(v);
         if (const char* v = getenv("LTM_VOXEL_FUSED_TAIL")) c->voxel_fused_tail = atoi(v);
