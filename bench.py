@@ -262,6 +262,9 @@ def main():
     if two_lanes:
         # kernel classes, rooflines, comm meter: a ONE-lane pass with the HIP-event profile on (events of overlapping launches would count the other lane's work)
         psteps = max(args.profile_steps, 1)
+        last = None
+        last = one_step(False)      # one untimed step in the one-lane order first: the pools re-balance (blocks that lived in the lane's pool are allocated afresh on the main one)
+        barrier()
         ctx.profile_reset()
         ctx.profile_enable(True)
         ctx.voxel_stats(reset=True)
