@@ -1,4 +1,4 @@
-"""Per-step, per-kernel totals from a minimal kernel trace (Kernel_Name, Queue_Id, Start_Timestamp, End_Timestamp; tools/exp_r6_4.sh): a step ends with the
+"""Per-step, per-kernel totals from a minimal kernel trace (Kernel_Name, Queue_Id, Start_Timestamp, End_Timestamp, as rocprofv3 --kernel-trace writes them): a step ends with the
 one k_voxel_centroids launch of updateScansScanwise.  Profiling helper."""
 import collections
 import csv
