@@ -118,10 +118,10 @@ void scan_images_prepare(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size
     uint64_t longest = 0;
     for (size_t k = kb; k < kb + nb; ++k) longest = std::max<uint64_t>(longest, ss.off[k + 1] - ss.off[k]);
     {
-        // The one-pass kernel pays when a scan has fewer points than an image has pixels (os1-64 on the lot: 0.45 points per pixel; cascade vote_scan 71.0 -> 63.8 ms
-        // per step).  With several points per pixel (hdl-64e on the street: 1.8) its six atomics per point pile up on the same few lines while the point's
-        // neighbours do the same: vote_scan 73.5 -> 112.5 ms per step there (street 3-res 1058 -> 1096 ms).  Above `scan_multi_max_density` points per pixel of the
-        // smallest shape the votes compute their images one shape at a time, as before round 6 (identical images either way).
+        // The one-pass kernel pays while a scan has about as many points as the smallest image has pixels (os1-64 on the lot: 1.4 points per pixel of the 64 x 513
+        // shape; cascade vote_scan 71.0 -> 63.8 ms per step).  With many points per pixel (hdl-64e on the street: 5.6) its six atomics per point pile up on the
+        // same few lines while the point's neighbours do the same: vote_scan 73.5 -> 112.5 ms per step there (street 3-res 1058 -> 1096 ms).  Above
+        // `scan_multi_max_density` (2.5) points per pixel the votes compute their images one shape at a time, as before round 6 (identical images either way).
         size_t min_px = (size_t)todo[0].rows * todo[0].cols;
         for (const Geom& t : todo) min_px = std::min(min_px, (size_t)t.rows * t.cols);
         const double density = (double)(npts / std::max<size_t>(nb, 1)) / (double)std::max<size_t>(min_px, 1);
