@@ -7,7 +7,7 @@ namespace ltm_detail {
 struct KnnIndex {
     ltm_ctx* c;
     float4* sorted = nullptr; HashEntry* table = nullptr; uint32_t mask = 0; KnnGrid g{}; float cell2_lo = 0; size_t Mt = 0;
-    void* buckets = nullptr; uint32_t n_buckets = 0;      // phase-1 table of the two-phase query (k <= 4), see ltm_kernels.hip
+    void* buckets = nullptr; uint32_t n_buckets = 0;      // phase-1 table of the two-phase query (k <= 4), see ltm_k_knn.hip
     void* bitmap = nullptr; uint32_t bitmap_mask = 0;     // sparse occupancy bitmap of the grid (phase 2 skips empty cells)
     explicit KnnIndex(ltm_ctx* c_) : c(c_) {}
     ~KnnIndex() { c->pool.free(sorted); c->pool.free(table); c->pool.free(buckets); c->pool.free(bitmap); }

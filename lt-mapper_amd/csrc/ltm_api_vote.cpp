@@ -118,10 +118,11 @@ void scan_images_prepare(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size
     uint64_t longest = 0;
     for (size_t k = kb; k < kb + nb; ++k) longest = std::max<uint64_t>(longest, ss.off[k + 1] - ss.off[k]);
     {
-        // The one-pass kernel pays while a scan has about as many points as the smallest image has pixels (os1-64 on the lot: 1.4 points per pixel of the 64 x 513
-        // shape; cascade vote_scan 71.0 -> 63.8 ms per step).  With many points per pixel (hdl-64e on the street: 5.6) its six atomics per point pile up on the
-        // same few lines while the point's neighbours do the same: vote_scan 73.5 -> 112.5 ms per step there (street 3-res 1058 -> 1096 ms).  Above
-        // `scan_multi_max_density` (2.5) points per pixel the votes compute their images one shape at a time, as before round 6 (identical images either way).
+        // The one-pass kernel pays while a scan has only a few points per pixel of the smallest shape (os1-64 on the lot, 64 x 513 pixels: 1.4 for fresh scans,
+        // 3.7 for the re-gridded scans a cascade hands over; cascade vote_scan 71.0 -> 63.8 ms per step).  With many (hdl-64e on the street, 38 x 513: 5.6) its
+        // six atomics per point pile up on the same few lines while the point's neighbours do the same: vote_scan 73.5 -> 112.5 ms per step there (street 3-res
+        // 1058 -> 1096 ms).  Above `scan_multi_max_density` (4.5) points per pixel the votes compute their images one shape at a time, as before round 6
+        // (identical images either way).
         size_t min_px = (size_t)todo[0].rows * todo[0].cols;
         for (const Geom& t : todo) min_px = std::min(min_px, (size_t)t.rows * t.cols);
         const double density = (double)(npts / std::max<size_t>(nb, 1)) / (double)std::max<size_t>(min_px, 1);
@@ -191,7 +192,7 @@ bool cull_geometry_ok(ltm_ctx* c, const Geom& g, const Poses& ps, size_t kf)
 }
 
 // Exact arg-min images of keyframes [kb, kb + nb) (reprojection, ND votes, RViz images): on a large map behind an occlusion cull
-// (ltm_kernels.hip: near pairs first, a coarse maximum of the partial image, far pairs that nearer returns cover completely are dropped).
+// (ltm_k_projection.hip: near pairs first, a coarse maximum of the partial image, far pairs that nearer returns cover completely are dropped).
 // The image is bit-identical to the plain launch; below `occlusion_min_pairs` (tile, keyframe) pairs the plain launch is used.
 void exact_map_images(ltm_ctx* c, const Cloud& map, const Poses& ps, size_t kb, size_t nb, const Geom& g, uint64_t* img)
 {
