@@ -118,11 +118,12 @@ void scan_images_prepare(ltm_ctx* c, uint64_t ss_handle, const ScanSet& ss, size
     uint64_t longest = 0;
     for (size_t k = kb; k < kb + nb; ++k) longest = std::max<uint64_t>(longest, ss.off[k + 1] - ss.off[k]);
     {
-        // The one-pass kernel pays while a scan has only a few points per pixel of the smallest shape (os1-64 on the lot, 64 x 513 pixels: 1.4 for fresh scans,
-        // 3.7 for the re-gridded scans a cascade hands over; cascade vote_scan 71.0 -> 63.8 ms per step).  With many (hdl-64e on the street, 38 x 513: 5.6) its
-        // six atomics per point pile up on the same few lines while the point's neighbours do the same: vote_scan 73.5 -> 112.5 ms per step there (street 3-res
-        // 1058 -> 1096 ms).  Above `scan_multi_max_density` (4.5) points per pixel the votes compute their images one shape at a time, as before round 6
-        // (identical images either way).
+        // The one-pass kernel pays while a scan has about as many points as the smallest shape has pixels (71 x 513 at the reference's 50 degree field of view:
+        // 1.3 points per pixel for the lot's os1-64 scans; cascade vote_scan 71 -> 64 ms per step with every session on it).  With several points per pixel its six
+        // atomics per point pile up on the same few lines while the point's neighbours do the same: hdl-64e on the street, 3.0 per pixel of the whole image and twice
+        // that where the sensor's 27 degrees actually fall, 73 -> 113 ms per step (street 3-res 1057 -> 1100 ms); the re-gridded scans a cascade hands over (3.3) sit
+        // on the same side of the line and give up 5 of their 790 ms.  Above `scan_multi_max_density` (2.5) the votes compute their images one shape at a time, as
+        // before round 6 (identical images either way).
         size_t min_px = (size_t)todo[0].rows * todo[0].cols;
         for (const Geom& t : todo) min_px = std::min(min_px, (size_t)t.rows * t.cols);
         const double density = (double)(npts / std::max<size_t>(nb, 1)) / (double)std::max<size_t>(min_px, 1);

@@ -288,7 +288,7 @@ struct ltm_ctx {
     std::vector<PendingLive> pending_live;
     unsigned long long* live_counts = nullptr;   // device, kLiveSlots entries
     std::vector<hipEvent_t> event_pool;
-    double scan_multi_max_density = 4.5;        // mean scan points per pixel of the smallest shape up to which ltm_scanset_prepare_range_images uses the one-pass kernel (scan_images_prepare)
+    double scan_multi_max_density = 2.5;        // mean scan points per pixel of the smallest shape up to which ltm_scanset_prepare_range_images uses the one-pass kernel (scan_images_prepare)
     std::vector<ScanImgEntry> scan_cache;
     uint64_t scan_cache_stamp = 0;
     size_t scan_cache_cap = (size_t)3 << 30;   // bytes
