@@ -143,13 +143,17 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
         uint64_t longest = 0;
         for (size_t kk = kf_begin; kk < kf_end; ++kk) longest = std::max<uint64_t>(longest, s.off[kk + 1] - s.off[kk]);
         if (index.buckets && n && n < 0xffffffffull) {
+            unsigned ibits = 0;
+            const unsigned kbits = knn_sorted_queue_bits(index.g, n, &ibits);      // 0: the keys do not fit, phase 2 walks the queue in scan order
+            // the global point of every undecided query, written by phase 1 (only those entries are ever read)
+            std::unique_ptr<DevBuf> gpu;
+            if (kbits) gpu.reset(new DevBuf(c, n * sizeof(float4)));
+            float4* gp = gpu ? gpu->as<float4>() : nullptr;
             {
                 ProfScope ps(c, "knn_query", (double)n, (double)n * (16.0 + 16.0 * k + 1.0));
                 LTM_HIP(knn_two_phase_fast(s.d, s.off_dev, kf_begin, kf_end, first, n, longest, p.pose_dev, p.inv_dev, c->B2L, c->b2l_identity, index.g, index.buckets,
-                                           index.n_buckets, k, thr, flag.as<uint8_t>(), local.as<float4>(), c->stream));
+                                           index.n_buckets, k, thr, flag.as<uint8_t>(), local.as<float4>(), c->stream, gp));
             }
-            unsigned ibits = 0;
-            const unsigned kbits = knn_sorted_queue_bits(index.g, n, &ibits);      // 0: the keys do not fit, phase 2 walks the queue in scan order
             if (kbits) {
                 // phase 2 on a queue sorted by cell (round 4): one host round trip for the undecided count (four kNN stages per step)
                 DevBuf pos(c, n * 4), count(c, 4);
@@ -158,7 +162,7 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
                 ProfScope ps(c, "knn_query_p2", 0.0, 0.0);
                 DevBuf q1(c, n * 8);
                 LTM_HIP(knn_two_phase_compact_keyed(s.d, s.off_dev, kf_begin, kf_end, first, n, p.pose_dev, c->B2L, c->b2l_identity, index.g, ibits, flag.as<uint8_t>(),
-                                                    pos.as<uint32_t>(), q1.as<uint64_t>(), count.as<uint32_t>(), temp.p, tb, c->stream));
+                                                    pos.as<uint32_t>(), q1.as<uint64_t>(), count.as<uint32_t>(), temp.p, tb, c->stream, gp));
                 uint32_t und = 0;
                 d2h(c, &und, count.p, 4);
                 if (c->prof_on) {      // the exact search's own floor: every undecided query is read again and must see its k neighbours (SURVEY 8d's per-query bytes)
@@ -169,7 +173,7 @@ int ltm_knn_partition(ltm_ctx* c, ltm_cloud htarget, ltm_scanset hs, ltm_poses h
                     DevBuf q2(c, (size_t)und * 8);
                     LTM_HIP(knn_two_phase_exact_sorted(s.d, s.off_dev, kf_begin, kf_end, first, p.pose_dev, c->B2L, c->b2l_identity, index.sorted, index.Mt, index.g, index.table,
                                                        index.mask, index.bitmap, index.bitmap_mask, k, thr, index.cell2_lo, flag.as<uint8_t>(), q1.as<uint64_t>(), q2.as<uint64_t>(),
-                                                       und, ibits, kbits, temp.p, tb, c->stream));
+                                                       und, ibits, kbits, temp.p, tb, c->stream, gp));
                 }
                 if (c->knn_stats_on) { c->knn_undecided += und; c->knn_queries += n; }
             } else {

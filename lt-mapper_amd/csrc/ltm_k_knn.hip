@@ -429,7 +429,7 @@ __global__ void __launch_bounds__(kBlock)
 k_knn_fast(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, uint64_t first_pt,
            const double* __restrict__ poses, const double* __restrict__ inv_poses, HostMat34 b2l_h, KnnGrid g,
            const KnnBucketRaw* __restrict__ buckets, uint32_t n_buckets, float cell_m, float dist_slack, float k_thr_lo,
-           uint8_t* __restrict__ coexist, float4* __restrict__ local_out)
+           uint8_t* __restrict__ coexist, float4* __restrict__ local_out, float4* __restrict__ gp_undecided)
 {
     const size_t kf = kb + blockIdx.y;
     const uint64_t a = offsets[kf], local = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -442,7 +442,10 @@ k_knn_fast(const float4* __restrict__ scans, const uint64_t* __restrict__ offset
     float3 l = xform(load_mat(inv_poses + 12 * kf), gp);                               // :603-604
     if (B2L_IDENTITY) l = xform_identity(l); else l = xform(to_dev(b2l_h), l);
     local_out[i] = make_float4(l.x, l.y, l.z, p4.w);
-    coexist[i] = (uint8_t)knn_bucket_coexist<KT>(gp.x, gp.y, gp.z, g, buckets, n_buckets, cell_m, dist_slack, k_thr_lo);      // 2 = undecided
+    const uint8_t f = (uint8_t)knn_bucket_coexist<KT>(gp.x, gp.y, gp.z, g, buckets, n_buckets, cell_m, dist_slack, k_thr_lo);      // 2 = undecided
+    coexist[i] = f;
+    // phase 2 starts from this point instead of finding the keyframe (nine dependent loads), the scan point and the pose again (round 6)
+    if (gp_undecided && f == 2) gp_undecided[i] = make_float4(gp.x, gp.y, gp.z, 0.0f);
 }
 
 // queue[pos[i]] = i for the undecided queries (pos = exclusive scan of flag == 2); *count = their number
@@ -480,7 +483,7 @@ struct FlagUndecided { __host__ __device__ uint32_t operator()(uint8_t v) const 
 
 hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
                               const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity, KnnGrid g, const void* buckets,
-                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s)
+                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s, float4* gp_undecided)
 {
     if (!n_pts || !max_kf_pts) return hipSuccess;
     if (k < 1 || k > 4) return hipErrorInvalidValue;
@@ -492,7 +495,7 @@ hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, 
         for (size_t k0 = kb; k0 < ke; k0 += 65535) {
             const size_t k1 = std::min(ke, k0 + 65535);
             k_knn_fast<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(grid_for(max_kf_pts), (unsigned)(k1 - k0)), dim3(kBlock), 0, s>>>(
-                scans, offsets_dev, k0, first_pt, poses_dev, inv_poses_dev, b2l, g, bk, n_buckets, cell_m, dist_slack, k_thr_lo, coexist, local_out);
+                scans, offsets_dev, k0, first_pt, poses_dev, inv_poses_dev, b2l, g, bk, n_buckets, cell_m, dist_slack, k_thr_lo, coexist, local_out, gp_undecided);
         }
     };
     auto by_kt = [&](auto b2l_tag) {
@@ -546,18 +549,22 @@ template <bool B2L_IDENTITY>
 __global__ void __launch_bounds__(kBlock)
 k_knn_queue_scatter_keyed(const uint8_t* __restrict__ flag, const uint32_t* __restrict__ pos, uint64_t n, const float4* __restrict__ scans,
                           const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt, const double* __restrict__ poses, HostMat34 b2l_h, KnnGrid g,
-                          unsigned ibits, uint64_t* __restrict__ queue, uint32_t* __restrict__ count)
+                          unsigned ibits, uint64_t* __restrict__ queue, uint32_t* __restrict__ count, const float4* __restrict__ gp_undecided)
 {
     const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     const bool und = flag[i] == 2;
     if (und) {
-        const uint64_t gi = first_pt + i;
-        const size_t kf = find_kf(offsets, kb, ke, gi);
-        const float4 p4 = scans[gi];
-        float3 p = make_float3(p4.x, p4.y, p4.z);
-        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
-        const float3 gp = xform(load_mat(poses + 12 * kf), p);
+        float3 gp;
+        if (gp_undecided) { const float4 v = gp_undecided[i]; gp = make_float3(v.x, v.y, v.z); }      // what phase 1 computed for this query
+        else {
+            const uint64_t gi = first_pt + i;
+            const size_t kf = find_kf(offsets, kb, ke, gi);
+            const float4 p4 = scans[gi];
+            float3 p = make_float3(p4.x, p4.y, p4.z);
+            if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+            gp = xform(load_mat(poses + 12 * kf), p);
+        }
         // undecided queries lie inside the grid (phase 1 answered the others): the same cell arithmetic as knn_near / knn_bucket_coexist
         const double fx = floor(((double)gp.x - g.ox) * g.inv_cell), fy = floor(((double)gp.y - g.oy) * g.inv_cell), fz = floor(((double)gp.z - g.oz) * g.inv_cell);
         const uint64_t cx = (uint64_t)min(max((long long)fx, 0ll), g.nx - 1), cy = (uint64_t)min(max((long long)fy, 0ll), g.ny - 1), cz = (uint64_t)min(max((long long)fz, 0ll), g.nz - 1);
@@ -571,16 +578,20 @@ __global__ void __launch_bounds__(kBlock)
 k_knn_slow_sorted(const float4* __restrict__ scans, const uint64_t* __restrict__ offsets, size_t kb, size_t ke, uint64_t first_pt,
                   const double* __restrict__ poses, HostMat34 b2l_h, const float4* __restrict__ tgt, size_t Mt, KnnGrid g,
                   const HashEntry* __restrict__ table, uint32_t mask, const unsigned long long* __restrict__ bitmap, uint32_t bitmap_mask, int k, float thr, float cell2_lo,
-                  const uint64_t* __restrict__ queue, uint32_t n, uint64_t imask, uint8_t* __restrict__ coexist)
+                  const uint64_t* __restrict__ queue, uint32_t n, uint64_t imask, uint8_t* __restrict__ coexist, const float4* __restrict__ gp_undecided)
 {
     for (uint32_t q = blockIdx.x * blockDim.x + threadIdx.x; q < n; q += gridDim.x * blockDim.x) {
         const uint64_t i = queue[q] & imask;
-        const uint64_t gi = first_pt + i;
-        const size_t kf = find_kf(offsets, kb, ke, gi);
-        const float4 p4 = scans[gi];
-        float3 p = make_float3(p4.x, p4.y, p4.z);
-        if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
-        const float3 gp = xform(load_mat(poses + 12 * kf), p);
+        float3 gp;
+        if (gp_undecided) { const float4 v = gp_undecided[i]; gp = make_float3(v.x, v.y, v.z); }
+        else {
+            const uint64_t gi = first_pt + i;
+            const size_t kf = find_kf(offsets, kb, ke, gi);
+            const float4 p4 = scans[gi];
+            float3 p = make_float3(p4.x, p4.y, p4.z);
+            if (B2L_IDENTITY) p = xform_identity(p); else p = xform(to_dev(b2l_h), p);
+            gp = xform(load_mat(poses + 12 * kf), p);
+        }
         coexist[i] = knn_near<KT>(gp.x, gp.y, gp.z, tgt, Mt, g, table, mask, k, thr, cell2_lo, bitmap, bitmap_mask) ? 1 : 0;
     }
 }
@@ -596,20 +607,20 @@ unsigned knn_sorted_queue_bits(KnnGrid g, uint64_t n_pts, unsigned* ibits_out)
 }
 hipError_t knn_two_phase_compact_keyed(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, const double* poses_dev,
                                        HostMat34 b2l, int b2l_identity, KnnGrid g, unsigned ibits, const uint8_t* flags, uint32_t* pos, uint64_t* queue, uint32_t* count,
-                                       void* temp, size_t temp_bytes, hipStream_t s)
+                                       void* temp, size_t temp_bytes, hipStream_t s, const float4* gp_undecided)
 {
     if (!n_pts) return hipMemsetAsync(count, 0, 4, s);
     auto it = rocprim::make_transform_iterator(flags, FlagUndecided());
     hipError_t e = rocprim::exclusive_scan(temp, temp_bytes, it, pos, 0u, n_pts, rocprim::plus<uint32_t>(), s);
     if (e != hipSuccess) return e;
-    if (b2l_identity) k_knn_queue_scatter_keyed<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(flags, pos, n_pts, scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, g, ibits, queue, count);
-    else k_knn_queue_scatter_keyed<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(flags, pos, n_pts, scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, g, ibits, queue, count);
+    if (b2l_identity) k_knn_queue_scatter_keyed<true><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(flags, pos, n_pts, scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, g, ibits, queue, count, gp_undecided);
+    else k_knn_queue_scatter_keyed<false><<<dim3(grid_for(n_pts)), dim3(kBlock), 0, s>>>(flags, pos, n_pts, scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, g, ibits, queue, count, gp_undecided);
     return hipGetLastError();
 }
 hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, const double* poses_dev, HostMat34 b2l,
                                       int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask, const void* bitmap,
                                       uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist, const uint64_t* queue_in, uint64_t* queue_sorted, uint32_t n_und,
-                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s)
+                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s, const float4* gp_undecided)
 {
     if (!n_und) return hipSuccess;
     if (k < 1 || k > 4 || Mt < (size_t)k) return hipErrorInvalidValue;
@@ -620,7 +631,7 @@ hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offse
     auto slow = [&](auto b2l_tag, auto kt_tag) {
         k_knn_slow_sorted<decltype(b2l_tag)::value, decltype(kt_tag)::value><<<dim3(blocks), dim3(kBlock), 0, s>>>(
             scans, offsets_dev, kb, ke, first_pt, poses_dev, b2l, sorted_target, Mt, g, table, table_mask, reinterpret_cast<const unsigned long long*>(bitmap), bitmap_mask, k, thr,
-            cell2_lo, queue_sorted, n_und, imask, coexist);
+            cell2_lo, queue_sorted, n_und, imask, coexist, gp_undecided);
     };
     auto by_kt = [&](auto b2l_tag) {
         switch (k) {

@@ -200,7 +200,8 @@ hipError_t knn_bitmap_build(const uint64_t* sorted_keys, const uint32_t* starts,
 // phase 1: local_out for every query, coexist[i] = 1 (certainly coexist) / 0 (certainly diff: outside the grid) / 2 (undecided)
 hipError_t knn_two_phase_fast(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, uint64_t max_kf_pts,
                               const double* poses_dev, const double* inv_poses_dev, HostMat34 b2l, int b2l_identity, KnnGrid g, const void* buckets,
-                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s);
+                              uint32_t n_buckets, int k, float thr, uint8_t* coexist, float4* local_out, hipStream_t s,
+                              float4* gp_undecided = nullptr);      // gp_undecided[i] = the query's global point where coexist[i] == 2: phase 2 starts from it
 // phase 2: the undecided queries are compacted (scan + scatter) and searched exactly; *count = their number
 hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts,
                                const double* poses_dev, HostMat34 b2l, int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g,
@@ -210,11 +211,11 @@ hipError_t knn_two_phase_exact(const float4* scans, const uint64_t* offsets_dev,
 unsigned knn_sorted_queue_bits(KnnGrid g, uint64_t n_pts, unsigned* ibits_out);
 hipError_t knn_two_phase_compact_keyed(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, uint64_t n_pts, const double* poses_dev,
                                        HostMat34 b2l, int b2l_identity, KnnGrid g, unsigned ibits, const uint8_t* flags, uint32_t* pos, uint64_t* queue, uint32_t* count,
-                                       void* temp, size_t temp_bytes, hipStream_t s);
+                                       void* temp, size_t temp_bytes, hipStream_t s, const float4* gp_undecided = nullptr);
 hipError_t knn_two_phase_exact_sorted(const float4* scans, const uint64_t* offsets_dev, size_t kb, size_t ke, uint64_t first_pt, const double* poses_dev, HostMat34 b2l,
                                       int b2l_identity, const float4* sorted_target, size_t Mt, KnnGrid g, const HashEntry* table, uint32_t table_mask, const void* bitmap,
                                       uint32_t bitmap_mask, int k, float thr, float cell2_lo, uint8_t* coexist, const uint64_t* queue_in, uint64_t* queue_sorted, uint32_t n_und,
-                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s);
+                                      unsigned ibits, unsigned kbits, void* temp, size_t temp_bytes, hipStream_t s, const float4* gp_undecided = nullptr);
 hipError_t knn_query_cloud(const float4* query, size_t Q, const float4* sorted_target, size_t Mt, KnnGrid g,
                            const HashEntry* table, uint32_t table_mask, int k, float thr, float cell2_lo,
                            uint8_t* near, hipStream_t s);
